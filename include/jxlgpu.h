@@ -1,0 +1,277 @@
+/*
+ * jxlgpu.h — C ABI of libjxlgpu.so, the MI355X (gfx950) implementation of jxl-oxide's
+ * per-group transform-and-render hot path.
+ *
+ * The reference (tirr-c/jxl-oxide, pure Rust) has no FFI of its own.  This header declares the
+ * entry points a Rust `extern "C"` block would bind at the two seams where the reference hands
+ * entropy-decoded state to its per-group CPU workers:
+ *
+ *   - VarDCT : jxl-render/src/vardct/mod.rs:316  ("Dequant and transform", the
+ *              `pool.for_each_vec(groups)` loop) plus the LF prologue at :164-204, the restoration
+ *              filters at jxl-render/src/render.rs:76-131 and the colour transform at
+ *              jxl-render/src/lib.rs:925-998.
+ *   - Modular: jxl-render/src/modular.rs:134 (`modular_image.prepare_subimage().finish(pool)`),
+ *              jxl-render/src/image.rs:148-189 (XYB dequant) and the same filters / colour tail.
+ *
+ * Everything is POD: plain pointers, sizes and scalars; no C++/torch types.  All functions return
+ * JXLGPU_OK (0) or a negative error code and never throw or abort across the boundary
+ * (the reference's convention is `Result<T, jxl_render::Error>`, jxl-render/src/error.rs).
+ *
+ * Threading: a `jxlgpu_ctx` owns one HIP stream and may be used from one thread at a time; create
+ * one ctx per rendering thread (the reference renders keyframes from arbitrary rayon workers,
+ * jxl-oxide-cli/src/decode.rs:293-304).  There is no global state.
+ */
+#ifndef JXLGPU_H_
+#define JXLGPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JXLGPU_ABI_VERSION 3u
+
+/* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
+#define JXLGPU_OK 0
+#define JXLGPU_ERR_INVALID_ARG (-1) /* malformed descriptor (maps to a panic/assert in the reference) */
+#define JXLGPU_ERR_OOM (-2)         /* device or pinned allocation failed (jxl_grid::OutOfMemory)     */
+#define JXLGPU_ERR_DEVICE (-3)      /* HIP runtime error; jxlgpu_last_error() has the text             */
+#define JXLGPU_ERR_UNSUPPORTED (-4) /* valid JPEG XL, but outside this library's scope (caller falls   */
+                                    /* back to the CPU path): jpeg_upsampling != 0, LF frames, ...     */
+#define JXLGPU_ERR_ABI (-5)         /* desc->abi != JXLGPU_ABI_VERSION                                  */
+
+typedef struct jxlgpu_ctx jxlgpu_ctx;     /* device + stream + scratch arena          */
+typedef struct jxlgpu_frame jxlgpu_frame; /* one frame's device-resident decode state */
+
+/* ---- TransformType, numbering of jxl-vardct/src/dct_select.rs:4-32 ---- */
+enum {
+    JXLGPU_DCT8 = 0, JXLGPU_HORNUSS, JXLGPU_DCT2, JXLGPU_DCT4, JXLGPU_DCT16, JXLGPU_DCT32,
+    JXLGPU_DCT16X8, JXLGPU_DCT8X16, JXLGPU_DCT32X8, JXLGPU_DCT8X32, JXLGPU_DCT32X16,
+    JXLGPU_DCT16X32, JXLGPU_DCT4X8, JXLGPU_DCT8X4, JXLGPU_AFV0, JXLGPU_AFV1, JXLGPU_AFV2,
+    JXLGPU_AFV3, JXLGPU_DCT64, JXLGPU_DCT64X32, JXLGPU_DCT32X64, JXLGPU_DCT128,
+    JXLGPU_DCT128X64, JXLGPU_DCT64X128, JXLGPU_DCT256, JXLGPU_DCT256X128, JXLGPU_DCT128X256,
+    JXLGPU_NUM_TRANSFORMS = 27
+};
+/* BlockInfo (jxl-vardct/src/hf_metadata.rs:39-50) flattened to one byte per 8x8 cell:
+ * 0..26 = Data{dct_select}, with hf_mul in the parallel int32 array.                      */
+#define JXLGPU_BLOCK_OCCUPIED 0xFEu
+#define JXLGPU_BLOCK_UNINIT 0xFFu
+
+/* Sample type of integer planes (`S: Sample`, jxl-modular/src/sample.rs). */
+#define JXLGPU_SAMPLE_I32 0u
+#define JXLGPU_SAMPLE_I16 1u
+
+/* ---- restoration filters (jxl-frame/src/filter.rs:6-202) ---- */
+typedef struct {
+    uint32_t gab_enabled;      /* Gabor::Enabled                                              */
+    float gab_weights[3][2];   /* per channel [w0 (side), w1 (diag)], filter.rs:12-16          */
+    uint32_t epf_iters;        /* 0 = EdgePreservingFilter::Disabled, else 1..3                */
+    float epf_channel_scale[3];
+    float epf_pass0_sigma_scale, epf_pass2_sigma_scale, epf_border_sad_mul; /* EpfSigma        */
+    float epf_sigma_for_modular; /* sigma used where no HfMetadata sigma grid exists           */
+} JxlGpuFilterParams;
+
+/* ---- colour transform XYB -> display (jxl-color/src/convert.rs:208-549 op list) ---- */
+#define JXLGPU_TF_LINEAR 0u
+#define JXLGPU_TF_SRGB 1u
+#define JXLGPU_TF_PQ 2u
+#define JXLGPU_TF_BT709 3u
+#define JXLGPU_TF_GAMMA 4u
+#define JXLGPU_TF_HLG 5u
+typedef struct {
+    uint32_t enabled;          /* 0: leave XYB (save_before_ct / stage tests)                   */
+    float opsin_bias[3];       /* OpsinInverseMatrix.opsin_bias, jxl-image/src/color.rs:620      */
+    float intensity_target;    /* ToneMapping.intensity_target                                  */
+    float matrix[9];           /* merged Matrix op after XybToMixedLms (convert.rs:661-690):     */
+                               /* opsin inv_mat, or  target_primaries * inv_mat                  */
+    uint32_t gamut_map;        /* insert GamutMap{luminances, saturation_factor} before matrix2  */
+    float gamut_luminances[3];
+    float gamut_saturation_factor;
+    uint32_t has_matrix2;      /* second Matrix op (after GamutMap)                              */
+    float matrix2[9];
+    uint32_t transfer_function;/* JXLGPU_TF_*                                                    */
+    float gamma;               /* for JXLGPU_TF_GAMMA                                            */
+    float hlg_luminances[3];   /* for JXLGPU_TF_HLG inverse OOTF                                 */
+} JxlGpuColorParams;
+
+/* ---- non-separable upsampling (jxl-render/src/features/upsampling.rs) ---- */
+typedef struct {
+    uint32_t factor;           /* 1, 2, 4 or 8 (frame_header.upsampling)                         */
+    const float* up2_weight;   /* 15 floats,  ImageMetadata.up2_weight (jxl-image/src/lib.rs:164) */
+    const float* up4_weight;   /* 55 floats                                                       */
+    const float* up8_weight;   /* 210 floats                                                      */
+} JxlGpuUpsampling;
+
+/* ---- one LF group's decoded state (jxl-frame LfGroup + jxl-vardct HfMetadata) ---- */
+typedef struct {
+    uint32_t width_px, height_px; /* LF group size in colour samples (<= group_dim*8)            */
+    /* LfCoeff.lf_quant image channels in the reference's channel order [0]=Y,[1]=X,[2]=B
+     * (jxl-render/src/util.rs:275-298); ceil(width_px/8) x ceil(height_px/8), tight stride.     */
+    const void* lf_quant[3];
+    uint32_t extra_precision;     /* LfCoeff.extra_precision (0..3)                               */
+    uint32_t has_hf_meta;         /* LfGroup.hf_meta.is_some()                                    */
+    const uint8_t* block_kind;    /* bw*bh cells, see JXLGPU_BLOCK_*                              */
+    const int32_t* hf_mul;        /* bw*bh, valid where block_kind <= 26                          */
+    const float* epf_sigma;       /* bw*bh (HfMetadata.epf_sigma)                                 */
+    const int32_t* x_from_y;      /* ceil(width_px/64) x ceil(height_px/64)                       */
+    const int32_t* b_from_y;
+} JxlGpuLfGroup;
+
+/* Stage mask for jxlgpu_*_render: lets the parity tests stop after any stage. */
+#define JXLGPU_STAGE_LF 0x01u        /* V1-V3: LF dequant, CfL-LF, adaptive smoothing              */
+#define JXLGPU_STAGE_TRANSFORM 0x02u /* V4-V8: dequant, CfL-HF, LLF injection, inverse transforms   */
+#define JXLGPU_STAGE_GABOR 0x04u
+#define JXLGPU_STAGE_EPF 0x08u
+#define JXLGPU_STAGE_UPSAMPLE 0x10u
+#define JXLGPU_STAGE_COLOR 0x20u
+#define JXLGPU_STAGE_ALL 0x3Fu
+
+typedef struct {
+    uint32_t abi;                 /* = JXLGPU_ABI_VERSION                                         */
+    uint32_t width, height;       /* frame_header.color_sample_width()/height()                   */
+    uint32_t group_dim;           /* frame_header.group_dim(); only 256 is supported              */
+    uint32_t lf_sample_type;      /* JXLGPU_SAMPLE_* of lf_quant                                   */
+    uint32_t jpeg_upsampling[3];  /* must be 0 (else JXLGPU_ERR_UNSUPPORTED)                       */
+    /* HF coefficients as `write_hf_coeff` leaves them (jxl-vardct/src/hf_coeff.rs:207-244):
+     * planes in framebuffer order [0]=X,[1]=Y,[2]=B, width_rounded x height_rounded (ceil to 8),
+     * row stride `coeff_stride` elements (jxl-render/src/vardct/mod.rs:206-222, 262-265).         */
+    const int32_t* coeff[3];
+    uint32_t coeff_stride;
+    uint32_t num_lf_groups;       /* frame_header.num_lf_groups(), raster order                    */
+    const JxlGpuLfGroup* lf_groups;
+    /* Quantizer / LfChannelDequantization / LfChannelCorrelation (jxl-vardct/src/lf.rs:11-34) */
+    uint32_t global_scale, quant_lf;
+    float m_lf[3];                /* m_x_lf, m_y_lf, m_b_lf                                        */
+    uint32_t colour_factor;
+    float base_correlation_x, base_correlation_b;
+    uint32_t x_factor_lf, b_factor_lf;
+    uint32_t x_qm_scale, b_qm_scale; /* frame_header, jxl-frame/src/header.rs:32-39                */
+    float quant_bias[3];          /* OpsinInverseMatrix, jxl-image/src/color.rs:621-626            */
+    float quant_bias_numerator;
+    uint32_t skip_adaptive_lf_smoothing; /* frame_header.flags                                      */
+    /* DequantMatrixSet (jxl-vardct/src/dequant.rs:661-716): for every TransformType and channel
+     * the matrix *as applied* at jxl-render/src/vardct/mod.rs:516-520 — i.e. `get_transposed()`
+     * when `need_transpose()`, else `get()` — raster order, (8*bw) x (8*bh) floats.               */
+    const float* dequant[JXLGPU_NUM_TRANSFORMS][3];
+    /* sec_half(n) tables for n = 64,128,256 (jxl-render/src/vardct/dct_common.rs:52-70): the
+     * reference computes them at run time with f32 cos(); pass them so both sides agree
+     * bit-for-bit.  NULL = library computes them with cosf().                                      */
+    const float* sec_half_large[3];
+    JxlGpuFilterParams filter;
+    JxlGpuUpsampling upsampling;
+    JxlGpuColorParams color;
+} JxlGpuVardctDesc;
+
+/* Output planes.  `planes[c]` are caller-owned f32 buffers of `height_out` rows with row stride
+ * `stride` elements (an `AlignedGrid<f32>` backing store: tight stride = width).  `mem` says
+ * whether the pointers are host or device memory.                                               */
+#define JXLGPU_MEM_HOST 0u
+#define JXLGPU_MEM_DEVICE 1u
+typedef struct {
+    float* planes[3];
+    uint32_t stride;
+    uint32_t mem;
+} JxlGpuOut;
+
+/* ---- context ---- */
+int jxlgpu_create(int device, jxlgpu_ctx** out_ctx);
+void jxlgpu_destroy(jxlgpu_ctx* ctx);
+const char* jxlgpu_last_error(const jxlgpu_ctx* ctx);
+uint32_t jxlgpu_abi_version(void);
+/* Block until everything queued on the ctx's stream has finished. */
+int jxlgpu_synchronize(jxlgpu_ctx* ctx);
+/* The ctx's hipStream_t (so callers can record HIP events around launches). */
+void* jxlgpu_stream(jxlgpu_ctx* ctx);
+
+/* ---- VarDCT ---- */
+/* Copy one frame's decoded state to the device (H2D on the ctx stream, asynchronous for pinned
+ * sources) and build the device-side tables.  The descriptor and everything it points to may be
+ * released as soon as the call returns.                                                          */
+int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* desc, jxlgpu_frame** out_frame);
+/* Run the selected stages on the device.  `out` may be NULL (results stay in the frame's device
+ * buffers, e.g. for benchmarking); otherwise the result of the last selected stage is written to
+ * `out` (D2H copy for JXLGPU_MEM_HOST, followed by a stream synchronisation).                     */
+int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* frame, uint32_t stages, const JxlGpuOut* out);
+/* upload + render(stages) + free in one call: the drop-in for `render_vardct` + filters + colour. */
+int jxlgpu_vardct_render_host(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* desc, uint32_t stages,
+                              const JxlGpuOut* out);
+void jxlgpu_frame_free(jxlgpu_ctx* ctx, jxlgpu_frame* frame);
+/* Dimensions of the output of `stages` for this frame (upsampling changes them). */
+int jxlgpu_frame_out_size(const jxlgpu_frame* frame, uint32_t stages, uint32_t* width, uint32_t* height);
+/* Device pointer to the result of the last render (plane c), for device-side consumers
+ * (RCCL gather in the multi-GPU path).  Valid until the next render/free on this frame.            */
+const float* jxlgpu_frame_result_plane(const jxlgpu_frame* frame, uint32_t c);
+/* Intermediate buffers for stage-level parity tests: the LF image after V1-V3 (3 planes,
+ * ceil(width/8) x ceil(height/8)).  Copies to host.                                                */
+int jxlgpu_frame_download_lf(jxlgpu_ctx* ctx, const jxlgpu_frame* frame, float* const planes[3]);
+
+/* Bytes the algorithm must move per render for the given stages (compulsory HBM traffic:
+ * coefficient read + final write + side data), used by bench.py for the roofline.                 */
+uint64_t jxlgpu_frame_algorithmic_bytes(const jxlgpu_frame* frame, uint32_t stages);
+
+/* ---- Modular (inverse transforms after the per-group entropy decode) ---- */
+#define JXLGPU_TR_RCT 0u
+#define JXLGPU_TR_PALETTE 1u
+#define JXLGPU_TR_SQUEEZE 2u
+/* One squeeze step (jxl-modular/src/transform.rs:125-137 SqueezeParams). */
+typedef struct {
+    uint32_t horizontal, in_place, begin_c, num_c;
+} JxlGpuSqueezeStep;
+/* TransformInfo (jxl-modular/src/transform.rs:19-23). */
+typedef struct {
+    uint32_t kind;               /* JXLGPU_TR_*                                                    */
+    /* Rct */
+    uint32_t begin_c, rct_type;
+    /* Palette */
+    uint32_t num_c, nb_colours, nb_deltas, d_pred;
+    int32_t wp_params[9];        /* WpHeader p1..p3[5], w[4] when d_pred == 6 (unsupported: slow path) */
+    /* Squeeze: explicit steps (after set_default_params, transform.rs:285-341) */
+    uint32_t num_sq;
+    const JxlGpuSqueezeStep* sq;
+} JxlGpuTransform;
+
+/* One channel of the *untransformed* image: a full-resolution buffer that holds, after the
+ * entropy decode, the transformed sub-channels carved as sub-rectangles exactly as
+ * `transform_channel_info` carves them (jxl-modular/src/transform.rs:343-437,
+ * jxl-modular/src/image.rs:209-371).                                                               */
+typedef struct {
+    const void* data;            /* width*height samples, tight stride                              */
+    uint32_t width, height;
+} JxlGpuModularChannel;
+
+typedef struct {
+    uint32_t abi;
+    uint32_t sample_type;        /* JXLGPU_SAMPLE_I16 / I32 (modular_16bit_buffers)                  */
+    uint32_t bit_depth;          /* bits_per_sample (palette delta scaling, int->float)              */
+    uint32_t num_channels;       /* colour channels first (1 or 3), then extra channels              */
+    const JxlGpuModularChannel* channels;
+    uint32_t num_meta_channels;  /* palette meta channels, in the order the inverse pops them         */
+    const JxlGpuModularChannel* meta_channels;
+    uint32_t num_transforms;     /* in bitstream order; the inverse runs them in reverse             */
+    const JxlGpuTransform* transforms;
+    /* what happens after the inverse transforms (jxl-render/src/image.rs:93-189) */
+    uint32_t xyb_encoded;        /* 1: convert_modular_xyb (M5); 0: int -> float by bit depth (C5)    */
+    float m_lf_unscaled[3];      /* m_x_lf/128, m_y_lf/128, m_b_lf/128 (lf.rs:37-50)                  */
+    uint32_t float_sample;       /* BitDepth::FloatSample (exp_bits), 0 = integer                     */
+    uint32_t exp_bits;
+    JxlGpuFilterParams filter;
+    JxlGpuUpsampling upsampling;
+    JxlGpuColorParams color;
+} JxlGpuModularDesc;
+
+#define JXLGPU_STAGE_MODULAR_INVERSE 0x02u /* same bit as TRANSFORM: inverse Squeeze/RCT/Palette    */
+#define JXLGPU_STAGE_MODULAR_TO_FLOAT 0x40u /* M5 / C5                                              */
+
+int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* desc, jxlgpu_frame** out_frame);
+/* Integer result of the inverse transforms (bit-exact contract), copied to host buffers of the
+ * frame's sample type: `planes[c]` has channels[c].width*height samples.                            */
+int jxlgpu_modular_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* frame, void* const* planes_or_null);
+/* Inverse transforms + int->float + filters + upsampling + colour, like jxlgpu_vardct_render.       */
+int jxlgpu_modular_render(jxlgpu_ctx* ctx, jxlgpu_frame* frame, uint32_t stages, const JxlGpuOut* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXLGPU_H_ */

@@ -1,0 +1,580 @@
+// Host side of libjxlgpu.so: the C ABI of include/jxlgpu.h.  Uploads one frame's decoded state,
+// builds the per-shape varblock work lists (the device-side replacement for the reference's
+// serial `for_each_varblocks` scan, jxl-render/src/vardct/mod.rs:693-730) and sequences the
+// kernels on the context's HIP stream.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "common.h"
+
+void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
+                       float* const out[3], uint32_t out_stride, bool gabor, int epf_iters, bool color);
+bool fused_post_supported(const jxlgpu_frame* f, bool gabor, int epf_iters);
+
+namespace {
+
+// TransformType -> (bw, bh), jxl-vardct/src/dct_select.rs:52-76
+const uint8_t kSize[27][2] = {{1, 1}, {1, 1}, {1, 1}, {1, 1}, {2, 2}, {4, 4}, {1, 2}, {2, 1}, {1, 4},
+                              {4, 1}, {2, 4}, {4, 2}, {1, 1}, {1, 1}, {1, 1}, {1, 1}, {1, 1}, {1, 1},
+                              {8, 8}, {4, 8}, {8, 4}, {16, 16}, {8, 16}, {16, 8}, {32, 32}, {16, 32}, {32, 16}};
+
+int class_of(int t) {
+    switch (t) {
+        case JXLGPU_DCT8: return CLS_DCT8;
+        case JXLGPU_HORNUSS: case JXLGPU_DCT2: case JXLGPU_DCT4: case JXLGPU_DCT4X8: case JXLGPU_DCT8X4:
+        case JXLGPU_AFV0: case JXLGPU_AFV1: case JXLGPU_AFV2: case JXLGPU_AFV3: return CLS_SPECIAL8;
+        case JXLGPU_DCT16: return CLS_16x16;
+        case JXLGPU_DCT16X8: return CLS_8x16;
+        case JXLGPU_DCT8X16: return CLS_16x8;
+        case JXLGPU_DCT32: return CLS_32x32;
+        case JXLGPU_DCT32X8: return CLS_8x32;
+        case JXLGPU_DCT8X32: return CLS_32x8;
+        case JXLGPU_DCT32X16: return CLS_16x32;
+        case JXLGPU_DCT16X32: return CLS_32x16;
+        case JXLGPU_DCT64: return CLS_64x64;
+        case JXLGPU_DCT64X32: return CLS_32x64;
+        case JXLGPU_DCT32X64: return CLS_64x32;
+        default: return CLS_BIG;
+    }
+}
+
+// compiler-rt __powisf2: what Rust's f32::powi lowers to (vardct/mod.rs:458-462)
+float powi_f32(float a, int b) {
+    const bool recip = b < 0;
+    float r = 1.0f;
+    for (;;) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1.0f / r : r;
+}
+
+template <typename T>
+int dev_alloc(jxlgpu_ctx* ctx, jxlgpu_frame* f, T** out, size_t count) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    HIP_TRY(ctx, hipMalloc(&p, bytes));
+    f->allocs.push_back(p);
+    *out = static_cast<T*>(p);
+    return JXLGPU_OK;
+}
+
+template <typename T>
+int dev_upload(jxlgpu_ctx* ctx, jxlgpu_frame* f, T** out, const std::vector<T>& host) {
+    int rc = dev_alloc(ctx, f, out, host.size());
+    if (rc) return rc;
+    if (!host.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    // pageable source: the runtime stages the copy before returning, `host` may die afterwards
+    return JXLGPU_OK;
+}
+
+#define TRY(expr)                 \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != JXLGPU_OK) return rc_; \
+    } while (0)
+
+int fail(jxlgpu_ctx* ctx, int code, const char* msg) {
+    ctx->last_error = msg;
+    return code;
+}
+
+void fill_color_args(const JxlGpuColorParams& cp, ColorArgs* c) {
+    memset(c, 0, sizeof(*c));
+    for (int i = 0; i < 3; ++i) {
+        c->opsin_bias[i] = cp.opsin_bias[i];
+        c->cbrt_opsin_bias[i] = cbrtf(cp.opsin_bias[i]);  // xyb.rs:42, once per frame on the host
+        c->gamut_lum[i] = cp.gamut_luminances[i];
+    }
+    c->itscale = 255.0f / cp.intensity_target;
+    c->intensity_target = cp.intensity_target;
+    memcpy(c->matrix, cp.matrix, sizeof(c->matrix));
+    memcpy(c->matrix2, cp.matrix2, sizeof(c->matrix2));
+    c->gamut_map = cp.gamut_map;
+    c->gamut_sat = cp.gamut_saturation_factor;
+    c->has_matrix2 = cp.has_matrix2;
+    c->tf = cp.transfer_function;
+}
+
+// upsample_inner's weights_quarter (features/upsampling.rs:77-93)
+std::vector<float> expand_up_weights(const float* weights, int k) {
+    int mat_n = k / 2;
+    std::vector<float> wq((size_t)mat_n * mat_n * 25, 0.0f);
+    size_t idx = 0;
+    for (int y = 0; y < 5 * mat_n; ++y) {
+        int mat_y = y / 5, ky = y % 5;
+        for (int x = y; x < 5 * mat_n; ++x) {
+            int mat_x = x / 5, kx = x % 5;
+            float w = weights[idx++];
+            wq[(size_t)(mat_y * mat_n + mat_x) * 25 + ky * 5 + kx] = w;
+            wq[(size_t)(mat_x * mat_n + mat_y) * 25 + kx * 5 + ky] = w;
+        }
+    }
+    return wq;
+}
+
+}  // namespace
+
+int upload_post_params(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuUpsampling& up) {
+    const float* src[3] = {up.up2_weight, up.up4_weight, up.up8_weight};
+    const int ks[3] = {2, 4, 8};
+    for (int i = 0; i < 3; ++i) {
+        if (!src[i]) continue;
+        std::vector<float> wq = expand_up_weights(src[i], ks[i]);
+        TRY(dev_upload(ctx, f, &f->up_weights[i], wq));
+    }
+    return JXLGPU_OK;
+}
+
+extern "C" {
+
+uint32_t jxlgpu_abi_version(void) { return JXLGPU_ABI_VERSION; }
+
+int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
+    if (!out_ctx) return JXLGPU_ERR_INVALID_ARG;
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return JXLGPU_ERR_DEVICE;
+    jxlgpu_ctx* ctx = new (std::nothrow) jxlgpu_ctx();
+    if (!ctx) return JXLGPU_ERR_OOM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return JXLGPU_ERR_DEVICE;
+    }
+    *out_ctx = ctx;
+    return JXLGPU_OK;
+}
+
+void jxlgpu_destroy(jxlgpu_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    delete ctx;
+}
+
+const char* jxlgpu_last_error(const jxlgpu_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
+
+int jxlgpu_synchronize(jxlgpu_ctx* ctx) {
+    if (!ctx) return JXLGPU_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return JXLGPU_OK;
+}
+
+void* jxlgpu_stream(jxlgpu_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+void jxlgpu_frame_free(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
+    if (!f) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    for (void* p : f->allocs) (void)hipFree(p);
+    delete f;
+}
+
+int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_frame** out_frame) {
+    if (!ctx || !d || !out_frame) return JXLGPU_ERR_INVALID_ARG;
+    *out_frame = nullptr;
+    if (d->abi != JXLGPU_ABI_VERSION) return fail(ctx, JXLGPU_ERR_ABI, "descriptor ABI version mismatch");
+    if (d->jpeg_upsampling[0] | d->jpeg_upsampling[1] | d->jpeg_upsampling[2])
+        return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "chroma-subsampled (jpeg_upsampling != 0) frames stay on the CPU path");
+    if (d->group_dim != 256) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "only group_dim == 256 is supported");
+    if (d->width == 0 || d->height == 0 || d->width > (1u << 18) || d->height > (1u << 18))
+        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "bad frame size");
+    if (d->global_scale == 0 || d->quant_lf == 0 || d->colour_factor == 0)
+        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "zero quantizer / colour_factor");
+    if (d->filter.epf_iters > 3) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "epf_iters > 3");
+    const uint32_t upf = d->upsampling.factor ? d->upsampling.factor : 1;
+    if (upf != 1 && upf != 2 && upf != 4 && upf != 8) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "bad upsampling factor");
+    for (int c = 0; c < 3; ++c)
+        if (!d->coeff[c]) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null coefficient plane");
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    jxlgpu_frame* f = new (std::nothrow) jxlgpu_frame();
+    if (!f) return JXLGPU_ERR_OOM;
+    struct Guard {
+        jxlgpu_ctx* c; jxlgpu_frame* f; bool armed = true;
+        ~Guard() { if (armed) jxlgpu_frame_free(c, f); }
+    } guard{ctx, f};
+
+    f->desc = *d;
+    f->width = d->width; f->height = d->height;
+    f->w8 = ceil_div(d->width, 8); f->h8 = ceil_div(d->height, 8);
+    f->wr = f->w8 * 8; f->hr = f->h8 * 8;
+    f->w64 = ceil_div(d->width, 64); f->h64 = ceil_div(d->height, 64);
+    f->group_dim = d->group_dim;
+    const uint32_t lf_dim = d->group_dim * 8;
+    f->lf_groups_per_row = ceil_div(d->width, lf_dim);
+    const uint32_t lf_rows = ceil_div(d->height, lf_dim);
+    f->num_lf_groups = f->lf_groups_per_row * lf_rows;
+    if (d->num_lf_groups != f->num_lf_groups || !d->lf_groups)
+        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "num_lf_groups does not match the frame size");
+    if (d->coeff_stride < f->wr) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "coeff_stride < width_rounded");
+
+    const size_t ncell = (size_t)f->w8 * f->h8, ntile = (size_t)f->w64 * f->h64;
+    const size_t npix = (size_t)f->wr * f->hr;
+    const bool i16 = d->lf_sample_type == JXLGPU_SAMPLE_I16;
+    f->lf_is_i16 = i16;
+
+    // ---- assemble frame-level side planes from the per-LF-group grids
+    std::vector<uint8_t> kind(ncell, JXLGPU_BLOCK_UNINIT);
+    std::vector<int32_t> hf_mul(ncell, 0);
+    std::vector<float> sigma(ncell, d->filter.epf_sigma_for_modular);
+    std::vector<float> kx_map(ntile, 0.0f), kb_map(ntile, 0.0f);
+    std::vector<float> lf_scale((size_t)f->num_lf_groups * 3, 0.0f);
+    std::vector<uint8_t> lfq_host[3];
+    const size_t lf_elem = i16 ? 2 : 4;
+    for (int c = 0; c < 3; ++c) lfq_host[c].assign(ncell * lf_elem, 0);
+    std::vector<uint8_t> has_meta(f->num_lf_groups, 0);
+
+    const uint64_t scale_inv = (uint64_t)d->global_scale * (uint64_t)d->quant_lf;
+    for (uint32_t g = 0; g < f->num_lf_groups; ++g) {
+        const JxlGpuLfGroup& lg = d->lf_groups[g];
+        const uint32_t gx = g % f->lf_groups_per_row, gy = g / f->lf_groups_per_row;
+        const uint32_t exp_w = std::min(lf_dim, d->width - gx * lf_dim), exp_h = std::min(lf_dim, d->height - gy * lf_dim);
+        if (lg.width_px != exp_w || lg.height_px != exp_h)
+            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "LF group size does not match the frame geometry");
+        if (lg.extra_precision > 3) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "extra_precision > 3");
+        const uint32_t bw = ceil_div(lg.width_px, 8), bh = ceil_div(lg.height_px, 8);
+        const uint32_t cw = ceil_div(lg.width_px, 64), ch = ceil_div(lg.height_px, 64);
+        const size_t cell0 = (size_t)gy * d->group_dim * f->w8 + (size_t)gx * d->group_dim;
+        // copy_lf_dequant scale (vardct/mod.rs:398-400), f64 on the host exactly as the reference
+        const int32_t precision_scale = 1 << (9 - lg.extra_precision);
+        for (int c = 0; c < 3; ++c)
+            lf_scale[(size_t)g * 3 + c] = (float)((double)d->m_lf[c] * (double)precision_scale / (double)scale_inv);
+        // util.rs:275-298: lf_x <- channel 1, lf_y <- channel 0, lf_b <- channel 2
+        static const int SRC[3] = {1, 0, 2};
+        for (int c = 0; c < 3; ++c) {
+            const uint8_t* src = static_cast<const uint8_t*>(lg.lf_quant[SRC[c]]);
+            if (!src) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null lf_quant");
+            for (uint32_t y = 0; y < bh; ++y)
+                memcpy(&lfq_host[c][(cell0 + (size_t)y * f->w8) * lf_elem], src + (size_t)y * bw * lf_elem, bw * lf_elem);
+        }
+        if (!lg.has_hf_meta) continue;
+        if (!lg.block_kind || !lg.hf_mul || !lg.x_from_y || !lg.b_from_y)
+            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "HfMetadata pointers missing");
+        has_meta[g] = 1;
+        for (uint32_t y = 0; y < bh; ++y)
+            for (uint32_t x = 0; x < bw; ++x) {
+                const size_t o = cell0 + (size_t)y * f->w8 + x;
+                kind[o] = lg.block_kind[(size_t)y * bw + x];
+                hf_mul[o] = lg.hf_mul[(size_t)y * bw + x];
+                if (lg.epf_sigma) sigma[o] = lg.epf_sigma[(size_t)y * bw + x];
+            }
+        const size_t t0 = (size_t)gy * (lf_dim / 64) * f->w64 + (size_t)gx * (lf_dim / 64);
+        for (uint32_t y = 0; y < ch; ++y)
+            for (uint32_t x = 0; x < cw; ++x) {
+                // chroma_from_luma_hf_grouped, vardct/mod.rs:590-593
+                kx_map[t0 + (size_t)y * f->w64 + x] =
+                    d->base_correlation_x + ((float)lg.x_from_y[(size_t)y * cw + x] / (float)d->colour_factor);
+                kb_map[t0 + (size_t)y * f->w64 + x] =
+                    d->base_correlation_b + ((float)lg.b_from_y[(size_t)y * cw + x] / (float)d->colour_factor);
+            }
+    }
+
+    // ---- varblock work lists, one per shape class, ordered by 256x256 group then raster
+    std::vector<uint32_t> lists[CLS_COUNT];
+    std::vector<uint32_t> nometa;
+    const uint32_t gcells = d->group_dim / 8;
+    const uint32_t groups_x = ceil_div(d->width, d->group_dim), groups_y = ceil_div(d->height, d->group_dim);
+    for (uint32_t gy = 0; gy < groups_y; ++gy)
+        for (uint32_t gx = 0; gx < groups_x; ++gx) {
+            const uint32_t lfg = (gy / 8) * f->lf_groups_per_row + gx / 8;
+            if (!has_meta[lfg]) {
+                nometa.push_back(gy * groups_x + gx);
+                continue;
+            }
+            const uint32_t x1 = std::min(f->w8, (gx + 1) * gcells), y1 = std::min(f->h8, (gy + 1) * gcells);
+            for (uint32_t y = gy * gcells; y < y1; ++y)
+                for (uint32_t x = gx * gcells; x < x1; ++x) {
+                    const uint8_t t = kind[(size_t)y * f->w8 + x];
+                    if (t > 26) continue;
+                    const uint32_t bw = kSize[t][0], bh = kSize[t][1];
+                    // hf_metadata.rs:144-158: a varblock never crosses a group; keep the device safe
+                    if (x + bw > x1 || y + bh > y1) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "varblock crosses a group border");
+                    if (hf_mul[(size_t)y * f->w8 + x] <= 0) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "non-positive HfMul");
+                    if (!d->dequant[t][0] || !d->dequant[t][1] || !d->dequant[t][2])
+                        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "missing dequant matrix for a used transform");
+                    lists[class_of(t)].push_back(x | (y << 16));
+                }
+        }
+
+    // ---- dequant matrices (only the types that appear), flat, 16-byte aligned offsets
+    std::vector<float> deq;
+    std::vector<uint32_t> deq_off(27 * 3, 0);
+    {
+        bool used[27] = {};
+        for (size_t i = 0; i < ncell; ++i)
+            if (kind[i] <= 26) used[kind[i]] = true;
+        for (int t = 0; t < 27; ++t) {
+            if (!used[t]) continue;
+            const size_t n = (size_t)kSize[t][0] * 8 * kSize[t][1] * 8;
+            for (int c = 0; c < 3; ++c) {
+                deq_off[t * 3 + c] = (uint32_t)deq.size();
+                deq.insert(deq.end(), d->dequant[t][c], d->dequant[t][c] + n);
+                f->deq_off_host[t][c] = deq_off[t * 3 + c];
+            }
+        }
+    }
+
+    // ---- device buffers + H2D
+    for (int c = 0; c < 3; ++c) {
+        TRY(dev_alloc(ctx, f, &f->coeff[c], npix));
+        HIP_TRY(ctx, hipMemcpy2DAsync(f->coeff[c], (size_t)f->wr * 4, d->coeff[c], (size_t)d->coeff_stride * 4,
+                                      (size_t)f->wr * 4, f->hr, hipMemcpyHostToDevice, ctx->stream));
+        uint8_t* p = nullptr;
+        TRY(dev_upload(ctx, f, &p, lfq_host[c]));
+        f->lfq[c] = p;
+        TRY(dev_alloc(ctx, f, &f->lf_a[c], ncell));
+        TRY(dev_alloc(ctx, f, &f->lf[c], ncell));
+        TRY(dev_alloc(ctx, f, &f->pix[c], npix));
+        TRY(dev_alloc(ctx, f, &f->buf_a[c], npix));
+        TRY(dev_alloc(ctx, f, &f->buf_b[c], npix));
+    }
+    TRY(dev_upload(ctx, f, &f->kind, kind));
+    TRY(dev_upload(ctx, f, &f->hf_mul, hf_mul));
+    TRY(dev_upload(ctx, f, &f->sigma, sigma));
+    TRY(dev_upload(ctx, f, &f->kx_map, kx_map));
+    TRY(dev_upload(ctx, f, &f->kb_map, kb_map));
+    TRY(dev_upload(ctx, f, &f->lf_scale, lf_scale));
+    TRY(dev_upload(ctx, f, &f->dequant, deq));
+    TRY(dev_upload(ctx, f, &f->deq_off, deq_off));
+    for (int cls = 0; cls < CLS_COUNT; ++cls) {
+        f->list_count[cls] = (uint32_t)lists[cls].size();
+        if (!lists[cls].empty()) TRY(dev_upload(ctx, f, &f->lists[cls], lists[cls]));
+    }
+    f->nometa_count = (uint32_t)nometa.size();
+    if (!nometa.empty()) TRY(dev_upload(ctx, f, &f->nometa_groups, nometa));
+    if (f->list_count[CLS_BIG]) TRY(dev_alloc(ctx, f, &f->big_tmp, npix * 3));
+
+    // sec_half(64/128/256): dct_common.rs:56-66
+    for (int i = 0, n = 64; i < 3; ++i, n *= 2) {
+        std::vector<float> tbl(n / 2);
+        if (d->sec_half_large[i]) {
+            memcpy(tbl.data(), d->sec_half_large[i], sizeof(float) * (n / 2));
+        } else {
+            for (int k = 0; k < n / 2; ++k) {
+                float theta = (float)(2 * k + 1) / (float)(2 * n) * 3.14159265358979323846f;
+                tbl[k] = (1.0f / cosf(theta)) / 2.0f;
+            }
+        }
+        TRY(dev_upload(ctx, f, &f->sec[i], tbl));
+    }
+
+    if (upf > 1) {
+        const uint32_t ow = d->width * upf, oh = d->height * upf;
+        for (int c = 0; c < 3; ++c) {
+            TRY(dev_alloc(ctx, f, &f->up[c], (size_t)ow * oh));
+            if (upf == 8) continue;
+        }
+        TRY(upload_post_params(ctx, f, d->upsampling));
+        const int need = upf == 2 ? 0 : upf == 4 ? 1 : 2;
+        if (!f->up_weights[need]) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "upsampling weights missing");
+    }
+
+    // ---- per-frame scalars
+    f->qm_scale[0] = powi_f32(0.8f, (int)d->x_qm_scale - 2);
+    f->qm_scale[1] = 1.0f;
+    f->qm_scale[2] = powi_f32(0.8f, (int)d->b_qm_scale - 2);
+    {   // chroma_from_luma_lf, vardct/mod.rs:557-560
+        int32_t x_factor = (int32_t)d->x_factor_lf - 128, b_factor = (int32_t)d->b_factor_lf - 128;
+        f->kx_lf = d->base_correlation_x + ((float)x_factor / (float)d->colour_factor);
+        f->kb_lf = d->base_correlation_b + ((float)b_factor / (float)d->colour_factor);
+    }
+    for (int c = 0; c < 3; ++c) f->lf_div[c] = (float)(512.0 * (double)d->m_lf[c] / (double)scale_inv);
+    fill_color_args(d->color, &f->color);
+
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // descriptor memory may be released now
+    // pointers inside the descriptor copy are dead from here on
+    for (int c = 0; c < 3; ++c) f->desc.coeff[c] = nullptr;
+    f->desc.lf_groups = nullptr;
+    memset(f->desc.dequant, 0, sizeof(f->desc.dequant));
+    guard.armed = false;
+    *out_frame = f;
+    return JXLGPU_OK;
+}
+
+int jxlgpu_frame_out_size(const jxlgpu_frame* f, uint32_t stages, uint32_t* width, uint32_t* height) {
+    if (!f) return JXLGPU_ERR_INVALID_ARG;
+    uint32_t k = 1;
+    if (f->kind_of_frame == 0) k = (stages & JXLGPU_STAGE_UPSAMPLE) && f->desc.upsampling.factor > 1 ? f->desc.upsampling.factor : 1;
+    if (width) *width = f->width * k;
+    if (height) *height = f->height * k;
+    return JXLGPU_OK;
+}
+
+const float* jxlgpu_frame_result_plane(const jxlgpu_frame* f, uint32_t c) {
+    return (f && c < 3) ? f->result[c] : nullptr;
+}
+
+uint64_t jxlgpu_frame_algorithmic_bytes(const jxlgpu_frame* f, uint32_t stages) {
+    if (!f) return 0;
+    uint32_t ow = 0, oh = 0;
+    jxlgpu_frame_out_size(f, stages, &ow, &oh);
+    const uint64_t ncell = (uint64_t)f->w8 * f->h8;
+    uint64_t bytes = 0;
+    if (stages & JXLGPU_STAGE_TRANSFORM) bytes += (uint64_t)f->wr * f->hr * 12;   // 3 x i32 coefficients
+    bytes += (uint64_t)ow * oh * 12;                                              // 3 x f32 result
+    bytes += ncell * (3 * (f->lf_is_i16 ? 2 : 4) + 1 + 4);                        // LF quant, BlockInfo, hf_mul
+    if (stages & JXLGPU_STAGE_EPF) bytes += ncell * 4;                            // sigma
+    bytes += (uint64_t)f->w64 * f->h64 * 8;                                       // CfL maps
+    return bytes;
+}
+
+int jxlgpu_frame_download_lf(jxlgpu_ctx* ctx, const jxlgpu_frame* f, float* const planes[3]) {
+    if (!ctx || !f || !planes) return JXLGPU_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const float* const* src = f->desc.skip_adaptive_lf_smoothing ? f->lf_a : f->lf;
+    for (int c = 0; c < 3; ++c)
+        if (planes[c])
+            HIP_TRY(ctx, hipMemcpyAsync(planes[c], src[c], (size_t)f->w8 * f->h8 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return JXLGPU_OK;
+}
+
+}  // extern "C"
+
+// Gabor -> EPF -> upsample -> colour on device planes; shared by the VarDCT and Modular paths.
+// `cur` holds W x H samples with stride `*cur_stride`; on return it points at the result.
+int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuFilterParams& fp,
+                    uint32_t up_factor, float* cur[3], uint32_t* cur_stride, uint32_t* ow, uint32_t* oh) {
+    hipStream_t s = ctx->stream;
+    const uint32_t W = f->width, H = f->height;
+    const bool do_gab = (stages & JXLGPU_STAGE_GABOR) && fp.gab_enabled;
+    const int epf_iters = (stages & JXLGPU_STAGE_EPF) ? (int)fp.epf_iters : 0;
+    const bool do_up = (stages & JXLGPU_STAGE_UPSAMPLE) && up_factor > 1;
+    const bool do_color = (stages & JXLGPU_STAGE_COLOR) && f->desc.color.enabled;
+
+    // Fast path: everything after the transform in one tile kernel (fused_kernels.hip)
+    if ((do_gab || epf_iters) && fused_post_supported(f, do_gab, epf_iters)) {
+        const float* in[3] = {cur[0], cur[1], cur[2]};
+        float** dst = (cur[0] == f->buf_a[0]) ? f->buf_b : f->buf_a;
+        launch_fused_post(s, f, in, *cur_stride, dst, f->wr, do_gab, epf_iters, do_color && !do_up);
+        for (int c = 0; c < 3; ++c) cur[c] = dst[c];
+        *cur_stride = f->wr;
+        if (do_color && !do_up) {
+            *ow = W; *oh = H;
+            return JXLGPU_OK;
+        }
+    } else {
+        auto other = [&](float* const* now) { return now[0] == f->buf_a[0] ? f->buf_b : f->buf_a; };
+        FilterArgs fa;
+        fa.width = W; fa.height = H;
+        fa.sigma = f->sigma; fa.sigma_stride = f->w8;
+        fa.fp = fp;
+        auto run = [&](int what, int step) {
+            float** dst = other(cur);
+            for (int c = 0; c < 3; ++c) { fa.in[c] = cur[c]; fa.out[c] = dst[c]; }
+            fa.in_stride = *cur_stride; fa.out_stride = f->wr;
+            if (what == 0) launch_gabor(s, fa); else launch_epf(s, step, fa);
+            for (int c = 0; c < 3; ++c) cur[c] = dst[c];
+            *cur_stride = f->wr;
+        };
+        if (do_gab) run(0, 0);
+        if (epf_iters == 3) run(1, 0);   // filter/epf.rs:44-93: step 0 only for iters == 3
+        if (epf_iters >= 1) run(1, 1);
+        if (epf_iters >= 2) run(1, 2);
+    }
+    *ow = W; *oh = H;
+    if (do_up) {
+        // features/upsampling.rs:18-41: 8x passes first, then the 2x / 4x remainder
+        const int log2f = up_factor == 2 ? 1 : up_factor == 4 ? 2 : 3;
+        const int k = log2f == 3 ? 8 : (log2f == 1 ? 2 : 4);
+        const float* kern = f->up_weights[k == 2 ? 0 : k == 4 ? 1 : 2];
+        for (int c = 0; c < 3; ++c) launch_upsample(s, cur[c], *cur_stride, W, H, f->up[c], W * k, k, kern);
+        for (int c = 0; c < 3; ++c) cur[c] = f->up[c];
+        *ow = W * k; *oh = H * k; *cur_stride = W * k;
+    }
+    if (do_color) launch_color(s, f->color, cur, *cur_stride, *ow, *oh);
+    return JXLGPU_OK;
+}
+
+int finish_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stride, uint32_t ow, uint32_t oh,
+                  const JxlGpuOut* out) {
+    for (int c = 0; c < 3; ++c) f->result[c] = cur[c];
+    f->result_stride = stride; f->result_w = ow; f->result_h = oh;
+    HIP_TRY(ctx, hipGetLastError());
+    if (out) {
+        if (out->stride < ow) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "output stride < output width");
+        const hipMemcpyKind kind = out->mem == JXLGPU_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        for (int c = 0; c < 3; ++c)
+            if (out->planes[c])
+                HIP_TRY(ctx, hipMemcpy2DAsync(out->planes[c], (size_t)out->stride * 4, cur[c], (size_t)stride * 4,
+                                              (size_t)ow * 4, oh, kind, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return JXLGPU_OK;
+}
+
+extern "C" {
+
+int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuOut* out) {
+    if (!ctx || !f || f->kind_of_frame != 0) return JXLGPU_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const JxlGpuVardctDesc& d = f->desc;
+
+    // ---- V1-V3
+    LfArgs la;
+    for (int c = 0; c < 3; ++c) { la.lfq[c] = f->lfq[c]; la.out[c] = f->lf_a[c]; }
+    la.is_i16 = f->lf_is_i16; la.scale = f->lf_scale;
+    la.w8 = f->w8; la.h8 = f->h8; la.lf_groups_per_row = f->lf_groups_per_row; la.group_cells = f->group_dim;
+    la.kx = f->kx_lf; la.kb = f->kb_lf;
+    launch_lf_dequant_cfl(s, la);
+    float* const* lf = f->lf_a;
+    if (!d.skip_adaptive_lf_smoothing) {
+        SmoothArgs sa;
+        for (int c = 0; c < 3; ++c) { sa.in[c] = f->lf_a[c]; sa.out[c] = f->lf[c]; sa.lf_div[c] = f->lf_div[c]; }
+        sa.w8 = f->w8; sa.h8 = f->h8;
+        launch_lf_smooth(s, sa);
+        lf = f->lf;
+    }
+    if (!(stages & JXLGPU_STAGE_TRANSFORM)) {
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        return JXLGPU_OK;
+    }
+
+    // ---- V4-V8
+    TransformArgs ta;
+    for (int c = 0; c < 3; ++c) {
+        ta.coeff[c] = f->coeff[c]; ta.pix[c] = f->pix[c]; ta.lf[c] = lf[c];
+        ta.qm_scale[c] = f->qm_scale[c]; ta.quant_bias[c] = d.quant_bias[c];
+    }
+    ta.kind = f->kind; ta.hf_mul = f->hf_mul; ta.kx_map = f->kx_map; ta.kb_map = f->kb_map;
+    ta.dequant = f->dequant; ta.deq_off = f->deq_off;
+    ta.sec64 = f->sec[0]; ta.sec128 = f->sec[1]; ta.sec256 = f->sec[2];
+    ta.cstride = f->wr; ta.pstride = f->wr; ta.w8 = f->w8; ta.h8 = f->h8; ta.w64 = f->w64;
+    ta.global_scale = (float)d.global_scale;
+    ta.quant_bias_numerator = d.quant_bias_numerator;
+    ta.big_tmp = f->big_tmp;
+    for (int cls = 0; cls < CLS_COUNT; ++cls)
+        launch_transform_class(s, cls, ta, f->lists[cls], f->list_count[cls]);
+    launch_nometa_groups(s, ta, f->nometa_groups, f->nometa_count, f->group_dim, ceil_div(f->width, f->group_dim));
+
+    float* cur[3] = {f->pix[0], f->pix[1], f->pix[2]};
+    uint32_t stride = f->wr, ow = f->width, oh = f->height;
+    TRY(run_post_stages(ctx, f, stages, d.filter, d.upsampling.factor ? d.upsampling.factor : 1, cur, &stride, &ow, &oh));
+    return finish_render(ctx, f, cur, stride, ow, oh, out);
+}
+
+int jxlgpu_vardct_render_host(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* desc, uint32_t stages, const JxlGpuOut* out) {
+    jxlgpu_frame* f = nullptr;
+    int rc = jxlgpu_vardct_upload(ctx, desc, &f);
+    if (rc != JXLGPU_OK) return rc;
+    rc = jxlgpu_vardct_render(ctx, f, stages, out);
+    jxlgpu_frame_free(ctx, f);
+    return rc;
+}
+
+}  // extern "C"

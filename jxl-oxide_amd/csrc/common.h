@@ -1,0 +1,183 @@
+// Internal definitions shared by the host API (api.hip) and the kernels.  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/jxlgpu.h"
+
+#define JXL_SQRT2F 1.41421356237309504880f
+
+// Varblock classes: one kernel instantiation per pixel shape (W x H) of the transform.
+// TransformType -> (bw, bh) follows jxl-vardct/src/dct_select.rs:52-76.
+enum VbClass : int {
+    CLS_DCT8 = 0,    // 8x8 DCT
+    CLS_SPECIAL8,    // Hornuss, Dct2, Dct4, Dct4x8, Dct8x4, Afv0-3
+    CLS_16x16,
+    CLS_8x16,        // W=8,  H=16  (Dct16x8)
+    CLS_16x8,        // W=16, H=8   (Dct8x16)
+    CLS_32x32,
+    CLS_8x32,        // Dct32x8
+    CLS_32x8,        // Dct8x32
+    CLS_16x32,       // Dct32x16
+    CLS_32x16,       // Dct16x32
+    CLS_64x64,
+    CLS_32x64,       // Dct64x32
+    CLS_64x32,       // Dct32x64
+    CLS_BIG,         // >= 128 in either dimension: global-memory two-pass path
+    CLS_COUNT
+};
+
+struct TransformArgs {
+    const int32_t* coeff[3];   // X, Y, B coefficient planes (i32), stride = cstride
+    float* pix[3];             // output planes, stride = pstride
+    const float* lf[3];        // LF planes after V1-V3, stride = w8
+    const uint8_t* kind;       // frame-level BlockInfo plane, stride w8
+    const int32_t* hf_mul;
+    const float* kx_map;       // base_correlation_x + x_from_y/colour_factor, per 64x64 tile
+    const float* kb_map;
+    const float* dequant;      // all matrices, flat
+    const uint32_t* deq_off;   // [27*3] offsets into `dequant`
+    const float* sec64;        // sec_half(64/128/256)
+    const float* sec128;
+    const float* sec256;
+    uint32_t cstride, pstride, w8, h8, w64;
+    float global_scale;        // as f32
+    float qm_scale[3];
+    float quant_bias[3];
+    float quant_bias_numerator;
+    float* big_tmp;            // 3 planes of pstride x (h8*8) scratch for the >=128 path
+};
+
+struct LfArgs {
+    const void* lfq[3];        // frame-level quantised LF planes, [0]=X,[1]=Y,[2]=B (already reordered)
+    uint32_t is_i16;
+    const float* scale;        // per LF group x 3 channels
+    float* out[3];
+    uint32_t w8, h8, lf_groups_per_row, group_cells;
+    float kx, kb;              // CfL-LF factors
+};
+
+struct SmoothArgs {
+    const float* in[3];
+    float* out[3];
+    uint32_t w8, h8;
+    float lf_div[3];           // lf_x, lf_y, lf_b (vardct/mod.rs:420-422)
+};
+
+struct PlaneSet {
+    float* p[3];
+    uint32_t stride;
+};
+
+struct FilterArgs {
+    const float* in[3];
+    float* out[3];
+    uint32_t in_stride, out_stride;
+    uint32_t width, height;
+    const float* sigma;        // per 8x8 cell, stride sigma_stride
+    uint32_t sigma_stride;
+    JxlGpuFilterParams fp;
+};
+
+struct ColorArgs {
+    float opsin_bias[3];
+    float cbrt_opsin_bias[3];
+    float itscale;
+    float intensity_target;
+    float matrix[9];
+    uint32_t gamut_map;
+    float gamut_lum[3];
+    float gamut_sat;
+    uint32_t has_matrix2;
+    float matrix2[9];
+    uint32_t tf;
+};
+
+struct jxlgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    void* pinned = nullptr;     // pinned staging buffer (grown on demand)
+    size_t pinned_size = 0;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct jxlgpu_frame {
+    int kind_of_frame = 0;      // 0 = VarDCT, 1 = Modular
+    // geometry
+    uint32_t width = 0, height = 0, w8 = 0, h8 = 0, wr = 0, hr = 0, w64 = 0, h64 = 0;
+    uint32_t group_dim = 256, lf_groups_per_row = 1, num_lf_groups = 1;
+    std::vector<void*> allocs;  // everything hipMalloc'ed for this frame
+    // VarDCT device state
+    int32_t* coeff[3] = {};
+    void* lfq[3] = {};
+    uint32_t lf_is_i16 = 0;
+    float* lf_scale = nullptr;
+    uint8_t* kind = nullptr;
+    int32_t* hf_mul = nullptr;
+    float* sigma = nullptr;
+    float* kx_map = nullptr;
+    float* kb_map = nullptr;
+    float* dequant = nullptr;
+    uint32_t* deq_off = nullptr;
+    uint32_t deq_off_host[JXLGPU_NUM_TRANSFORMS][3] = {};
+    float* sec[3] = {};
+    float* lf_a[3] = {};        // after V1+V2
+    float* lf[3] = {};          // after V3 (== lf_a when smoothing is skipped)
+    float* pix[3] = {};         // transform output, wr x hr
+    float* buf_a[3] = {};       // filter ping
+    float* buf_b[3] = {};       // filter pong
+    float* big_tmp = nullptr;  // scratch for the >=128 transform path (aliases buf_a[0])
+    float* up[3] = {};          // upsampled planes
+    float* up_tmp[3] = {};
+    uint32_t* lists[CLS_COUNT] = {};
+    uint32_t list_count[CLS_COUNT] = {};
+    bool has_no_meta_groups = false;
+    uint32_t* nometa_groups = nullptr;  // groups whose LF group has no HfMetadata
+    uint32_t nometa_count = 0;
+    // params
+    JxlGpuVardctDesc desc = {}; // scalar copy (pointers invalid after upload)
+    float qm_scale[3] = {1, 1, 1};
+    float kx_lf = 0, kb_lf = 0;
+    float lf_div[3] = {};
+    ColorArgs color = {};
+    float* up_weights[3] = {};  // expanded 5x5 kernels per phase for 2x/4x/8x
+    // result of the last render
+    const float* result[3] = {};
+    uint32_t result_stride = 0, result_w = 0, result_h = 0;
+    // modular state lives in modular.hip's own struct
+    void* modular = nullptr;
+};
+
+#define HIP_TRY(ctx, expr)                                                           \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);  \
+            return e_ == hipErrorOutOfMemory ? JXLGPU_ERR_OOM : JXLGPU_ERR_DEVICE;   \
+        }                                                                            \
+    } while (0)
+
+static inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// kernel launchers implemented in the .hip files
+void launch_lf_dequant_cfl(hipStream_t s, const LfArgs& a);
+void launch_lf_smooth(hipStream_t s, const SmoothArgs& a);
+void launch_transform_class(hipStream_t s, int cls, const TransformArgs& a, const uint32_t* list,
+                            uint32_t count);
+void launch_nometa_groups(hipStream_t s, const TransformArgs& a, const uint32_t* groups,
+                          uint32_t count, uint32_t group_dim, uint32_t groups_per_row);
+void launch_gabor(hipStream_t s, const FilterArgs& a);
+void launch_epf(hipStream_t s, int step, const FilterArgs& a);
+void launch_color(hipStream_t s, const ColorArgs& c, float* const planes[3], uint32_t stride,
+                  uint32_t width, uint32_t height);
+void launch_upsample(hipStream_t s, const float* in, uint32_t in_stride, uint32_t w, uint32_t h,
+                     float* out, uint32_t out_stride, int k, const float* kernels);

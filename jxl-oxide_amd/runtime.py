@@ -1,0 +1,98 @@
+"""Thin Python host over the C ABI (ctypes): plumbing for tests, smoke() and bench.py.
+Every call goes through libjxlgpu.so; there is no CPU fallback here."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+class JxlGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"jxlgpu error {code}: {msg}")
+        self.code = code
+
+
+class Frame:
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle = ctx, handle
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.jxlgpu_frame_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def out_size(self, stages):
+        w, h = C.c_uint32(), C.c_uint32()
+        self.ctx._check(self.ctx.lib.jxlgpu_frame_out_size(self.handle, stages, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def algorithmic_bytes(self, stages):
+        return int(self.ctx.lib.jxlgpu_frame_algorithmic_bytes(self.handle, stages))
+
+    def result_plane_ptr(self, c):
+        return C.cast(self.ctx.lib.jxlgpu_frame_result_plane(self.handle, c), C.c_void_p).value
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = abi.load_library()
+        if self.lib.jxlgpu_abi_version() != abi.ABI_VERSION:
+            raise RuntimeError("libjxlgpu.so ABI version does not match abi.py")
+        h = C.c_void_p()
+        rc = self.lib.jxlgpu_create(device, C.byref(h))
+        if rc != abi.OK:
+            raise JxlGpuError(rc, "jxlgpu_create failed (no MI355X visible?)")
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            self.lib.jxlgpu_destroy(self.handle)
+            self.handle = None
+
+    def _check(self, rc):
+        if rc != abi.OK:
+            raise JxlGpuError(rc, self.lib.jxlgpu_last_error(self.handle).decode())
+
+    def stream(self):
+        return self.lib.jxlgpu_stream(self.handle)
+
+    def synchronize(self):
+        self._check(self.lib.jxlgpu_synchronize(self.handle))
+
+    # ---- VarDCT
+    def vardct_upload(self, desc):
+        fh = C.c_void_p()
+        self._check(self.lib.jxlgpu_vardct_upload(self.handle, C.byref(desc), C.byref(fh)))
+        return Frame(self, fh)
+
+    def vardct_render(self, frame, stages, to_host=True):
+        """Runs the stages; returns planes[3][h, w] (numpy) or None when to_host is False."""
+        if not to_host:
+            self._check(self.lib.jxlgpu_vardct_render(self.handle, frame.handle, stages, None))
+            return None
+        w, h = frame.out_size(stages)
+        out = np.zeros((3, h, w), dtype=np.float32)
+        o = abi.Out()
+        for c in range(3):
+            o.planes[c] = out[c].ctypes.data_as(abi.f32p)
+        o.stride = w
+        o.mem = abi.MEM_HOST
+        self._check(self.lib.jxlgpu_vardct_render(self.handle, frame.handle, stages, C.byref(o)))
+        return out
+
+    def vardct_render_host(self, desc, stages, out_w, out_h):
+        out = np.zeros((3, out_h, out_w), dtype=np.float32)
+        o = abi.Out()
+        for c in range(3):
+            o.planes[c] = out[c].ctypes.data_as(abi.f32p)
+        o.stride = out_w
+        o.mem = abi.MEM_HOST
+        self._check(self.lib.jxlgpu_vardct_render_host(self.handle, C.byref(desc), stages, C.byref(o)))
+        return out
+
+    def download_lf(self, frame, w8, h8):
+        lf = np.zeros((3, h8, w8), dtype=np.float32)
+        arr = (abi.f32p * 3)(*[lf[c].ctypes.data_as(abi.f32p) for c in range(3)])
+        self._check(self.lib.jxlgpu_frame_download_lf(self.handle, frame.handle, arr))
+        return lf

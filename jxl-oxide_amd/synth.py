@@ -1,0 +1,297 @@
+"""Synthetic boundary-state generator: valid *post-entropy-decode* state of a JPEG XL frame.
+
+There is no JPEG XL encoder (and no fixture) in this environment, so workloads are generated at
+the device boundary exactly as SURVEY.md §8(d) specifies: coefficient planes as `write_hf_coeff`
+leaves them, varblock tilings as `HfMetadata::parse` would produce (jxl-vardct/src/
+hf_metadata.rs:55-229: raster placement, never across a 256-px group, Occupied cells, hf_mul>0,
+sigma from sharpness), LF-quant planes, CfL maps and the default dequant matrices.
+
+`VardctWorkload.desc()` builds the `JxlGpuVardctDesc` that both libjxlgpu.so and the oracle take.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .abi import DCT_SELECT_SIZE
+from .dequant import default_dequant_matrices
+
+SEED_BASE = 0x4A584C00
+
+# jxl-image/src/lib.rs:533- (data tables)
+D_UP2 = np.array([
+    -0.01716200, -0.03452303, -0.04022174, -0.02921014, -0.00624645,
+    0.14111091, 0.28896755, 0.00278718, -0.01610267, 0.56661550,
+    0.03777607, -0.01986694, -0.03144731, -0.01185068, -0.00213539], dtype=np.float32)
+
+
+def _load_up_weights():
+    import os
+    import re
+    # parsed once from the committed copy of the table (tests/golden/upsampling_weights.npz)
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = os.path.join(here, "upsampling_weights.npz")
+    z = np.load(p)
+    return z["up2"], z["up4"], z["up8"]
+
+
+# jxl-image/src/color.rs:613-627 OpsinInverseMatrix defaults
+OPSIN_INV = np.array([
+    11.031566901960783, -9.866943921568629, -0.16462299647058826,
+    -3.254147380392157, 4.418770392156863, -0.16462299647058826,
+    -3.6588512862745097, 2.7129230470588235, 1.9459282392156863], dtype=np.float32)
+OPSIN_BIAS = np.float32(-0.0037930732552754493)
+QUANT_BIAS = np.array([1.0 - 0.05465007330715401, 1.0 - 0.07005449891748593,
+                       1.0 - 0.049935103337343655], dtype=np.float32)
+QUANT_BIAS_NUMERATOR = np.float32(0.145)
+
+# cfg-2 type mix
+_MIX = [
+    (0.60, [abi.TRANSFORM_NAMES.index("Dct8")]),
+    (0.20, [abi.TRANSFORM_NAMES.index(n) for n in ("Dct16", "Dct8x16", "Dct16x8")]),
+    (0.08, [abi.TRANSFORM_NAMES.index(n) for n in ("Dct32", "Dct32x8", "Dct8x32", "Dct32x16", "Dct16x32")]),
+    (0.10, [abi.TRANSFORM_NAMES.index(n) for n in ("Dct4x8", "Dct8x4", "Dct4", "Afv0", "Afv1", "Afv2", "Afv3", "Hornuss", "Dct2")]),
+    (0.02, [abi.TRANSFORM_NAMES.index("Dct64")]),
+]
+
+
+def sec_half_large():
+    """sec_half(n) for n = 64,128,256 as jxl-render/src/vardct/dct_common.rs:56-66 computes them
+    (f32).  Generated once on the host and handed to both sides so the tables are identical."""
+    out = []
+    for n in (64, 128, 256):
+        k = np.arange(n // 2, dtype=np.float32)
+        theta = (np.float32(2) * k + np.float32(1)) / np.float32(2 * n) * np.float32(np.pi)
+        out.append(((np.float32(1.0) / np.cos(theta, dtype=np.float32)) / np.float32(2.0)).astype(np.float32))
+    return out
+
+
+def draw_tiling(rng, w8, h8, mix=_MIX, types=None, group_cells=32):
+    """Raster varblock placement, hf_metadata.rs:109-205.  Returns (kind u8[h8,w8], hf_mul i32)."""
+    kind = np.full((h8, w8), abi.BLOCK_UNINIT, dtype=np.uint8)
+    hf_mul = np.zeros((h8, w8), dtype=np.int32)
+    if types is not None:
+        cand = np.asarray(types)
+        draws = cand[rng.integers(0, len(cand), size=(h8, w8))]
+    else:
+        probs = np.array([m[0] for m in mix])
+        cls = rng.choice(len(mix), size=(h8, w8), p=probs / probs.sum())
+        sub = rng.integers(0, 1 << 16, size=(h8, w8))
+        draws = np.zeros((h8, w8), dtype=np.int64)
+        for i, (_, lst) in enumerate(mix):
+            lst = np.asarray(lst)
+            sel = cls == i
+            draws[sel] = lst[sub[sel] % len(lst)]
+    muls = rng.integers(1, 17, size=(h8, w8)).astype(np.int32)
+    occ = np.zeros((h8, w8), dtype=bool)
+    for y in range(h8):
+        x = 0
+        row_occ = occ[y]
+        while x < w8:
+            if row_occ[x]:
+                x += 1
+                continue
+            t = int(draws[y, x])
+            bw, bh = DCT_SELECT_SIZE[t]
+            if (bw > 1 or bh > 1) and (
+                (x % group_cells) + bw > group_cells or (y % group_cells) + bh > group_cells
+                or x + bw > w8 or y + bh > h8 or occ[y:y + bh, x:x + bw].any()):
+                t = 0  # falls back to Dct8 when the drawn type does not fit
+                bw = bh = 1
+            occ[y:y + bh, x:x + bw] = True
+            kind[y:y + bh, x:x + bw] = abi.BLOCK_OCCUPIED
+            kind[y, x] = t
+            hf_mul[y, x] = muls[y, x]
+            x += bw
+    return kind, hf_mul
+
+
+class VardctWorkload:
+    """Holds numpy arrays (kept alive) + builds the C descriptor."""
+
+    def __init__(self, width, height, seed=0, epf_iters=2, gabor=True, tf=abi.TF_SRGB,
+                 intensity_target=255.0, upsampling=1, types=None, lf_i16=True,
+                 zero_fraction=0.85, skip_lf_smoothing=False, hdr_pq=False, group_dim=256):
+        rng = np.random.default_rng(SEED_BASE + seed)
+        self.width, self.height = width, height
+        self.group_dim = group_dim
+        w8, h8 = -(-width // 8), -(-height // 8)
+        self.w8, self.h8 = w8, h8
+        wr, hr = w8 * 8, h8 * 8
+        self.wr, self.hr = wr, hr
+        self.global_scale = int(rng.integers(3000, 6001))
+        self.quant_lf = 16
+        self.mats = default_dequant_matrices()
+        self.sec = sec_half_large()
+
+        kind, hf_mul = draw_tiling(rng, w8, h8, types=types)
+        self.kind, self.hf_mul = kind, hf_mul
+
+        # ---- HF coefficients: Laplacian, scale ~ 1/(1+freq), ~85 % zeros, LLF corner zero
+        coeff = np.zeros((3, hr, wr), dtype=np.int32)
+        ys, xs = np.nonzero(kind <= 26)
+        tt = kind[ys, xs]
+        for t in np.unique(tt):
+            bw, bh = DCT_SELECT_SIZE[int(t)]
+            W, H = bw * 8, bh * 8
+            sel = tt == t
+            n = int(sel.sum())
+            fy = np.arange(H, dtype=np.float32)[:, None] / bh
+            fx = np.arange(W, dtype=np.float32)[None, :] / bw
+            # target dequantised amplitude per channel (X, Y, B), decaying ~ 1/(1+freq); the
+            # quantised value is that amplitude divided by the dequant step of its position
+            amp = np.array([0.002, 0.02, 0.015], dtype=np.float32)[:, None, None] / (1.0 + np.sqrt(fx * fx + fy * fy))
+            step = np.stack([self.mats[int(t)][c] for c in range(3)]) * np.float32(65536.0 / self.global_scale)
+            scale = amp / step
+            blk_mul = hf_mul[ys[sel], xs[sel]].astype(np.float32)[:, None, None, None]
+            vals = rng.laplace(0.0, 1.0, size=(n, 3, H, W)).astype(np.float32) * scale * blk_mul
+            keep = rng.random(size=(n, 3, H, W)) >= zero_fraction
+            q = np.where(keep, np.rint(vals), 0).astype(np.int32)
+            q[:, :, :bh, :bw] = 0  # LLF positions are not coded in HF (hf_coeff.rs)
+            for i, (cy, cx) in enumerate(zip(ys[sel], xs[sel])):
+                coeff[:, cy * 8:cy * 8 + H, cx * 8:cx * 8 + W] = q[i]
+        self.coeff = coeff
+
+        # ---- LF quant: blurred random image, channel order of the reference: Y, X, B
+        def smooth(amp, offset):
+            g = rng.normal(size=(h8 // 8 + 3, w8 // 8 + 3))
+            g = np.kron(g, np.ones((8, 8)))[:h8 + 8, :w8 + 8]
+            k = np.ones(9) / 9.0
+            g = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, g)
+            g = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 0, g)
+            g = g[4:4 + h8, 4:4 + w8] + 0.15 * rng.normal(size=(h8, w8))
+            return np.rint(offset + amp * g)
+        lf_dtype = np.int16 if lf_i16 else np.int32
+        self.lf_sample_type = abi.SAMPLE_I16 if lf_i16 else abi.SAMPLE_I32
+        self.lfq = [smooth(180.0, 220.0).astype(lf_dtype),   # Y
+                    smooth(60.0, 0.0).astype(lf_dtype),      # X
+                    smooth(90.0, 120.0).astype(lf_dtype)]    # B
+
+        w64, h64 = -(-width // 64), -(-height // 64)
+        self.xfy = rng.integers(-16, 17, size=(h64, w64)).astype(np.int32)
+        self.bfy = rng.integers(-16, 17, size=(h64, w64)).astype(np.int32)
+
+        # ---- EPF sigma, hf_metadata.rs:110-115,160-161,200-210
+        self.epf_iters = epf_iters
+        sharp_lut = (np.arange(8, dtype=np.float32) / np.float32(7.0)).astype(np.float32)
+        sharp_lut[7] = 1.0
+        sharpness = rng.integers(0, 8, size=(h8, w8))
+        quant_mul = np.float32(0.46) * np.float32(65536.0) / np.float32(self.global_scale)
+        owner_mul = np.zeros((h8, w8), dtype=np.float32)
+        for (cy, cx) in zip(ys, xs):
+            bw, bh = DCT_SELECT_SIZE[int(kind[cy, cx])]
+            owner_mul[cy:cy + bh, cx:cx + bw] = hf_mul[cy, cx]
+        self.sigma = ((quant_mul / owner_mul).astype(np.float32) * sharp_lut[sharpness]).astype(np.float32)
+
+        self.filter = abi.FilterParams()
+        self.filter.gab_enabled = 1 if gabor else 0
+        for c in range(3):
+            self.filter.gab_weights[c][0] = 0.115169525
+            self.filter.gab_weights[c][1] = 0.061248592
+        self.filter.epf_iters = epf_iters
+        self.filter.epf_channel_scale[:] = [40.0, 5.0, 3.5]
+        self.filter.epf_pass0_sigma_scale = 0.9
+        self.filter.epf_pass2_sigma_scale = 6.5
+        self.filter.epf_border_sad_mul = 2.0 / 3.0
+        self.filter.epf_sigma_for_modular = 1.0
+
+        self.color = abi.ColorParams()
+        self.color.enabled = 1
+        self.color.opsin_bias[:] = [OPSIN_BIAS] * 3
+        self.color.intensity_target = intensity_target
+        self.color.matrix[:] = list(OPSIN_INV)
+        self.color.transfer_function = tf
+        if hdr_pq:
+            # Appendix C of SURVEY.md: XYB -> linear sRGB -> GamutMap -> Rec.2020 -> PQ
+            self.color.gamut_map = 1
+            self.color.gamut_luminances[:] = [0.2126, 0.7152, 0.0722]
+            self.color.gamut_saturation_factor = 0.3
+            self.color.has_matrix2 = 1
+            self.color.matrix2[:] = [0.6274039, 0.3292830, 0.0433131,
+                                     0.0690973, 0.9195404, 0.0113623,
+                                     0.0163914, 0.0880133, 0.8955953]
+            self.color.transfer_function = abi.TF_PQ
+
+        self.up_factor = upsampling
+        self.up_w = None
+        if upsampling > 1:
+            self.up_w = _load_up_weights()
+
+        self.x_qm_scale = 3
+        self.b_qm_scale = 2
+        self.skip_lf_smoothing = skip_lf_smoothing
+        self._keep = []
+
+    # ---- descriptor
+    def desc(self):
+        d = abi.VardctDesc()
+        d.abi = abi.ABI_VERSION
+        d.width, d.height = self.width, self.height
+        d.group_dim = self.group_dim
+        d.lf_sample_type = self.lf_sample_type
+        for c in range(3):
+            d.coeff[c] = self.coeff[c].ctypes.data_as(abi.i32p)
+        d.coeff_stride = self.wr
+        lf_dim = self.group_dim * 8
+        gx_n, gy_n = -(-self.width // lf_dim), -(-self.height // lf_dim)
+        groups = (abi.LfGroup * (gx_n * gy_n))()
+        cells = self.group_dim
+        tiles = lf_dim // 64
+        keep = []
+        for gy in range(gy_n):
+            for gx in range(gx_n):
+                g = groups[gy * gx_n + gx]
+                wpx = min(lf_dim, self.width - gx * lf_dim)
+                hpx = min(lf_dim, self.height - gy * lf_dim)
+                g.width_px, g.height_px = wpx, hpx
+                bw, bh = -(-wpx // 8), -(-hpx // 8)
+                cw, ch = -(-wpx // 64), -(-hpx // 64)
+                sl = (slice(gy * cells, gy * cells + bh), slice(gx * cells, gx * cells + bw))
+                tl = (slice(gy * tiles, gy * tiles + ch), slice(gx * tiles, gx * tiles + cw))
+                arrs = dict(
+                    lfq=[np.ascontiguousarray(p[sl]) for p in self.lfq],
+                    kind=np.ascontiguousarray(self.kind[sl]),
+                    mul=np.ascontiguousarray(self.hf_mul[sl]),
+                    sigma=np.ascontiguousarray(self.sigma[sl]),
+                    xfy=np.ascontiguousarray(self.xfy[tl]),
+                    bfy=np.ascontiguousarray(self.bfy[tl]),
+                )
+                keep.append(arrs)
+                for c in range(3):
+                    g.lf_quant[c] = arrs["lfq"][c].ctypes.data
+                g.extra_precision = (gx + gy) % 2  # exercise per-LF-group precision
+                g.has_hf_meta = 1
+                g.block_kind = arrs["kind"].ctypes.data_as(abi.u8p)
+                g.hf_mul = arrs["mul"].ctypes.data_as(abi.i32p)
+                g.epf_sigma = arrs["sigma"].ctypes.data_as(abi.f32p)
+                g.x_from_y = arrs["xfy"].ctypes.data_as(abi.i32p)
+                g.b_from_y = arrs["bfy"].ctypes.data_as(abi.i32p)
+        d.num_lf_groups = gx_n * gy_n
+        d.lf_groups = C.cast(groups, C.POINTER(abi.LfGroup))
+        d.global_scale, d.quant_lf = self.global_scale, self.quant_lf
+        d.m_lf[:] = [1.0 / 32.0, 1.0 / 4.0, 1.0 / 2.0]
+        d.colour_factor = 84
+        d.base_correlation_x, d.base_correlation_b = 0.0, 1.0
+        d.x_factor_lf, d.b_factor_lf = 126, 131
+        d.x_qm_scale, d.b_qm_scale = self.x_qm_scale, self.b_qm_scale
+        d.quant_bias[:] = list(QUANT_BIAS)
+        d.quant_bias_numerator = QUANT_BIAS_NUMERATOR
+        d.skip_adaptive_lf_smoothing = 1 if self.skip_lf_smoothing else 0
+        for t in range(abi.NUM_TRANSFORMS):
+            for c in range(3):
+                d.dequant[t][c] = self.mats[t][c].ctypes.data_as(abi.f32p)
+        for i in range(3):
+            d.sec_half_large[i] = self.sec[i].ctypes.data_as(abi.f32p)
+        d.filter = self.filter
+        d.color = self.color
+        d.upsampling.factor = self.up_factor
+        if self.up_w is not None:
+            d.upsampling.up2_weight = self.up_w[0].ctypes.data_as(abi.f32p)
+            d.upsampling.up4_weight = self.up_w[1].ctypes.data_as(abi.f32p)
+            d.upsampling.up8_weight = self.up_w[2].ctypes.data_as(abi.f32p)
+        self._keep = [groups, keep]
+        return d
+
+    def out_size(self, stages):
+        f = self.up_factor if (stages & abi.STAGE_UPSAMPLE) else 1
+        return self.width * f, self.height * f

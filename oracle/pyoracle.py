@@ -1,0 +1,81 @@
+"""ORACLE — test infrastructure only.  ctypes access to oracle/_build/liboracle.so (the plain-C
+restatement of the reference's generic CPU path).  Import this only from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liboracle.so")
+f32p = C.POINTER(C.c_float)
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
+            for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = C.CDLL(_LIB)
+        _lib.orc_dct_1d.argtypes = [f32p, f32p, C.c_size_t, C.c_int]
+        _lib.orc_dct_2d.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+        _lib.orc_sec_half.restype = f32p
+        _lib.orc_sec_half.argtypes = [C.c_size_t]
+        _lib.orc_set_sec_half_large.argtypes = [C.c_size_t, f32p]
+        _lib.orc_transform_block.argtypes = [f32p, C.c_size_t, C.c_int]
+        _lib.orc_inject_llf.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, C.c_int]
+        _lib.jxl_oracle_vardct_render.restype = C.c_int
+        _lib.jxl_oracle_vardct_render.argtypes = [C.c_void_p, C.c_uint32, f32p * 3, C.c_uint32, f32p * 3]
+        _lib.orc_gabor_plane.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
+        _lib.orc_upsample_inner.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_int, f32p]
+        _lib.orc_color_transform.argtypes = [f32p * 3, C.c_size_t, C.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(f32p)
+
+
+def dct_1d(x, forward):
+    io = np.ascontiguousarray(x, dtype=np.float32).copy()
+    scratch = np.zeros_like(io)
+    lib().orc_dct_1d(_p(io), _p(scratch), io.size, 1 if forward else 0)
+    return io
+
+
+def dct_2d(x, forward):
+    io = np.ascontiguousarray(x, dtype=np.float32).copy()
+    h, w = io.shape
+    lib().orc_dct_2d(_p(io), w, w, h, 1 if forward else 0)
+    return io
+
+
+def transform_block(coeff, dct_select):
+    io = np.ascontiguousarray(coeff, dtype=np.float32).copy()
+    lib().orc_transform_block(_p(io), io.shape[1], dct_select)
+    return io
+
+
+def vardct_render(desc, stages, out_w, out_h, want_lf=False, w8=0, h8=0):
+    """Returns (planes[3][h,w] or None, lf[3][h8,w8] or None)."""
+    out = np.zeros((3, out_h, out_w), dtype=np.float32)
+    outp = (f32p * 3)(*[_p(out[c]) for c in range(3)])
+    lf = None
+    lfp = (f32p * 3)()
+    if want_lf:
+        lf = np.zeros((3, h8, w8), dtype=np.float32)
+        lfp = (f32p * 3)(*[_p(lf[c]) for c in range(3)])
+    rc = lib().jxl_oracle_vardct_render(C.byref(desc), stages, outp, out_w, lfp)
+    if rc != 0:
+        raise RuntimeError(f"oracle vardct_render failed: {rc}")
+    return out, lf

@@ -1,0 +1,120 @@
+"""GPU parity: libjxlgpu.so (through the C ABI) vs the CPU oracle on the same seeded synthetic
+frames.  North-star tolerance for float VarDCT is 1 ULP; the kernels are built to be bit-exact
+against the oracle, so the asserted bound is MAX_ULP = 1 and the observed value is normally 0."""
+import numpy as np
+import pytest
+
+from jxl_oxide_amd import abi
+from jxl_oxide_amd.synth import VardctWorkload
+from util import assert_ulp
+
+pytestmark = pytest.mark.gpu
+MAX_ULP = 1  # tolerance stated by BASELINE.json's north_star for float VarDCT
+
+S_LF = abi.STAGE_LF
+S_TR = S_LF | abi.STAGE_TRANSFORM
+S_GAB = S_TR | abi.STAGE_GABOR
+S_EPF = S_GAB | abi.STAGE_EPF
+S_ALL = abi.STAGE_ALL
+
+
+def _both(gpu_ctx, oracle, wl, stages):
+    d = wl.desc()
+    ow, oh = wl.out_size(stages)
+    exp, _ = oracle.vardct_render(d, stages, ow, oh)
+    frame = gpu_ctx.vardct_upload(d)
+    try:
+        got = gpu_ctx.vardct_render(frame, stages)
+    finally:
+        frame.free()
+    return got, exp
+
+
+def test_lf_stage(gpu_ctx, oracle):
+    wl = VardctWorkload(520, 264, seed=1)
+    d = wl.desc()
+    _, lf_exp = oracle.vardct_render(d, S_LF, wl.width, wl.height, want_lf=True, w8=wl.w8, h8=wl.h8)
+    frame = gpu_ctx.vardct_upload(d)
+    try:
+        gpu_ctx.vardct_render(frame, S_LF, to_host=False)
+        lf = gpu_ctx.download_lf(frame, wl.w8, wl.h8)
+    finally:
+        frame.free()
+    assert_ulp(lf, lf_exp, 0, "LF image (V1-V3)")
+
+
+@pytest.mark.parametrize("t", list(range(27)))
+def test_each_transform_type(gpu_ctx, oracle, t):
+    bw, bh = abi.DCT_SELECT_SIZE[t]
+    w = max(64, bw * 8 * 2 + 8)
+    h = max(64, bh * 8 * 2 + 8)
+    w, h = min(w, 256 + 64), min(h, 256 + 64)
+    wl = VardctWorkload(w, h, seed=100 + t, types=[t], zero_fraction=0.5)
+    assert (wl.kind == t).any(), "generator placed no block of this type"
+    got, exp = _both(gpu_ctx, oracle, wl, S_TR)
+    assert_ulp(got, exp, MAX_ULP, f"transform {abi.TRANSFORM_NAMES[t]}")
+
+
+@pytest.mark.parametrize("size", [(8, 8), (9, 7), (24, 40), (255, 257), (300, 520)])
+def test_ragged_sizes_all_stages(gpu_ctx, oracle, size):
+    w, h = size
+    wl = VardctWorkload(w, h, seed=7 + w)
+    for stages, name in ((S_TR, "transform"), (S_GAB, "gabor"), (S_EPF, "epf"), (S_ALL, "colour")):
+        got, exp = _both(gpu_ctx, oracle, wl, stages)
+        assert_ulp(got, exp, MAX_ULP, f"{name} {w}x{h}")
+
+
+@pytest.mark.parametrize("iters", [0, 1, 2, 3])
+@pytest.mark.parametrize("gab", [False, True])
+def test_filter_configs(gpu_ctx, oracle, iters, gab):
+    wl = VardctWorkload(264, 200, seed=40 + iters, epf_iters=iters, gabor=gab)
+    got, exp = _both(gpu_ctx, oracle, wl, S_ALL)
+    assert_ulp(got, exp, MAX_ULP, f"iters={iters} gab={gab}")
+
+
+def test_mixed_frame_multi_lf_group(gpu_ctx, oracle):
+    # > 2048 px wide: two LF groups with different extra_precision
+    wl = VardctWorkload(2100, 300, seed=9, lf_i16=False)
+    got, exp = _both(gpu_ctx, oracle, wl, S_ALL)
+    assert_ulp(got, exp, MAX_ULP, "2100x300 full pipeline")
+
+
+def test_hdr_pq_chain(gpu_ctx, oracle):
+    wl = VardctWorkload(200, 136, seed=11, epf_iters=3, intensity_target=4000.0, hdr_pq=True)
+    got, exp = _both(gpu_ctx, oracle, wl, S_ALL)
+    assert_ulp(got, exp, MAX_ULP, "PQ chain")
+
+
+@pytest.mark.parametrize("factor", [2, 4, 8])
+def test_upsampling(gpu_ctx, oracle, factor):
+    wl = VardctWorkload(72, 56, seed=20 + factor, upsampling=factor, epf_iters=1)
+    got, exp = _both(gpu_ctx, oracle, wl, S_ALL)
+    assert got.shape == (3, 56 * factor, 72 * factor)
+    assert_ulp(got, exp, MAX_ULP, f"upsampling x{factor}")
+
+
+def test_render_host_one_shot(gpu_ctx, oracle):
+    wl = VardctWorkload(136, 120, seed=3)
+    d = wl.desc()
+    exp, _ = oracle.vardct_render(d, S_ALL, wl.width, wl.height)
+    got = gpu_ctx.vardct_render_host(d, S_ALL, wl.width, wl.height)
+    assert_ulp(got, exp, MAX_ULP, "render_host")
+
+
+def test_error_codes(gpu_ctx):
+    wl = VardctWorkload(64, 64, seed=5)
+    d = wl.desc()
+    d.abi = 999
+    with pytest.raises(Exception) as e:
+        gpu_ctx.vardct_upload(d)
+    assert e.value.code == abi.ERR_ABI
+    d = wl.desc()
+    d.jpeg_upsampling[1] = 1
+    with pytest.raises(Exception) as e:
+        gpu_ctx.vardct_upload(d)
+    assert e.value.code == abi.ERR_UNSUPPORTED
+    d = wl.desc()
+    d.coeff[0] = None
+    with pytest.raises(Exception) as e:
+        gpu_ctx.vardct_upload(d)
+    assert e.value.code == abi.ERR_INVALID_ARG
