@@ -3,6 +3,7 @@
 // serial `for_each_varblocks` scan, jxl-render/src/vardct/mod.rs:693-730) and sequences the
 // kernels on the context's HIP stream.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -69,8 +70,8 @@ int dev_upload(jxlgpu_ctx* ctx, jxlgpu_frame* f, T** out, const std::vector<T>& 
     int rc = dev_alloc(ctx, f, out, host.size());
     if (rc) return rc;
     if (!host.empty())
-        HIP_TRY(ctx, hipMemcpyAsync(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    // pageable source: the runtime stages the copy before returning, `host` may die afterwards
+        HIP_TRY(ctx, hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    // blocking copy: `host` (pageable) may be released as soon as this returns
     return JXLGPU_OK;
 }
 
@@ -330,8 +331,8 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
     // ---- device buffers + H2D
     for (int c = 0; c < 3; ++c) {
         TRY(dev_alloc(ctx, f, &f->coeff[c], npix));
-        HIP_TRY(ctx, hipMemcpy2DAsync(f->coeff[c], (size_t)f->wr * 4, d->coeff[c], (size_t)d->coeff_stride * 4,
-                                      (size_t)f->wr * 4, f->hr, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpy2D(f->coeff[c], (size_t)f->wr * 4, d->coeff[c], (size_t)d->coeff_stride * 4,
+                                 (size_t)f->wr * 4, f->hr, hipMemcpyHostToDevice));
         uint8_t* p = nullptr;
         TRY(dev_upload(ctx, f, &p, lfq_host[c]));
         f->lfq[c] = p;
@@ -435,10 +436,10 @@ int jxlgpu_frame_download_lf(jxlgpu_ctx* ctx, const jxlgpu_frame* f, float* cons
     if (!ctx || !f || !planes) return JXLGPU_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const float* const* src = f->desc.skip_adaptive_lf_smoothing ? f->lf_a : f->lf;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int c = 0; c < 3; ++c)
         if (planes[c])
-            HIP_TRY(ctx, hipMemcpyAsync(planes[c], src[c], (size_t)f->w8 * f->h8 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipMemcpy(planes[c], src[c], (size_t)f->w8 * f->h8 * 4, hipMemcpyDeviceToHost));
     return JXLGPU_OK;
 }
 
@@ -495,7 +496,9 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
         for (int c = 0; c < 3; ++c) cur[c] = f->up[c];
         *ow = W * k; *oh = H * k; *cur_stride = W * k;
     }
+    if (getenv("JXLGPU_DEBUG_SYNC")) (void)hipStreamSynchronize(s);
     if (do_color) launch_color(s, f->color, cur, *cur_stride, *ow, *oh);
+    if (getenv("JXLGPU_DEBUG_SYNC")) (void)hipStreamSynchronize(s);
     return JXLGPU_OK;
 }
 
@@ -506,12 +509,30 @@ int finish_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stri
     HIP_TRY(ctx, hipGetLastError());
     if (out) {
         if (out->stride < ow) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "output stride < output width");
-        const hipMemcpyKind kind = out->mem == JXLGPU_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-        for (int c = 0; c < 3; ++c)
-            if (out->planes[c])
-                HIP_TRY(ctx, hipMemcpy2DAsync(out->planes[c], (size_t)out->stride * 4, cur[c], (size_t)stride * 4,
-                                              (size_t)ow * 4, oh, kind, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (out->mem == JXLGPU_MEM_DEVICE) {
+            for (int c = 0; c < 3; ++c)
+                if (out->planes[c])
+                    HIP_TRY(ctx, hipMemcpy2DAsync(out->planes[c], (size_t)out->stride * 4, cur[c], (size_t)stride * 4,
+                                                  (size_t)ow * 4, oh, hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        } else {
+            // D2H into the ctx's pinned staging buffer (tight rows), then into the caller's grids
+            const size_t plane = (size_t)ow * oh * 4;
+            if (ctx->pinned_size < plane * 3) {
+                if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+                ctx->pinned = nullptr; ctx->pinned_size = 0;
+                HIP_TRY(ctx, hipHostMalloc(&ctx->pinned, plane * 3, hipHostMallocDefault));
+                ctx->pinned_size = plane * 3;
+            }
+            for (int c = 0; c < 3; ++c)
+                HIP_TRY(ctx, hipMemcpy2DAsync((char*)ctx->pinned + plane * c, (size_t)ow * 4, cur[c], (size_t)stride * 4,
+                                              (size_t)ow * 4, oh, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (int c = 0; c < 3; ++c)
+                if (out->planes[c])
+                    for (uint32_t y = 0; y < oh; ++y)
+                        memcpy(out->planes[c] + (size_t)y * out->stride, (char*)ctx->pinned + plane * c + (size_t)y * ow * 4, (size_t)ow * 4);
+        }
     }
     return JXLGPU_OK;
 }
