@@ -185,6 +185,15 @@ int jxlgpu_synchronize(jxlgpu_ctx* ctx);
 /* The ctx's hipStream_t (so callers can record HIP events around launches). */
 void* jxlgpu_stream(jxlgpu_ctx* ctx);
 
+/* Measurement hook (no reference counterpart: the reference only has wall-clock MP/s in its CLI,
+ * jxl-oxide-cli/src/decode.rs:164-209).  Brackets every launch group of the selected kind with
+ * a HIP event pair on the ctx stream; `jxlgpu_profile_read` synchronises, sums the elapsed times
+ * of the brackets recorded since the last read and resets.  group: 0 = LF prologue (V1-V3),
+ * 1 = varblock transforms (V4-V8), 2 = restoration filters + upsampling + colour, 3 = Modular
+ * inverse transforms; -1 = off.                                                                   */
+int jxlgpu_profile_select(jxlgpu_ctx* ctx, int group);
+int jxlgpu_profile_read(jxlgpu_ctx* ctx, double* total_ms, uint64_t* brackets);
+
 /* ---- VarDCT ---- */
 /* Copy one frame's decoded state to the device (H2D on the ctx stream, asynchronous for pinned
  * sources) and build the device-side tables.  The descriptor and everything it points to may be

@@ -200,6 +200,8 @@ _SYMBOLS = [
     ("jxlgpu_abi_version", C.c_uint32, []),
     ("jxlgpu_synchronize", C.c_int, [C.c_void_p]),
     ("jxlgpu_stream", C.c_void_p, [C.c_void_p]),
+    ("jxlgpu_profile_select", C.c_int, [C.c_void_p, C.c_int]),
+    ("jxlgpu_profile_read", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("jxlgpu_vardct_upload", C.c_int, [C.c_void_p, C.POINTER(VardctDesc), C.POINTER(C.c_void_p)]),
     ("jxlgpu_vardct_render", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Out)]),
     ("jxlgpu_vardct_render_host", C.c_int, [C.c_void_p, C.POINTER(VardctDesc), C.c_uint32, C.POINTER(Out)]),

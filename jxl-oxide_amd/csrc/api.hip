@@ -159,6 +159,7 @@ void jxlgpu_destroy(jxlgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete ctx;
 }
 
@@ -172,6 +173,29 @@ int jxlgpu_synchronize(jxlgpu_ctx* ctx) {
 }
 
 void* jxlgpu_stream(jxlgpu_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int jxlgpu_profile_select(jxlgpu_ctx* ctx, int group) {
+    if (!ctx || group >= PROF_COUNT) return JXLGPU_ERR_INVALID_ARG;
+    ctx->prof_group = group;
+    ctx->prof_used = 0;
+    return JXLGPU_OK;
+}
+
+int jxlgpu_profile_read(jxlgpu_ctx* ctx, double* total_ms, uint64_t* brackets) {
+    if (!ctx) return JXLGPU_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double sum = 0;
+    for (size_t i = 0; i < ctx->prof_used; ++i) {
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->prof_events[i].first, ctx->prof_events[i].second));
+        sum += ms;
+    }
+    if (total_ms) *total_ms = sum;
+    if (brackets) *brackets = ctx->prof_used;
+    ctx->prof_used = 0;
+    return JXLGPU_OK;
+}
 
 void jxlgpu_frame_free(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     if (!f) return;
@@ -551,6 +575,7 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
     la.is_i16 = f->lf_is_i16; la.scale = f->lf_scale;
     la.w8 = f->w8; la.h8 = f->h8; la.lf_groups_per_row = f->lf_groups_per_row; la.group_cells = f->group_dim;
     la.kx = f->kx_lf; la.kb = f->kb_lf;
+    ctx->prof_begin(PROF_LF);
     launch_lf_dequant_cfl(s, la);
     float* const* lf = f->lf_a;
     if (!d.skip_adaptive_lf_smoothing) {
@@ -560,6 +585,7 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
         launch_lf_smooth(s, sa);
         lf = f->lf;
     }
+    ctx->prof_end(PROF_LF);
     if (!(stages & JXLGPU_STAGE_TRANSFORM)) {
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -579,13 +605,17 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
     ta.global_scale = (float)d.global_scale;
     ta.quant_bias_numerator = d.quant_bias_numerator;
     ta.big_tmp = f->big_tmp;
+    ctx->prof_begin(PROF_TRANSFORM);
     for (int cls = 0; cls < CLS_COUNT; ++cls)
         launch_transform_class(s, cls, ta, f->lists[cls], f->list_count[cls]);
     launch_nometa_groups(s, ta, f->nometa_groups, f->nometa_count, f->group_dim, ceil_div(f->width, f->group_dim));
+    ctx->prof_end(PROF_TRANSFORM);
 
     float* cur[3] = {f->pix[0], f->pix[1], f->pix[2]};
     uint32_t stride = f->wr, ow = f->width, oh = f->height;
+    ctx->prof_begin(PROF_POST);
     TRY(run_post_stages(ctx, f, stages, d.filter, d.upsampling.factor ? d.upsampling.factor : 1, cur, &stride, &ow, &oh));
+    ctx->prof_end(PROF_POST);
     return finish_render(ctx, f, cur, stride, ow, oh, out);
 }
 

@@ -97,12 +97,34 @@ struct ColorArgs {
     uint32_t tf;
 };
 
+// Kernel groups that can be bracketed with HIP events (jxlgpu_profile_*).
+enum ProfGroup : int { PROF_LF = 0, PROF_TRANSFORM = 1, PROF_POST = 2, PROF_MODULAR = 3, PROF_COUNT = 4 };
+
 struct jxlgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string last_error;
     void* pinned = nullptr;     // pinned staging buffer (grown on demand)
     size_t pinned_size = 0;
+    // event-pair profiling of one kernel group on the ctx stream
+    int prof_group = -1;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
+    void prof_begin(int g) {
+        if (g != prof_group) return;
+        if (prof_used == prof_events.size()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            prof_events.emplace_back(a, b);
+        }
+        (void)hipEventRecord(prof_events[prof_used].first, stream);
+    }
+    void prof_end(int g) {
+        if (g != prof_group) return;
+        (void)hipEventRecord(prof_events[prof_used].second, stream);
+        ++prof_used;
+    }
 };
 
 struct DevBuf {

@@ -60,6 +60,14 @@ class Context:
     def synchronize(self):
         self._check(self.lib.jxlgpu_synchronize(self.handle))
 
+    def profile_select(self, group):
+        self._check(self.lib.jxlgpu_profile_select(self.handle, group))
+
+    def profile_read(self):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self.lib.jxlgpu_profile_read(self.handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     # ---- VarDCT
     def vardct_upload(self, desc):
         fh = C.c_void_p()

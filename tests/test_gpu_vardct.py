@@ -72,6 +72,24 @@ def test_filter_configs(gpu_ctx, oracle, iters, gab):
     assert_ulp(got, exp, MAX_ULP, f"iters={iters} gab={gab}")
 
 
+def test_staged_post_path_matches(gpu_ctx, oracle, monkeypatch):
+    """The stage-at-a-time kernels (fallback path) must agree with the oracle too."""
+    monkeypatch.setenv("JXLGPU_NO_FUSED", "1")
+    for iters in (1, 2, 3):
+        wl = VardctWorkload(200, 136, seed=70 + iters, epf_iters=iters)
+        got, exp = _both(gpu_ctx, oracle, wl, S_ALL)
+        assert_ulp(got, exp, MAX_ULP, f"staged iters={iters}")
+
+
+@pytest.mark.parametrize("size", [(1, 1), (2, 3), (5, 4), (3, 40), (33, 2)])
+def test_tiny_images(gpu_ctx, oracle, size):
+    w, h = size
+    for iters in (0, 2, 3):
+        wl = VardctWorkload(w, h, seed=80 + w + iters, epf_iters=iters)
+        got, exp = _both(gpu_ctx, oracle, wl, S_ALL)
+        assert_ulp(got, exp, MAX_ULP, f"tiny {w}x{h} iters={iters}")
+
+
 def test_mixed_frame_multi_lf_group(gpu_ctx, oracle):
     # > 2048 px wide: two LF groups with different extra_precision
     wl = VardctWorkload(2100, 300, seed=9, lf_i16=False)
