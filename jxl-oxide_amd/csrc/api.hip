@@ -146,7 +146,10 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     if (!ctx) return JXLGPU_ERR_OOM;
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return JXLGPU_ERR_DEVICE;
     }
@@ -158,6 +161,9 @@ void jxlgpu_destroy(jxlgpu_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete ctx;
@@ -308,7 +314,7 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
     }
 
     // ---- varblock work lists, one per shape class, ordered by 256x256 group then raster
-    std::vector<uint32_t> lists[CLS_COUNT];
+    std::vector<uint4> lists[CLS_COUNT];
     std::vector<uint32_t> nometa;
     const uint32_t gcells = d->group_dim / 8;
     const uint32_t groups_x = ceil_div(d->width, d->group_dim), groups_y = ceil_div(d->height, d->group_dim);
@@ -330,7 +336,7 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
                     if (hf_mul[(size_t)y * f->w8 + x] <= 0) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "non-positive HfMul");
                     if (!d->dequant[t][0] || !d->dequant[t][1] || !d->dequant[t][2])
                         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "missing dequant matrix for a used transform");
-                    lists[class_of(t)].push_back(x | (y << 16));
+                    lists[class_of(t)].push_back(make_uint4(x | (y << 16), t, (uint32_t)hf_mul[(size_t)y * f->w8 + x], 0));
                 }
         }
 
@@ -374,9 +380,25 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
     TRY(dev_upload(ctx, f, &f->lf_scale, lf_scale));
     TRY(dev_upload(ctx, f, &f->dequant, deq));
     TRY(dev_upload(ctx, f, &f->deq_off, deq_off));
-    for (int cls = 0; cls < CLS_COUNT; ++cls) {
-        f->list_count[cls] = (uint32_t)lists[cls].size();
-        if (!lists[cls].empty()) TRY(dev_upload(ctx, f, &f->lists[cls], lists[cls]));
+    {
+        // one entry array (classes concatenated) + one descriptor per workgroup of the <=32 kernel,
+        // widest shapes first so the long workgroups start early
+        static const int kNB[CLS_COUNT] = {32, 32, 8, 16, 16, 2, 8, 8, 4, 4, 1, 1, 1, 1};
+        static const int kOrder[] = {CLS_32x32, CLS_16x32, CLS_32x16, CLS_8x32, CLS_32x8, CLS_16x16,
+                                     CLS_8x16, CLS_16x8, CLS_DCT8};
+        std::vector<uint4> entries, wgs;
+        for (int cls = 0; cls < CLS_COUNT; ++cls) {
+            f->class_first[cls] = (uint32_t)entries.size();
+            f->list_count[cls] = (uint32_t)lists[cls].size();
+            entries.insert(entries.end(), lists[cls].begin(), lists[cls].end());
+        }
+        for (int cls : kOrder)
+            for (uint32_t i = 0; i < f->list_count[cls]; i += kNB[cls])
+                wgs.push_back(make_uint4((uint32_t)cls, f->class_first[cls] + i,
+                                         std::min<uint32_t>(kNB[cls], f->list_count[cls] - i), 0));
+        TRY(dev_upload(ctx, f, &f->entries, entries));
+        f->n_wg_descs = (uint32_t)wgs.size();
+        TRY(dev_upload(ctx, f, &f->wg_descs, wgs));
     }
     f->nometa_count = (uint32_t)nometa.size();
     if (!nometa.empty()) TRY(dev_upload(ctx, f, &f->nometa_groups, nometa));
@@ -606,8 +628,19 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
     ta.quant_bias_numerator = d.quant_bias_numerator;
     ta.big_tmp = f->big_tmp;
     ctx->prof_begin(PROF_TRANSFORM);
-    for (int cls = 0; cls < CLS_COUNT; ++cls)
-        launch_transform_class(s, cls, ta, f->lists[cls], f->list_count[cls]);
+    const bool has64 = f->list_count[CLS_64x64] | f->list_count[CLS_32x64] | f->list_count[CLS_64x32] |
+                       f->list_count[CLS_SPECIAL8];
+    if (has64) {
+        // fork: the 64-pixel shapes (different LDS / register footprint) run beside the <=32 kernel
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        for (int cls : {CLS_64x64, CLS_32x64, CLS_64x32, CLS_SPECIAL8})
+            launch_transform_class(ctx->stream2, cls, ta, f->entries + f->class_first[cls], f->list_count[cls]);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+    }
+    launch_transform_small(s, ta, f->wg_descs, f->n_wg_descs, f->entries);
+    if (has64) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+    launch_transform_class(s, CLS_BIG, ta, f->entries + f->class_first[CLS_BIG], f->list_count[CLS_BIG]);
     launch_nometa_groups(s, ta, f->nometa_groups, f->nometa_count, f->group_dim, ceil_div(f->width, f->group_dim));
     ctx->prof_end(PROF_TRANSFORM);
 

@@ -89,12 +89,12 @@ __device__ __forceinline__ float dequant_big(int32_t qn, float quant_bias, float
 }
 
 // One workgroup per (varblock, channel).
-__global__ __launch_bounds__(256) void big_block_kernel(TransformArgs a, const uint32_t* list, float* tmp) {
+__global__ __launch_bounds__(256) void big_block_kernel(TransformArgs a, const uint4* list, float* tmp) {
     __shared__ float llf[32 * 33];
     const SecLarge sl{a.sec64, a.sec128, a.sec256};
     const int t = threadIdx.x;
     const int c = blockIdx.y;
-    uint32_t e = list[blockIdx.x];
+    uint32_t e = list[blockIdx.x].x;
     uint32_t cx = e & 0xffffu, cy = e >> 16;
     size_t cell = (size_t)cy * a.w8 + cx;
     uint32_t type = a.kind[cell];
@@ -156,6 +156,6 @@ __global__ __launch_bounds__(256) void big_block_kernel(TransformArgs a, const u
         idct_iterative(Strided{out + x, a.pstride}, Strided{scratch + x, a.pstride}, H, sl);
 }
 
-void launch_big_blocks(hipStream_t s, const TransformArgs& a, const uint32_t* list, uint32_t count) {
+void launch_big_blocks(hipStream_t s, const TransformArgs& a, const uint4* list, uint32_t count) {
     big_block_kernel<<<dim3(count, 3), 256, 0, s>>>(a, list, a.big_tmp);
 }

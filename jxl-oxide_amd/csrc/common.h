@@ -103,6 +103,8 @@ enum ProfGroup : int { PROF_LF = 0, PROF_TRANSFORM = 1, PROF_POST = 2, PROF_MODU
 struct jxlgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // side stream: 64-pixel varblock kernels overlap the <=32 kernel
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string last_error;
     void* pinned = nullptr;     // pinned staging buffer (grown on demand)
     size_t pinned_size = 0;
@@ -160,8 +162,11 @@ struct jxlgpu_frame {
     float* big_tmp = nullptr;  // scratch for the >=128 transform path (aliases buf_a[0])
     float* up[3] = {};          // upsampled planes
     float* up_tmp[3] = {};
-    uint32_t* lists[CLS_COUNT] = {};
+    uint4* entries = nullptr;            // all varblocks, classes concatenated
+    uint32_t class_first[CLS_COUNT] = {};
     uint32_t list_count[CLS_COUNT] = {};
+    uint4* wg_descs = nullptr;           // {class, first entry, count, 0} per workgroup of the <=32 kernel
+    uint32_t n_wg_descs = 0;
     bool has_no_meta_groups = false;
     uint32_t* nometa_groups = nullptr;  // groups whose LF group has no HfMetadata
     uint32_t nometa_count = 0;
@@ -171,6 +176,8 @@ struct jxlgpu_frame {
     float kx_lf = 0, kb_lf = 0;
     float lf_div[3] = {};
     ColorArgs color = {};
+    uint32_t* ring_tiles = nullptr;      // outer ring of 32x32 tiles for the fused tile kernel
+    uint32_t n_ring_tiles = 0;
     float* up_weights[3] = {};  // expanded 5x5 kernels per phase for 2x/4x/8x
     // result of the last render
     const float* result[3] = {};
@@ -193,8 +200,10 @@ static inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b
 // kernel launchers implemented in the .hip files
 void launch_lf_dequant_cfl(hipStream_t s, const LfArgs& a);
 void launch_lf_smooth(hipStream_t s, const SmoothArgs& a);
-void launch_transform_class(hipStream_t s, int cls, const TransformArgs& a, const uint32_t* list,
+void launch_transform_class(hipStream_t s, int cls, const TransformArgs& a, const uint4* entries,
                             uint32_t count);
+void launch_transform_small(hipStream_t s, const TransformArgs& a, const uint4* wgs, uint32_t n_wgs,
+                            const uint4* entries);
 void launch_nometa_groups(hipStream_t s, const TransformArgs& a, const uint32_t* groups,
                           uint32_t count, uint32_t group_dim, uint32_t groups_per_row);
 void launch_gabor(hipStream_t s, const FilterArgs& a);

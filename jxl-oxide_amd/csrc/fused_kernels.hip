@@ -8,6 +8,9 @@
 // Image borders: each stage of the reference mirrors ITS OWN input (util.rs:376-386), so after
 // every stage the out-of-image cells of the stage's region are refilled from the mirrored
 // in-image cells before the next stage reads them.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 #include "pixel_device.h"
 
@@ -36,6 +39,9 @@ struct FusedArgs {
     JxlGpuFilterParams fp;
     ColorArgs color;
     uint32_t do_color;
+    const uint32_t* tiles;   // optional list of tiles (tx | ty << 16); null = full 2-D grid
+    // streaming kernel geometry: it covers [sx0, sx1) x [sy0, sy1), strictly inside the image
+    int sx0, sx1, sy0, sy1, rows_per_seg, strips, segs;
 };
 
 // Refill the out-of-image cells of the square region [lo, LW-lo) of `buf` (3 planes) from their
@@ -95,7 +101,13 @@ __global__ __launch_bounds__(256) void fused_post_kernel(FusedArgs a) {
     float* bufA = lds;
     float* bufB = lds + 3 * PLANE;
     const int t = threadIdx.x;
-    const int tx0 = blockIdx.x * T, ty0 = blockIdx.y * T;
+    int tile_x = blockIdx.x, tile_y = blockIdx.y;
+    if (a.tiles) {
+        uint32_t e = a.tiles[blockIdx.x];
+        tile_x = e & 0xffffu;
+        tile_y = e >> 16;
+    }
+    const int tx0 = tile_x * T, ty0 = tile_y * T;
     const int ox = tx0 - HALO, oy = ty0 - HALO;  // image coordinate of LDS cell (0,0)
     const int W = a.width, H = a.height;
     const bool border = ox < 0 || oy < 0 || ox + LW > W || oy + LW > H;
@@ -191,6 +203,221 @@ __global__ __launch_bounds__(256) void fused_post_kernel(FusedArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Streaming form of the same pipeline for the interior of the image (Gabor + EPF steps 1,2 +
+// colour, the default `iters = 2` configuration): no LDS at all.  One wave owns a strip of 64
+// columns (56 outputs + 4 halo lanes each side) and walks down `rows_per_seg` rows; every lane
+// keeps the sliding row windows of its column in registers and reaches x-1 / x+1 with DPP
+// wave shifts.  Absolute differences are shared between taps and between neighbouring pixels:
+// with V(x,y) = |G(x,y) - G(x,y-1)| and H(x,y) = |G(x,y) - G(x-1,y)| every term
+// |G(p+k+i) - G(p+i)| of epf_row<1> (filter/impls/generic/epf.rs:118-145) is a V or an H, summed
+// in the reference's order, so results stay bit-identical while the subtractions drop 10x.
+// The frame's outer ring of 32-px tiles (where the reference mirrors) goes through the tile
+// kernel above; this kernel never sees a border.
+constexpr int SW = 56;  // outputs per strip
+constexpr int SH = 4;   // halo lanes / rows (1 Gabor + 2 EPF step 1 + 1 EPF step 2)
+
+__device__ __forceinline__ float from_left(float v) {   // value held by lane - 1 (pixel x - 1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_right(float v) {  // value held by lane + 1 (pixel x + 1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+struct StreamState {
+    // row rings, slot = (row phase) & 3: I rows j-2..j; G, V, H rows g-3..g (g = j-1);
+    // E rows e-2..e (e = j-3); Wd = |E(r) - E(r-1)| rows e-1..e
+    float I[4][3], G[4][3], V[4][3], H[4][3], E[4][3], Wd[4][3];
+    float nxt[3];
+    float sig_nxt, sig_e, sig_f;  // sigma for rows e(next), e, f = e-1 (one load per row, prefetched)
+};
+
+struct StreamConst {
+    float gw0[3], gw1[3], ggw[3];
+    float cs0, cs1, cs2, K;
+    float sm1_in, sm1_bd, sm2_in, sm2_bd;
+    bool x_bd, store_lane;
+    int x, xl, yb;
+};
+
+// One row step; P = (j - j_start) & 3 is a compile-time phase so every ring slot below is a
+// fixed register (no rotation moves).
+template <int P, int TF>
+__device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst& k, StreamState& st, int j) {
+    constexpr int s0 = P & 3, sm1 = (P + 3) & 3, sm2 = (P + 2) & 3, sm3 = (P + 1) & 3;  // rows j, j-1, j-2, j-3 (== j-4 -> s0)
+    // ---- take the prefetched input row j, prefetch row j+1
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st.I[s0][c] = st.nxt[c];
+    {
+        int jn = min(j + 1, a.height - 1);
+        size_t gi = (size_t)jn * a.in_stride + k.xl;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) st.nxt[c] = a.in[c][gi];
+        // sigma of row e+1 = j-2 for the next step; this step's f = e-1 reuses the previous e
+        st.sig_f = st.sig_e;
+        st.sig_e = st.sig_nxt;
+        st.sig_nxt = a.sigma[(size_t)((j - 2) >> 3) * a.sigma_stride + (k.xl >> 3)];
+    }
+    // ---- Gabor row g = j-1 (run_gabor_row_generic interior expression, gabor.rs:135-147):
+    //      t = I(j-2), c = I(j-1), b = I(j).  G(g) -> slot sm1; G(g-1) is slot sm2.
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float It = st.I[sm2][c], Ic = st.I[sm1][c], Ib = st.I[s0][c];
+        float sum_side = It + from_left(Ic) + from_right(Ic) + Ib;
+        float sum_diag = from_left(It) + from_right(It) + from_left(Ib) + from_right(Ib);
+        float g = (Ic + sum_side * k.gw0[c] + sum_diag * k.gw1[c]) * k.ggw[c];
+        st.V[sm1][c] = fabsf(g - st.G[sm2][c]);
+        st.G[sm1][c] = g;
+        st.H[sm1][c] = fabsf(g - from_left(g));
+    }
+    // ---- EPF step 1, row e = j-3 = g-2: V(e-1..e+2) = slots s0(g-3) sm3(g-2) sm2(g-1) sm1(g);
+    //      H, G (e-1..e+1) = slots s0, sm3, sm2
+    const int e = j - 3;
+    {
+        float sigma_val = st.sig_e;
+        bool y_bd = ((e + 1) & 6) == 0;
+        float sm = (y_bd || k.x_bd) ? k.sm1_bd : k.sm1_in;
+        float neg_inv_sigma = k.K / sigma_val * sm;
+        float acc[4][3], tapv[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float Va = st.V[s0][c], Vb = st.V[sm3][c], Vc = st.V[sm2][c], Vd = st.V[sm1][c];
+            float Ha = st.H[s0][c], Hb = st.H[sm3][c], Hc = st.H[sm2][c];
+            // tap (0,-1): V(x,y-1) V(x,y) V(x,y+1) V(x-1,y) V(x+1,y)
+            acc[0][c] = Va + Vb + Vc + from_left(Vb) + from_right(Vb);
+            // tap (0,1):  V(x,y) V(x,y+1) V(x,y+2) V(x-1,y+1) V(x+1,y+1)
+            acc[1][c] = Vb + Vc + Vd + from_left(Vc) + from_right(Vc);
+            // tap (-1,0): H(x,y-1) H(x,y) H(x,y+1) H(x-1,y) H(x+1,y)
+            float hbr = from_right(Hb);
+            acc[2][c] = Ha + Hb + Hc + from_left(Hb) + hbr;
+            // tap (1,0):  H(x+1,y-1) H(x+1,y) H(x+1,y+1) H(x,y) H(x+2,y)
+            acc[3][c] = from_right(Ha) + hbr + from_right(Hc) + Hb + from_right(hbr);
+            float Gc = st.G[sm3][c];
+            tapv[0][c] = st.G[s0][c];
+            tapv[1][c] = st.G[sm2][c];
+            tapv[2][c] = from_left(Gc);
+            tapv[3][c] = from_right(Gc);
+        }
+        float sum_w = 1.0f;
+        float sum_c[3] = {st.G[sm3][0], st.G[sm3][1], st.G[sm3][2]};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float dist = k.cs0 * acc[t][0];
+            dist += k.cs1 * acc[t][1];
+            dist += k.cs2 * acc[t][2];
+            float w = fmaxf(1.0f + dist * neg_inv_sigma, 0.0f);
+            sum_w += w;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sum_c[c] += w * tapv[t][c];
+        }
+        const bool copy = sigma_val < 0.3f;
+        // E(e) -> slot sm3; E(e-1) is slot s0 (row j-4)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float r = copy ? st.G[sm3][c] : sum_c[c] / sum_w;
+            st.Wd[sm3][c] = fabsf(r - st.E[s0][c]);
+            st.E[sm3][c] = r;
+        }
+    }
+    // ---- EPF step 2, row f = j-4 = e-1: E(f-1), E(f), E(f+1) = slots sm1 (row j-5), s0, sm3
+    const int f = j - 4;
+    float o[3];
+    {
+        float sigma_val = st.sig_f;
+        bool y_bd = ((f + 1) & 6) == 0;
+        float sm = (y_bd || k.x_bd) ? k.sm2_bd : k.sm2_in;
+        float neg_inv_sigma = k.K / sigma_val * sm;
+        float d[4][3], tapv[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float Ec = st.E[s0][c];
+            float el = from_left(Ec);
+            float hl = fabsf(el - Ec);            // |E(x-1,f) - E(x,f)|
+            d[0][c] = st.Wd[s0][c];               // |E(f) - E(f-1)|
+            d[1][c] = st.Wd[sm3][c];              // |E(f+1) - E(f)|
+            d[2][c] = hl;
+            d[3][c] = from_right(hl);             // |E(x+1,f) - E(x,f)|
+            tapv[0][c] = st.E[sm1][c];
+            tapv[1][c] = st.E[sm3][c];
+            tapv[2][c] = el;
+            tapv[3][c] = from_right(Ec);
+        }
+        float sum_w = 1.0f;
+        float sum_c[3] = {st.E[s0][0], st.E[s0][1], st.E[s0][2]};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float dist = k.cs0 * d[t][0];
+            dist += k.cs1 * d[t][1];
+            dist += k.cs2 * d[t][2];
+            float w = fmaxf(1.0f + dist * neg_inv_sigma, 0.0f);
+            sum_w += w;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sum_c[c] += w * tapv[t][c];
+        }
+        const bool copy = sigma_val < 0.3f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = copy ? st.E[s0][c] : sum_c[c] / sum_w;
+    }
+    if (f >= k.yb && k.store_lane) {
+        if (a.do_color) {
+            if constexpr (TF == JXLGPU_TF_SRGB) color_pixel_srgb(a.color, o);
+            else color_pixel(a.color, o);
+        }
+        size_t go = (size_t)f * a.out_stride + k.x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.out[c][go] = o[c];
+    }
+}
+
+template <int TF>
+__global__ __launch_bounds__(256) void post_stream_kernel(FusedArgs a) {
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int strip = wave % a.strips, seg = wave / a.strips;
+    if (seg >= a.segs) return;
+    StreamConst k;
+    k.x = a.sx0 + strip * SW - SH + lane;
+    k.xl = min(k.x, a.width - 1);
+    k.yb = a.sy0 + seg * a.rows_per_seg;
+    const int ye = min(k.yb + a.rows_per_seg, a.sy1);
+    k.store_lane = lane >= SH && lane < SH + SW && k.x < a.sx1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        k.gw0[c] = a.fp.gab_weights[c][0];
+        k.gw1[c] = a.fp.gab_weights[c][1];
+        k.ggw[c] = 1.0f / (1.0f + k.gw0[c] * 4.0f + k.gw1[c] * 4.0f);
+    }
+    k.cs0 = a.fp.epf_channel_scale[0]; k.cs1 = a.fp.epf_channel_scale[1]; k.cs2 = a.fp.epf_channel_scale[2];
+    const float FRAC_1_SQRT_2 = 0.70710678118654752440f;
+    k.K = 6.6f * (FRAC_1_SQRT_2 - 1.0f);
+    const float border = a.fp.epf_border_sad_mul;
+    k.sm1_in = 1.0f; k.sm1_bd = 1.0f * border;
+    k.sm2_in = a.fp.epf_pass2_sigma_scale; k.sm2_bd = a.fp.epf_pass2_sigma_scale * border;
+    k.x_bd = (k.x & 7) == 0 || (k.x & 7) == 7;
+
+    StreamState st;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) st.I[i][c] = st.G[i][c] = st.V[i][c] = st.H[i][c] = st.E[i][c] = st.Wd[i][c] = 0.0f;
+    {
+        size_t gi = (size_t)(k.yb - SH) * a.in_stride + k.xl;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) st.nxt[c] = a.in[c][gi];
+        // first step is j = yb-SH with e = j-3: sig_nxt must hold sigma(row j-3) when it rotates in
+        st.sig_e = st.sig_f = 1.0f;
+        st.sig_nxt = a.sigma[(size_t)((k.yb - SH - 3) >> 3) * a.sigma_stride + (k.xl >> 3)];
+    }
+    // (ye - yb) and 2*SH are multiples of 4: whole groups of four phases
+    for (int j = k.yb - SH; j < ye + SH; j += 4) {
+        stream_row<0, TF>(a, k, st, j);
+        stream_row<1, TF>(a, k, st, j + 1);
+        stream_row<2, TF>(a, k, st, j + 2);
+        stream_row<3, TF>(a, k, st, j + 3);
+    }
+}
+
 template <bool GAB, int ITERS>
 void launch_cfg(hipStream_t s, const FusedArgs& a) {
     dim3 grid(ceil_div(a.width, T), ceil_div(a.height, T));
@@ -214,13 +441,51 @@ bool fused_post_supported(const jxlgpu_frame* f, bool gabor, int epf_iters) {
 void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
                        float* const out[3], uint32_t out_stride, bool gabor, int epf_iters, bool color) {
     FusedArgs a;
+    memset(&a, 0, sizeof(a));
     for (int c = 0; c < 3; ++c) { a.in[c] = in[c]; a.out[c] = out[c]; }
     a.in_stride = in_stride; a.out_stride = out_stride;
     a.width = (int)f->width; a.height = (int)f->height;
     a.sigma = f->sigma; a.sigma_stride = f->w8;
-    a.fp = f->kind_of_frame == 0 ? f->desc.filter : f->desc.filter;
+    a.fp = f->desc.filter;
     a.color = f->color;
     a.do_color = color ? 1u : 0u;
+    a.tiles = nullptr;
+
+    // Default configuration (Gabor + 2 EPF steps) on a frame with an interior: the streaming
+    // kernel takes everything except the outer ring of tiles.
+    const int ntx = (int)ceil_div(f->width, T), nty = (int)ceil_div(f->height, T);
+    int tx_hi = ntx - 1, ty_hi = nty - 1;
+    while (tx_hi > 1 && T * tx_hi + SH > (int)f->width) --tx_hi;
+    while (ty_hi > 1 && T * ty_hi + SH > (int)f->height) --ty_hi;
+    static const bool no_stream = getenv("JXLGPU_NO_STREAM") != nullptr;
+    if (gabor && epf_iters == 2 && tx_hi > 1 && ty_hi > 1 && !no_stream) {
+        if (!f->ring_tiles) {
+            std::vector<uint32_t> ring;
+            for (int ty = 0; ty < nty; ++ty)
+                for (int tx = 0; tx < ntx; ++tx)
+                    if (tx < 1 || tx >= tx_hi || ty < 1 || ty >= ty_hi) ring.push_back((uint32_t)tx | ((uint32_t)ty << 16));
+            void* p = nullptr;
+            if (hipMalloc(&p, ring.size() * 4) != hipSuccess) return;
+            f->allocs.push_back(p);
+            (void)hipMemcpy(p, ring.data(), ring.size() * 4, hipMemcpyHostToDevice);
+            f->ring_tiles = static_cast<uint32_t*>(p);
+            f->n_ring_tiles = (uint32_t)ring.size();
+        }
+        static const int rows_env = getenv("JXLGPU_STREAM_ROWS") ? atoi(getenv("JXLGPU_STREAM_ROWS")) : 48;
+        a.sx0 = T; a.sx1 = T * tx_hi; a.sy0 = T; a.sy1 = T * ty_hi;
+        a.rows_per_seg = rows_env;
+        a.strips = (a.sx1 - a.sx0 + SW - 1) / SW;
+        a.segs = (a.sy1 - a.sy0 + a.rows_per_seg - 1) / a.rows_per_seg;
+        const int waves = a.strips * a.segs;
+        // plain XYB -> sRGB (no gamut map / second matrix) gets a branch-free colour epilogue
+        const bool plain_srgb = a.color.tf == JXLGPU_TF_SRGB && !a.color.gamut_map && !a.color.has_matrix2;
+        if (plain_srgb) post_stream_kernel<JXLGPU_TF_SRGB><<<(waves + 3) / 4, 256, 0, s>>>(a);
+        else post_stream_kernel<-1><<<(waves + 3) / 4, 256, 0, s>>>(a);
+        a.tiles = f->ring_tiles;
+        constexpr size_t lds_bytes = 2 * 3 * PostCfg<true, 2>::PLANE * sizeof(float);
+        fused_post_kernel<true, 2><<<f->n_ring_tiles, 256, lds_bytes, s>>>(a);
+        return;
+    }
     switch ((gabor ? 4 : 0) + epf_iters) {
         case 0: launch_cfg<false, 0>(s, a); break;
         case 1: launch_cfg<false, 1>(s, a); break;

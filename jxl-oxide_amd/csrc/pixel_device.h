@@ -231,3 +231,18 @@ __device__ __forceinline__ void color_pixel(const ColorArgs& cp, float (&v)[3]) 
         for (int c = 0; c < 3; ++c) v[c] = linear_to_pq_dev(v[c], cp.intensity_target);
     }
 }
+
+// Same, specialised for the common chain XybToMixedLms -> Matrix -> sRGB (no branches).
+__device__ __forceinline__ void color_pixel_srgb(const ColorArgs& cp, float (&v)[3]) {
+    float x = v[0], y = v[1], b = v[2];
+    float g_l = y + x, g_m = y - x, g_s = b;
+    g_l = g_l - cp.cbrt_opsin_bias[0];
+    g_m = g_m - cp.cbrt_opsin_bias[1];
+    g_s = g_s - cp.cbrt_opsin_bias[2];
+    v[0] = __builtin_fmaf(g_l * g_l, g_l, cp.opsin_bias[0]) * cp.itscale;
+    v[1] = __builtin_fmaf(g_m * g_m, g_m, cp.opsin_bias[1]) * cp.itscale;
+    v[2] = __builtin_fmaf(g_s * g_s, g_s, cp.opsin_bias[2]) * cp.itscale;
+    matmul3vec_dev(cp.matrix, v);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = linear_to_srgb_dev(v[c]);
+}

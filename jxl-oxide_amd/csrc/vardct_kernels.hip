@@ -285,8 +285,9 @@ __device__ void transform_afv(Blk<S> c, int n, const SecLarge& sl) {
 
 // ---------------------------------------------------------------- V4-V8: the varblock kernel
 // W, H: pixel size of the varblock shape; SPECIAL: the 8x8 non-DCT8 family.
-// list[i] = cell_x | cell_y << 16 (top-left 8x8 cell of the varblock), sorted by group then
-// raster so neighbouring lanes touch neighbouring cache lines.
+// entries[i] = {cell_x | cell_y << 16, TransformType, hf_mul, 0}: one 16-byte record per varblock,
+// written by the host at upload in group-then-raster order so neighbouring lanes touch
+// neighbouring cache lines and no lane has to chase BlockInfo -> hf_mul -> LF through HBM.
 template <int W, int H>
 struct VbCfg {
     static constexpr int BW = W / 8, BH = H / 8;
@@ -294,38 +295,76 @@ struct VbCfg {
     static constexpr int S = W + 1;            // padded LDS row stride (words)
     static constexpr int BLK = H * S;          // words per block per channel
     static constexpr int CH = NB * BLK;        // words per channel
+    static constexpr int LDS_WORDS = 3 * CH + NB;  // tiles + per-block cell position
 };
 
 template <int W, int H, bool SPECIAL>
-__global__ __launch_bounds__(256) void transform_kernel(TransformArgs a, const uint32_t* __restrict__ list,
-                                                        uint32_t count) {
+__device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* __restrict__ entries,
+                                          int nvalid, float* lds) {
     using Cfg = VbCfg<W, H>;
     constexpr int NB = Cfg::NB, S = Cfg::S, BLK = Cfg::BLK, CH = Cfg::CH, BW = Cfg::BW, BH = Cfg::BH;
-    __shared__ float tile[3 * CH];
-    __shared__ float s_mul[NB][3];
-    __shared__ uint32_t s_cell[NB];  // cx | cy << 16
-    __shared__ uint32_t s_type[NB];
-    __shared__ float s_llf[NB][3][BW * BH];
+    float* tile = lds;
+    uint32_t* s_cell = reinterpret_cast<uint32_t*>(lds + 3 * CH);
 
     const SecLarge sl{a.sec64, a.sec128, a.sec256};
     const int t = threadIdx.x;
-    const uint32_t base = blockIdx.x * NB;
-    const int nvalid = (int)min((uint32_t)NB, count - base);
 
-    // ---- P0: per-(block, channel) setup: multiplier (mod.rs:513-514) and the LLF coefficients
+    // ---- A1: 4 coefficients x 3 channels per lane-iteration: dequantise (V4, mod.rs:513-537),
+    //          chroma-from-luma (V5, mod.rs:589-600), stage in LDS.  The LLF corner is left to A2.
+    constexpr int VEC_PER_BLK = W * H / 4;
+    constexpr int VECS = NB * VEC_PER_BLK;
+#pragma unroll 2
+    for (int v4 = t; v4 < VECS; v4 += 256) {
+        int blk = v4 / VEC_PER_BLK;
+        if (blk >= nvalid) break;
+        int r = v4 % VEC_PER_BLK;
+        int y = r / (W / 4), x = (r % (W / 4)) * 4;
+        const uint4 e = entries[blk];
+        if (r == 0) s_cell[blk] = e.x;
+        uint32_t px = (e.x & 0xffffu) * 8 + x, py = (e.x >> 16) * 8 + y;
+        size_t goff = (size_t)py * a.cstride + px;
+        int4 q[3];
+        float4 m[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            q[c] = *reinterpret_cast<const int4*>(a.coeff[c] + goff);
+            uint32_t off = a.deq_off[e.y * 3 + c];
+            m[c] = *reinterpret_cast<const float4*>(a.dequant + off + y * W + x);
+        }
+        float kx = a.kx_map[(py >> 6) * a.w64 + (px >> 6)];
+        float kb = a.kb_map[(py >> 6) * a.w64 + (px >> 6)];
+        const float mul_base = 65536.0f / (a.global_scale * (float)(int32_t)e.z);
+        float d[3][4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float mul = mul_base * a.qm_scale[c];
+            d[c][0] = dequant_one(q[c].x, a.quant_bias[c], a.quant_bias_numerator, m[c].x, mul);
+            d[c][1] = dequant_one(q[c].y, a.quant_bias[c], a.quant_bias_numerator, m[c].y, mul);
+            d[c][2] = dequant_one(q[c].z, a.quant_bias[c], a.quant_bias_numerator, m[c].z, mul);
+            d[c][3] = dequant_one(q[c].w, a.quant_bias[c], a.quant_bias_numerator, m[c].w, mul);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float cy_ = d[1][j];
+            d[0][j] += kx * cy_;
+            d[2][j] += kb * cy_;
+        }
+        const bool corner_row = y < BH && x < BW;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float* dst = tile + c * CH + blk * BLK + y * S + x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!(corner_row && x + j < BW)) dst[j] = d[c][j];
+        }
+    }
+    // ---- A2: one lane per (block, channel): LF -> lowest-frequency coefficients
     //          (transform_common.rs:40-66: copy LF, forward DCT, divide by scale_f products)
     if (t < NB * 3) {
         int blk = t / 3, c = t % 3;
         if (blk < nvalid) {
-            uint32_t e = list[base + blk];
-            uint32_t cx = e & 0xffffu, cy = e >> 16;
-            size_t cell = (size_t)cy * a.w8 + cx;
-            if (c == 0) {
-                s_cell[blk] = e;
-                s_type[blk] = a.kind[cell];
-            }
-            float mul = 65536.0f / (a.global_scale * (float)a.hf_mul[cell]) * a.qm_scale[c];
-            s_mul[blk][c] = mul;
+            const uint32_t pos = entries[blk].x;
+            size_t cell = (size_t)(pos >> 16) * a.w8 + (pos & 0xffffu);
             float v[BH][BW];
 #pragma unroll
             for (int y = 0; y < BH; ++y)
@@ -339,64 +378,11 @@ __global__ __launch_bounds__(256) void transform_kernel(TransformArgs a, const u
 #pragma unroll
                     for (int x = 0; x < BW; ++x) v[y][x] /= kScaleF[y << sy] * kScaleF[x << sx];
             }
+            float* dst = tile + c * CH + blk * BLK;
 #pragma unroll
             for (int y = 0; y < BH; ++y)
 #pragma unroll
-                for (int x = 0; x < BW; ++x) s_llf[blk][c][y * BW + x] = v[y][x];
-        }
-    }
-    __syncthreads();
-
-    // ---- P1: load 4 coefficients x 3 channels per lane-iteration, dequantise (V4), apply
-    //          chroma-from-luma (V5, mod.rs:589-600), drop in the LLF corner, stage in LDS
-    constexpr int VEC_PER_BLK = W * H / 4;
-    constexpr int VECS = NB * VEC_PER_BLK;
-    for (int v4 = t; v4 < VECS; v4 += 256) {
-        int blk = v4 / VEC_PER_BLK;
-        if (blk >= nvalid) break;
-        int r = v4 % VEC_PER_BLK;
-        int y = r / (W / 4), x = (r % (W / 4)) * 4;
-        uint32_t e = s_cell[blk];
-        uint32_t px = (e & 0xffffu) * 8 + x, py = (e >> 16) * 8 + y;
-        uint32_t type = s_type[blk];
-        size_t goff = (size_t)py * a.cstride + px;
-        int4 q[3];
-        float4 m[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            q[c] = *reinterpret_cast<const int4*>(a.coeff[c] + goff);
-            uint32_t off = a.deq_off[type * 3 + c];
-            m[c] = *reinterpret_cast<const float4*>(a.dequant + off + y * W + x);
-        }
-        float kx = a.kx_map[(py >> 6) * a.w64 + (px >> 6)];
-        float kb = a.kb_map[(py >> 6) * a.w64 + (px >> 6)];
-        float d[3][4];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float mul = s_mul[blk][c];
-            d[c][0] = dequant_one(q[c].x, a.quant_bias[c], a.quant_bias_numerator, m[c].x, mul);
-            d[c][1] = dequant_one(q[c].y, a.quant_bias[c], a.quant_bias_numerator, m[c].y, mul);
-            d[c][2] = dequant_one(q[c].z, a.quant_bias[c], a.quant_bias_numerator, m[c].z, mul);
-            d[c][3] = dequant_one(q[c].w, a.quant_bias[c], a.quant_bias_numerator, m[c].w, mul);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float cy_ = d[1][j];
-            d[0][j] += kx * cy_;
-            d[2][j] += kb * cy_;
-        }
-        if (y < BH && x < BW) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (x + j < BW) d[c][j] = s_llf[blk][c][y * BW + x + j];
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float* dst = tile + c * CH + blk * BLK + y * S + x;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dst[j] = d[c][j];
+                for (int x = 0; x < BW; ++x) dst[y * S + x] = v[y][x];
         }
     }
     __syncthreads();
@@ -407,7 +393,7 @@ __global__ __launch_bounds__(256) void transform_kernel(TransformArgs a, const u
             int blk = t / 3, c = t % 3;
             if (blk < nvalid) {
                 Blk<S> b{tile + c * CH + blk * BLK};
-                switch (s_type[blk]) {
+                switch (entries[blk].y) {
                     case JXLGPU_DCT2: transform_dct2<S>(b); break;
                     case JXLGPU_DCT4: transform_dct4<S>(b, sl); break;
                     case JXLGPU_HORNUSS: transform_hornuss<S>(b); break;
@@ -472,32 +458,87 @@ __global__ __launch_bounds__(256) void transform_kernel(TransformArgs a, const u
     }
 }
 
-template <int W, int H, bool SPECIAL>
-static void launch_tk(hipStream_t s, const TransformArgs& a, const uint32_t* list, uint32_t count) {
-    constexpr int NB = VbCfg<W, H>::NB;
-    transform_kernel<W, H, SPECIAL><<<ceil_div(count, NB), 256, 0, s>>>(a, list, count);
+// All varblock shapes up to 32x32 in ONE launch: every workgroup reads its descriptor
+// {class, first entry, count} and branches (workgroup-uniformly) into the code for that shape, so
+// the thin classes (a few hundred 32x8 blocks...) fill the machine together instead of each
+// paying a launch and a tail.
+__global__ __launch_bounds__(256) void transform_small_kernel(TransformArgs a, const uint4* __restrict__ wgs,
+                                                              const uint4* __restrict__ entries) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const uint4 wg = wgs[blockIdx.x];
+    const uint4* e = entries + wg.y;
+    const int n = (int)wg.z;
+    switch (wg.x) {
+        case CLS_DCT8: run_class<8, 8, false>(a, e, n, lds); break;
+        case CLS_16x16: run_class<16, 16, false>(a, e, n, lds); break;
+        case CLS_8x16: run_class<8, 16, false>(a, e, n, lds); break;
+        case CLS_16x8: run_class<16, 8, false>(a, e, n, lds); break;
+        case CLS_32x32: run_class<32, 32, false>(a, e, n, lds); break;
+        case CLS_8x32: run_class<8, 32, false>(a, e, n, lds); break;
+        case CLS_32x8: run_class<32, 8, false>(a, e, n, lds); break;
+        case CLS_16x32: run_class<16, 32, false>(a, e, n, lds); break;
+        case CLS_32x16: run_class<32, 16, false>(a, e, n, lds); break;
+        default: break;
+    }
 }
 
-void launch_big_blocks(hipStream_t s, const TransformArgs& a, const uint32_t* list, uint32_t count);
+constexpr int kSmallLdsWords = 3 * 2304 + 32;  // max over the classes above (VbCfg::LDS_WORDS)
+static_assert(VbCfg<8, 8>::LDS_WORDS <= kSmallLdsWords && VbCfg<16, 16>::LDS_WORDS <= kSmallLdsWords &&
+              VbCfg<8, 16>::LDS_WORDS <= kSmallLdsWords && VbCfg<16, 8>::LDS_WORDS <= kSmallLdsWords &&
+              VbCfg<32, 32>::LDS_WORDS <= kSmallLdsWords && VbCfg<8, 32>::LDS_WORDS <= kSmallLdsWords &&
+              VbCfg<32, 8>::LDS_WORDS <= kSmallLdsWords && VbCfg<16, 32>::LDS_WORDS <= kSmallLdsWords &&
+              VbCfg<32, 16>::LDS_WORDS <= kSmallLdsWords, "LDS budget of transform_small_kernel");
 
-void launch_transform_class(hipStream_t s, int cls, const TransformArgs& a, const uint32_t* list,
+void launch_transform_small(hipStream_t s, const TransformArgs& a, const uint4* wgs, uint32_t n_wgs,
+                            const uint4* entries) {
+    if (!n_wgs) return;
+    transform_small_kernel<<<n_wgs, 256, kSmallLdsWords * sizeof(float), s>>>(a, wgs, entries);
+}
+
+// The 8x8 non-DCT family (Hornuss, DCT2, DCT4, 4x8, 8x4, AFV): register-hungry serial code per
+// block, kept out of the kernel above so it does not drag its occupancy down; runs on the side
+// stream together with the 64-pixel shapes.
+__global__ __launch_bounds__(256) void transform_special_kernel(TransformArgs a, const uint4* __restrict__ entries,
+                                                                uint32_t count) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NB = VbCfg<8, 8>::NB;
+    const uint32_t first = blockIdx.x * NB;
+    run_class<8, 8, true>(a, entries + first, (int)min((uint32_t)NB, count - first), lds);
+}
+
+// 64-pixel shapes: one varblock per workgroup (49 KiB of LDS, 64-point butterflies in registers).
+template <int W, int H>
+__global__ __launch_bounds__(256) void transform_kernel64(TransformArgs a, const uint4* __restrict__ entries) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    run_class<W, H, false>(a, entries + blockIdx.x, 1, lds);
+}
+
+template <int W, int H>
+static void launch_tk64(hipStream_t s, const TransformArgs& a, const uint4* entries, uint32_t count) {
+    constexpr int bytes = VbCfg<W, H>::LDS_WORDS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&transform_kernel64<W, H>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        attr_set = true;
+    }
+    transform_kernel64<W, H><<<count, 256, bytes, s>>>(a, entries);
+}
+
+void launch_big_blocks(hipStream_t s, const TransformArgs& a, const uint4* entries, uint32_t count);
+
+void launch_transform_class(hipStream_t s, int cls, const TransformArgs& a, const uint4* entries,
                             uint32_t count) {
     if (count == 0) return;
     switch (cls) {
-        case CLS_DCT8: launch_tk<8, 8, false>(s, a, list, count); break;
-        case CLS_SPECIAL8: launch_tk<8, 8, true>(s, a, list, count); break;
-        case CLS_16x16: launch_tk<16, 16, false>(s, a, list, count); break;
-        case CLS_8x16: launch_tk<8, 16, false>(s, a, list, count); break;
-        case CLS_16x8: launch_tk<16, 8, false>(s, a, list, count); break;
-        case CLS_32x32: launch_tk<32, 32, false>(s, a, list, count); break;
-        case CLS_8x32: launch_tk<8, 32, false>(s, a, list, count); break;
-        case CLS_32x8: launch_tk<32, 8, false>(s, a, list, count); break;
-        case CLS_16x32: launch_tk<16, 32, false>(s, a, list, count); break;
-        case CLS_32x16: launch_tk<32, 16, false>(s, a, list, count); break;
-        case CLS_64x64: launch_tk<64, 64, false>(s, a, list, count); break;
-        case CLS_32x64: launch_tk<32, 64, false>(s, a, list, count); break;
-        case CLS_64x32: launch_tk<64, 32, false>(s, a, list, count); break;
-        case CLS_BIG: launch_big_blocks(s, a, list, count); break;
+        case CLS_SPECIAL8:
+            transform_special_kernel<<<ceil_div(count, VbCfg<8, 8>::NB), 256,
+                                       VbCfg<8, 8>::LDS_WORDS * sizeof(float), s>>>(a, entries, count);
+            break;
+        case CLS_64x64: launch_tk64<64, 64>(s, a, entries, count); break;
+        case CLS_32x64: launch_tk64<32, 64>(s, a, entries, count); break;
+        case CLS_64x32: launch_tk64<64, 32>(s, a, entries, count); break;
+        case CLS_BIG: launch_big_blocks(s, a, entries, count); break;
         default: break;
     }
 }
