@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 3u
+#define JXLGPU_ABI_VERSION 4u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -260,6 +260,12 @@ typedef struct {
     const JxlGpuModularChannel* meta_channels;
     uint32_t num_transforms;     /* in bitstream order; the inverse runs them in reverse             */
     const JxlGpuTransform* transforms;
+    /* M4, predictor application where it is separable from the entropy decode: 0xFFFFFFFF = the
+     * channel buffers already hold reconstructed samples; 5 = they hold Gradient-predictor
+     * residuals of a single-leaf tree (`decode_simple_grad`, jxl-modular/src/image.rs:821-872),
+     * applied per group_dim x group_dim tile.  Anything else: JXLGPU_ERR_UNSUPPORTED.               */
+    uint32_t residual_predictor;
+    uint32_t group_dim;
     /* what happens after the inverse transforms (jxl-render/src/image.rs:93-189) */
     uint32_t xyb_encoded;        /* 1: convert_modular_xyb (M5); 0: int -> float by bit depth (C5)    */
     float m_lf_unscaled[3];      /* m_x_lf/128, m_y_lf/128, m_b_lf/128 (lf.rs:37-50)                  */

@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -182,6 +182,8 @@ class ModularDesc(C.Structure):
         ("meta_channels", C.POINTER(ModularChannel)),
         ("num_transforms", C.c_uint32),
         ("transforms", C.POINTER(Transform)),
+        ("residual_predictor", C.c_uint32),
+        ("group_dim", C.c_uint32),
         ("xyb_encoded", C.c_uint32),
         ("m_lf_unscaled", C.c_float * 3),
         ("float_sample", C.c_uint32),

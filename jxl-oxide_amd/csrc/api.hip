@@ -122,6 +122,8 @@ std::vector<float> expand_up_weights(const float* weights, int k) {
 
 }  // namespace
 
+void fill_color_args_public(const JxlGpuColorParams& cp, ColorArgs* c) { fill_color_args(cp, c); }
+
 int upload_post_params(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuUpsampling& up) {
     const float* src[3] = {up.up2_weight, up.up4_weight, up.up8_weight};
     const int ks[3] = {2, 4, 8};
@@ -210,6 +212,7 @@ void jxlgpu_frame_free(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
         (void)hipStreamSynchronize(ctx->stream);
     }
     for (void* p : f->allocs) (void)hipFree(p);
+    if (f->modular && f->modular_free) f->modular_free(f->modular);
     delete f;
 }
 
@@ -454,7 +457,7 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
 int jxlgpu_frame_out_size(const jxlgpu_frame* f, uint32_t stages, uint32_t* width, uint32_t* height) {
     if (!f) return JXLGPU_ERR_INVALID_ARG;
     uint32_t k = 1;
-    if (f->kind_of_frame == 0) k = (stages & JXLGPU_STAGE_UPSAMPLE) && f->desc.upsampling.factor > 1 ? f->desc.upsampling.factor : 1;
+    k = (stages & JXLGPU_STAGE_UPSAMPLE) && f->desc.upsampling.factor > 1 ? f->desc.upsampling.factor : 1;
     if (width) *width = f->width * k;
     if (height) *height = f->height * k;
     return JXLGPU_OK;

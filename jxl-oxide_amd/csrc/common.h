@@ -184,6 +184,7 @@ struct jxlgpu_frame {
     uint32_t result_stride = 0, result_w = 0, result_h = 0;
     // modular state lives in modular.hip's own struct
     void* modular = nullptr;
+    void (*modular_free)(void*) = nullptr;
 };
 
 #define HIP_TRY(ctx, expr)                                                           \

@@ -1,15 +1,715 @@
-// Modular inverse transforms (placeholder exports until the Squeeze/RCT/Palette kernels land).
+// Modular stage for gfx950: predictor application where it is separable (Gradient, single leaf),
+// inverse Squeeze / RCT / Palette on the integer channel buffers, and the int -> float tail.
+//
+// Integer, wrapping arithmetic in the sample type S (i16 or i32) exactly as the reference
+// (jxl-modular/src/transform/{squeeze,rct,palette}.rs); results are bit-exact.
+//
+// Layout: every channel is a full-resolution buffer holding the squeezed pyramid as nested
+// sub-rectangles (avg = left/top half, residual = right/bottom half, transform.rs:343-437).  The
+// CPU code undoes a step in place through a per-row scratch copy; here each step reads the avg and
+// residual rectangles from where they live and writes the merged rectangle into another of three
+// working copies of the buffer (the merged rectangle overlaps both inputs, so in place would race
+// across lanes).  Parallelism is what the transform allows: one lane per row (horizontal step) or
+// per column (vertical step), each lane a serial chain because `tendency` needs the previous
+// output sample.
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
 #include "common.h"
 
+int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuFilterParams& fp,
+                    uint32_t up_factor, float* cur[3], uint32_t* cur_stride, uint32_t* ow, uint32_t* oh);
+int finish_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stride, uint32_t ow, uint32_t oh,
+                  const JxlGpuOut* out);
+int upload_post_params(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuUpsampling& up);
+void fill_color_args_public(const JxlGpuColorParams& cp, ColorArgs* c);
+
+namespace {
+
+// ---------------------------------------------------------------- device: Squeeze
+// tendency_i32 / tendency_i16, squeeze.rs:1104-1172 (Wrapping<S> == truncate to S after every op)
+template <typename S>
+__device__ __forceinline__ S tendency(S a, S b, S c) {
+    if (a >= b && b >= c) {
+        S x = (S)((S)((S)((S)((S)(4 * a) - (S)(3 * c)) - b) + 6) / 12);
+        if ((S)(x - (x & 1)) > (S)(2 * (S)(a - b))) x = (S)((S)(2 * (S)(a - b)) + 1);
+        if ((S)(x + (x & 1)) > (S)(2 * (S)(b - c))) x = (S)(2 * (S)(b - c));
+        return x;
+    } else if (a <= b && b <= c) {
+        S x = (S)((S)((S)((S)((S)(4 * a) - (S)(3 * c)) - b) - 6) / 12);
+        if ((S)(x + (x & 1)) < (S)(2 * (S)(a - b))) x = (S)((S)(2 * (S)(a - b)) - 1);
+        if ((S)(x - (x & 1)) < (S)(2 * (S)(b - c))) x = (S)(2 * (S)(b - c));
+        return x;
+    }
+    return 0;
+}
+
+// i32 needs 4*a etc. to wrap without UB: go through unsigned
+template <>
+__device__ __forceinline__ int32_t tendency<int32_t>(int32_t a, int32_t b, int32_t c) {
+    auto W = [](uint32_t v) { return (int32_t)v; };
+    const uint32_t ua = (uint32_t)a, ub = (uint32_t)b, uc = (uint32_t)c;
+    if (a >= b && b >= c) {
+        int32_t x = W(4u * ua - 3u * uc - ub + 6u) / 12;
+        int32_t ab2 = W(2u * (ua - ub)), bc2 = W(2u * (ub - uc));
+        if (W((uint32_t)x - (uint32_t)(x & 1)) > ab2) x = W((uint32_t)ab2 + 1u);
+        if (W((uint32_t)x + (uint32_t)(x & 1)) > bc2) x = bc2;
+        return x;
+    } else if (a <= b && b <= c) {
+        int32_t x = W(4u * ua - 3u * uc - ub - 6u) / 12;
+        int32_t ab2 = W(2u * (ua - ub)), bc2 = W(2u * (ub - uc));
+        if (W((uint32_t)x + (uint32_t)(x & 1)) < ab2) x = W((uint32_t)ab2 - 1u);
+        if (W((uint32_t)x - (uint32_t)(x & 1)) < bc2) x = bc2;
+        return x;
+    }
+    return 0;
+}
+
+template <typename S>
+struct Wrap;
+template <>
+struct Wrap<int16_t> {
+    static __device__ __forceinline__ int16_t add(int16_t a, int16_t b) { return (int16_t)(a + b); }
+    static __device__ __forceinline__ int16_t sub(int16_t a, int16_t b) { return (int16_t)(a - b); }
+};
+template <>
+struct Wrap<int32_t> {
+    static __device__ __forceinline__ int32_t add(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+    static __device__ __forceinline__ int32_t sub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+};
+
+struct SqzArgs {
+    const void* avg;   // top-left of the avg rectangle
+    const void* res;   // top-left of the residual rectangle
+    void* out;         // top-left of the merged rectangle (another working copy)
+    uint32_t avg_stride, res_stride, out_stride;  // elements
+    uint32_t width, height;                       // merged size
+};
+
+// inverse_v_*_base, squeeze.rs:803-862: one lane per column, coalesced row accesses
+template <typename S>
+__global__ __launch_bounds__(64) void squeeze_v_kernel(SqzArgs a) {
+    uint32_t x = blockIdx.x * 64 + threadIdx.x;
+    if (x >= a.width) return;
+    const S* avgp = (const S*)a.avg + x;
+    const S* resp = (const S*)a.res + x;
+    S* out = (S*)a.out + x;
+    const uint32_t avg_h = (a.height + 1) / 2, pairs = a.height / 2;
+    S avg = avgp[0];
+    S top = avg;
+    S nxt = avg_h > 1 ? avgp[a.avg_stride] : avg;
+    uint32_t y = 0;
+    // software pipeline: 4 residuals / next-avgs in flight per lane
+    for (; y + 4 <= pairs; y += 4) {
+        S r[4], n[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r[k] = resp[(size_t)(y + k) * a.res_stride];
+            uint32_t ny = y + k + 2;
+            n[k] = ny < avg_h ? avgp[(size_t)ny * a.avg_stride] : (S)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            S next_avg = (y + k + 1 < avg_h) ? nxt : avg;
+            S diff = Wrap<S>::add(r[k], tendency<S>(top, avg, next_avg));
+            S first = Wrap<S>::add(avg, (S)(diff / 2));
+            S second = Wrap<S>::sub(first, diff);
+            out[(size_t)(2 * (y + k)) * a.out_stride] = first;
+            out[(size_t)(2 * (y + k) + 1) * a.out_stride] = second;
+            avg = next_avg;
+            top = second;
+            nxt = n[k];
+        }
+    }
+    for (; y < pairs; ++y) {
+        S r = resp[(size_t)y * a.res_stride];
+        S next_avg = (y + 1 < avg_h) ? nxt : avg;
+        S n2 = (y + 2 < avg_h) ? avgp[(size_t)(y + 2) * a.avg_stride] : (S)0;
+        S diff = Wrap<S>::add(r, tendency<S>(top, avg, next_avg));
+        S first = Wrap<S>::add(avg, (S)(diff / 2));
+        S second = Wrap<S>::sub(first, diff);
+        out[(size_t)(2 * y) * a.out_stride] = first;
+        out[(size_t)(2 * y + 1) * a.out_stride] = second;
+        avg = next_avg;
+        top = second;
+        nxt = n2;
+    }
+    if (a.height & 1) out[(size_t)(a.height - 1) * a.out_stride] = avgp[(size_t)(avg_h - 1) * a.avg_stride];
+}
+
+// inverse_h_*_base, squeeze.rs:59-120: 64 rows per wave.  Rows are staged through LDS in
+// 64 x CH tiles so global accesses stay coalesced along x while every lane walks its own row.
+template <typename S>
+__global__ __launch_bounds__(64) void squeeze_h_kernel(SqzArgs a) {
+    constexpr int CH = 32;                       // pairs per chunk
+    __shared__ S s_avg[64][CH + 2];
+    __shared__ S s_res[64][CH + 1];
+    __shared__ S s_out[64][2 * CH + 1];
+    const int lane = threadIdx.x;
+    const uint32_t y0 = blockIdx.x * 64;
+    const uint32_t rows = min(64u, a.height - y0);
+    const uint32_t avg_w = (a.width + 1) / 2, pairs = a.width / 2;
+    const S* avgp = (const S*)a.avg + (size_t)y0 * a.avg_stride;
+    const S* resp = (const S*)a.res + (size_t)y0 * a.res_stride;
+    S* outp = (S*)a.out + (size_t)y0 * a.out_stride;
+
+    S avg = 0, left = 0;
+    for (uint32_t x0 = 0; x0 < pairs; x0 += CH) {
+        const uint32_t n = min((uint32_t)CH, pairs - x0);
+        // cooperative, row-major loads: lane = column within the chunk
+        for (uint32_t r = 0; r < rows; ++r) {
+            for (uint32_t c = lane; c < n + 1; c += 64) {
+                uint32_t ax = x0 + c;
+                s_avg[r][c] = ax < avg_w ? avgp[(size_t)r * a.avg_stride + ax] : (S)0;
+            }
+            for (uint32_t c = lane; c < n; c += 64) s_res[r][c] = resp[(size_t)r * a.res_stride + x0 + c];
+        }
+        __syncthreads();
+        if ((uint32_t)lane < rows) {
+            if (x0 == 0) { avg = s_avg[lane][0]; left = avg; }
+            for (uint32_t c = 0; c < n; ++c) {
+                S residu = s_res[lane][c];
+                S next_avg = (x0 + c + 1 < avg_w) ? s_avg[lane][c + 1] : avg;
+                S diff = Wrap<S>::add(residu, tendency<S>(left, avg, next_avg));
+                S first = Wrap<S>::add(avg, (S)(diff / 2));
+                S second = Wrap<S>::sub(first, diff);
+                s_out[lane][2 * c] = first;
+                s_out[lane][2 * c + 1] = second;
+                avg = next_avg;
+                left = second;
+            }
+        }
+        __syncthreads();
+        for (uint32_t r = 0; r < rows; ++r)
+            for (uint32_t c = lane; c < 2 * n; c += 64) outp[(size_t)r * a.out_stride + 2 * x0 + c] = s_out[r][c];
+        __syncthreads();
+    }
+    if ((a.width & 1) && (uint32_t)lane < rows)
+        outp[(size_t)lane * a.out_stride + a.width - 1] = avgp[(size_t)lane * a.avg_stride + avg_w - 1];
+}
+
+// ---------------------------------------------------------------- device: RCT, palette, gradient
+struct RctArgs {
+    void* p[3];
+    uint32_t stride[3];
+    uint32_t width, height, rct_type;
+};
+
+// inverse_row_*_base + inverse_permute, rct.rs:154-256
+template <typename S>
+__global__ __launch_bounds__(256) void rct_kernel(RctArgs g) {
+    uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= g.width) return;
+    S* pa = (S*)g.p[0] + (size_t)y * g.stride[0] + x;
+    S* pb = (S*)g.p[1] + (size_t)y * g.stride[1] + x;
+    S* pc = (S*)g.p[2] + (size_t)y * g.stride[2] + x;
+    const uint32_t permutation = g.rct_type / 7, type = g.rct_type % 7;
+    S a = *pa, b = *pb, c = *pc, d, e, f;
+    if (type == 6) {
+        S tmp = Wrap<S>::sub(a, (S)(c >> 1));
+        e = Wrap<S>::add(c, tmp);
+        f = Wrap<S>::sub(tmp, (S)(b >> 1));
+        d = Wrap<S>::add(f, b);
+    } else {
+        d = a;
+        f = (type & 1) ? Wrap<S>::add(c, a) : c;
+        e = (type >> 1) == 1 ? Wrap<S>::add(b, a)
+          : (type >> 1) == 2 ? Wrap<S>::add(b, (S)(Wrap<S>::add(a, f) >> 1)) : b;
+    }
+    S o0 = d, o1 = e, o2 = f;  // rows after inverse_permute's swap sequence
+    switch (permutation) {
+        case 1: o0 = f; o1 = d; o2 = e; break;
+        case 2: o0 = e; o1 = f; o2 = d; break;
+        case 3: o0 = d; o1 = f; o2 = e; break;
+        case 4: o0 = e; o1 = d; o2 = f; break;
+        case 5: o0 = f; o1 = e; o2 = d; break;
+        default: break;
+    }
+    *pa = o0; *pb = o1; *pc = o2;
+}
+
+struct PalArgs {
+    const void* palette;   // nb_colours x num_c, stride pal_stride
+    void* idx;             // leader (index) grid
+    void* dst[8];          // dst[0] = leader itself
+    uint32_t pal_stride, idx_stride, dst_stride[8];
+    uint32_t width, height, num_c, nb_colours;
+    int* not_simple;       // set to 1 when an index is outside [0, nb_colours)
+};
+
+// inverse_simple, palette.rs:146-173 (+ the is_simple scan, :37-45)
+template <typename S>
+__global__ __launch_bounds__(256) void palette_kernel(PalArgs g) {
+    uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= g.width) return;
+    int32_t index = ((const S*)g.idx)[(size_t)y * g.idx_stride + x];
+    if (index < 0 || index >= (int32_t)g.nb_colours) {
+        atomicOr(g.not_simple, 1);
+        return;
+    }
+    for (uint32_t c = g.num_c; c-- > 0;)
+        ((S*)g.dst[c])[(size_t)y * g.dst_stride[c] + x] = ((const S*)g.palette)[(size_t)c * g.pal_stride + index];
+}
+
+// decode_simple_grad arithmetic (image.rs:821-872) on one group_dim x group_dim tile per
+// workgroup: lane r owns row r and trails row r-1 by one column (wavefront), samples staged in LDS.
+template <typename S>
+__global__ __launch_bounds__(256) void gradient_kernel(void* buf, uint32_t stride, uint32_t width, uint32_t height,
+                                                       uint32_t group_dim) {
+    S* base = (S*)buf;
+    const uint32_t x0 = blockIdx.x * group_dim, y0 = blockIdx.y * group_dim;
+    const uint32_t gw = min(group_dim, width - x0), gh = min(group_dim, height - y0);
+    S* g = base + (size_t)y0 * stride + x0;
+    const uint32_t r = threadIdx.x;  // group_dim <= 256 rows
+    // wavefront: at step s lane r handles column s - r.  Rows of the previous lane are read back
+    // from global memory (L1/L2) after a workgroup barrier.
+    S w = 0;
+    for (uint32_t s = 0; s < gw + gh - 1; ++s) {
+        int32_t x = (int32_t)s - (int32_t)r;
+        if (r < gh && x >= 0 && x < (int32_t)gw) {
+            S* row = g + (size_t)r * stride;
+            S res = row[x];
+            S value;
+            if (r == 0) {
+                value = Wrap<S>::add(res, w);
+            } else {
+                const S* prev = row - stride;
+                if (x == 0) {
+                    value = Wrap<S>::add(res, prev[0]);
+                } else {
+                    int64_t n = prev[x], nw = prev[x - 1], ww = w;
+                    int64_t hi = ww > n ? ww : n, lo = ww > n ? n : ww;
+                    int64_t p = lo + hi - nw;
+                    p = p < lo ? lo : (p > hi ? hi : p);
+                    value = Wrap<S>::add(res, (S)p);
+                }
+            }
+            row[x] = value;
+            w = value;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- device: int -> float
+struct ToFloatArgs {
+    const void* in[3];
+    float* out[3];
+    uint32_t in_stride[3], out_stride, width, height;
+    uint32_t xyb, is_i16, bit_depth, float_sample, exp_bits;
+    float m[3];
+};
+
+// convert_to_float_modular_xyb (jxl-render/src/image.rs:148-189) or BitDepth::parse_integer_sample
+// (jxl-image/src/lib.rs:458-494); output planes in framebuffer order.
+__global__ __launch_bounds__(256) void to_float_kernel(ToFloatArgs a) {
+    uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= a.width) return;
+    int32_t v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        size_t i = (size_t)y * a.in_stride[c] + x;
+        v[c] = a.is_i16 ? (int32_t)((const int16_t*)a.in[c])[i] : ((const int32_t*)a.in[c])[i];
+    }
+    size_t o = (size_t)y * a.out_stride + x;
+    if (a.xyb) {
+        int32_t yv = v[0], xv = v[1], bv = v[2], bs;
+        if (a.is_i16) {
+            int32_t t = bv + yv;
+            bs = t > 32767 ? 32767 : (t < -32768 ? -32768 : t);
+        } else {
+            int64_t t = (int64_t)bv + yv;
+            bs = t > 2147483647ll ? 2147483647 : (t < -2147483648ll ? (int32_t)-2147483648ll : (int32_t)t);
+        }
+        a.out[0][o] = (float)xv * a.m[0];
+        a.out[1][o] = (float)yv * a.m[1];
+        a.out[2][o] = (float)bs * a.m[2];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float r;
+            if (!a.float_sample) {
+                int32_t div = (int32_t)((1u << a.bit_depth) - 1);
+                r = (float)v[c] / (float)div;
+            } else {
+                uint32_t s = (uint32_t)v[c];
+                uint32_t mantissa_bits = a.bit_depth - a.exp_bits - 1;
+                uint32_t mantissa_mask = (1u << mantissa_bits) - 1;
+                uint32_t exp_mask = ((1u << (a.bit_depth - 1)) - 1) ^ mantissa_mask;
+                uint32_t is_signed = (s & (1u << (a.bit_depth - 1))) != 0;
+                uint32_t mantissa = s & mantissa_mask;
+                int32_t exp = (int32_t)((s & exp_mask) >> mantissa_bits) - ((1 << (a.exp_bits - 1)) - 1);
+                if (mantissa_bits < 23) mantissa <<= (23 - mantissa_bits);
+                else if (mantissa_bits > 23) mantissa >>= (mantissa_bits - 23);
+                r = __uint_as_float((is_signed << 31) | ((uint32_t)(exp + 127) << 23) | mantissa);
+            }
+            a.out[c][o] = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host: bookkeeping
+struct Grid {
+    int buf;                 // >= 0 channel buffer, < 0: ~meta index
+    uint32_t x0, y0, w, h;
+    int loc;                 // which working copy holds the data (channel buffers only)
+    std::vector<int> members;  // palette: buffers of the merged member channels
+};
+
+struct ModularState {
+    JxlGpuModularDesc desc;  // scalar copy
+    size_t esz = 4;
+    std::vector<uint32_t> cw, ch;             // channel buffer sizes
+    std::vector<void*> orig;                  // uploaded buffers (never modified)
+    std::vector<void*> work[3];               // working copies
+    std::vector<void*> meta;
+    std::vector<uint32_t> mw, mh;
+    std::vector<JxlGpuTransform> transforms;
+    std::vector<std::vector<JxlGpuSqueezeStep>> explicit_steps;  // per transform (empty = default)
+    std::vector<std::vector<JxlGpuSqueezeStep>> steps;
+    std::vector<int> final_loc;               // after the last inverse run
+    int* d_flag = nullptr;
+    float* fpix[3] = {};
+};
+
+// Squeeze::set_default_params, transform.rs:285-341
+void default_squeeze(const std::vector<Grid>& l, int nb_meta, std::vector<JxlGpuSqueezeStep>* sp) {
+    uint32_t first = (uint32_t)nb_meta;
+    uint32_t w = l[first].w, h = l[first].h;
+    if (l.size() - first >= 3 && l[first + 1].w == w && l[first + 1].h == h) {
+        sp->push_back({1, 0, first + 1, 2});
+        sp->push_back({0, 0, first + 1, 2});
+    }
+    uint32_t num_c = (uint32_t)l.size() - first;
+    if (h >= w && h > 8) { sp->push_back({0, 1, first, num_c}); h = (h + 1) / 2; }
+    while (w > 8 || h > 8) {
+        if (w > 8) { sp->push_back({1, 1, first, num_c}); w = (w + 1) / 2; }
+        if (h > 8) { sp->push_back({0, 1, first, num_c}); h = (h + 1) / 2; }
+    }
+}
+
+template <typename T>
+int malloc_dev(jxlgpu_ctx* ctx, jxlgpu_frame* f, T** out, size_t bytes) {
+    void* p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, std::max<size_t>(bytes, 16)));
+    f->allocs.push_back(p);
+    *out = static_cast<T*>(p);
+    return JXLGPU_OK;
+}
+
+int fail(jxlgpu_ctx* ctx, int code, const char* msg) {
+    ctx->last_error = msg;
+    return code;
+}
+
+template <typename S>
+void launch_squeeze(hipStream_t s, bool horizontal, const SqzArgs& a) {
+    if (horizontal) squeeze_h_kernel<S><<<ceil_div(a.height, 64), 64, 0, s>>>(a);
+    else squeeze_v_kernel<S><<<ceil_div(a.width, 64), 64, 0, s>>>(a);
+}
+
+// Runs predictor application + all inverse transforms on the working copies.
+int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
+    ModularState* m = static_cast<ModularState*>(f->modular);
+    hipStream_t s = ctx->stream;
+    const bool i16 = m->desc.sample_type == JXLGPU_SAMPLE_I16;
+    const size_t esz = m->esz;
+    const uint32_t nch = (uint32_t)m->orig.size();
+    for (uint32_t c = 0; c < nch; ++c)
+        HIP_TRY(ctx, hipMemcpyAsync(m->work[0][c], m->orig[c], (size_t)m->cw[c] * m->ch[c] * esz, hipMemcpyDeviceToDevice, s));
+
+    if (m->desc.residual_predictor == 5) {
+        const uint32_t gd = m->desc.group_dim ? m->desc.group_dim : 256;
+        for (uint32_t c = 0; c < nch; ++c) {
+            dim3 grid(ceil_div(m->cw[c], gd), ceil_div(m->ch[c], gd));
+            if (i16) gradient_kernel<int16_t><<<grid, 256, 0, s>>>(m->work[0][c], m->cw[c], m->cw[c], m->ch[c], gd);
+            else gradient_kernel<int32_t><<<grid, 256, 0, s>>>(m->work[0][c], m->cw[c], m->cw[c], m->ch[c], gd);
+        }
+    }
+
+    // forward bookkeeping (transform_channel_info): which rectangle is which transformed channel
+    std::vector<Grid> l;
+    int nb_meta = 0;
+    for (uint32_t c = 0; c < nch; ++c) l.push_back(Grid{(int)c, 0, 0, m->cw[c], m->ch[c], 0, {}});
+    int meta_next = 0;
+    m->steps.assign(m->transforms.size(), {});
+    for (size_t t = 0; t < m->transforms.size(); ++t) {
+        const JxlGpuTransform& tr = m->transforms[t];
+        if (tr.kind == JXLGPU_TR_RCT) {
+            if (tr.begin_c + 3 > l.size()) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "RCT channel range");
+            const Grid& a = l[tr.begin_c];
+            for (int k = 1; k < 3; ++k)
+                if (l[tr.begin_c + k].w != a.w || l[tr.begin_c + k].h != a.h) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "RCT size mismatch");
+        } else if (tr.kind == JXLGPU_TR_PALETTE) {
+            const uint32_t begin = tr.begin_c, end = tr.begin_c + tr.num_c;
+            if (end > l.size() || tr.num_c == 0 || tr.num_c > 8 || meta_next >= (int)m->meta.size())
+                return fail(ctx, JXLGPU_ERR_INVALID_ARG, "palette parameters");
+            if (begin < (uint32_t)nb_meta) nb_meta = nb_meta + 2 - (int)tr.num_c; else nb_meta += 1;
+            for (uint32_t i = begin + 1; i < end; ++i) {
+                if (l[begin + 1].buf < 0 || l[begin + 1].w != l[begin].w || l[begin + 1].h != l[begin].h)
+                    return fail(ctx, JXLGPU_ERR_INVALID_ARG, "palette member mismatch");
+                l[begin].members.push_back(l[begin + 1].buf);
+                l.erase(l.begin() + begin + 1);
+            }
+            l.insert(l.begin(), Grid{~meta_next, 0, 0, tr.nb_colours, tr.num_c, 0, {}});
+            ++meta_next;
+        } else if (tr.kind == JXLGPU_TR_SQUEEZE) {
+            std::vector<JxlGpuSqueezeStep>& sp = m->steps[t];
+            if (!m->explicit_steps[t].empty()) sp = m->explicit_steps[t];
+            else default_squeeze(l, nb_meta, &sp);
+            for (const JxlGpuSqueezeStep& st : sp) {
+                const uint32_t begin = st.begin_c, end = st.begin_c + st.num_c;
+                if (end > l.size()) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "squeeze channel range");
+                if (begin < (uint32_t)nb_meta) {
+                    if (!st.in_place || end > (uint32_t)nb_meta) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "squeeze on meta channels");
+                    nb_meta += (int)st.num_c;
+                }
+                std::vector<Grid> res;
+                for (uint32_t i = begin; i < end; ++i) {
+                    Grid& g = l[i];
+                    if (g.w == 0 || g.h == 0 || g.buf < 0) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "cannot squeeze this channel");
+                    Grid r = g;
+                    if (st.horizontal) { uint32_t len = g.w; g.w = (len + 1) / 2; r.w = len / 2; r.x0 = g.x0 + g.w; }
+                    else { uint32_t len = g.h; g.h = (len + 1) / 2; r.h = len / 2; r.y0 = g.y0 + g.h; }
+                    res.push_back(r);
+                }
+                l.insert(st.in_place ? l.begin() + end : l.end(), res.begin(), res.end());
+            }
+        } else {
+            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "unknown transform kind");
+        }
+    }
+
+    auto ptr = [&](const Grid& g, int loc, uint32_t* stride) -> char* {
+        if (g.buf >= 0) {
+            *stride = m->cw[g.buf];
+            return (char*)m->work[loc][g.buf] + ((size_t)g.y0 * *stride + g.x0) * esz;
+        }
+        *stride = m->mw[~g.buf];
+        return (char*)m->meta[~g.buf];
+    };
+
+    // inverse, last transform first (transform.rs:75-86)
+    for (int t = (int)m->transforms.size() - 1; t >= 0; --t) {
+        const JxlGpuTransform& tr = m->transforms[t];
+        if (tr.kind == JXLGPU_TR_SQUEEZE) {
+            const std::vector<JxlGpuSqueezeStep>& sp = m->steps[t];
+            for (int i = (int)sp.size() - 1; i >= 0; --i) {
+                const JxlGpuSqueezeStep& st = sp[i];
+                const int begin = (int)st.begin_c, count = (int)st.num_c, end = begin + count;
+                const int from = st.in_place ? end : (int)l.size() - count;
+                std::vector<Grid> res(l.begin() + from, l.begin() + from + count);
+                l.erase(l.begin() + from, l.begin() + from + count);
+                for (int k = 0; k < count; ++k) {
+                    Grid& g = l[begin + k];
+                    const Grid& r = res[k];
+                    int out_loc = 0;
+                    while (out_loc == g.loc || out_loc == r.loc) ++out_loc;
+                    SqzArgs a;
+                    a.avg = ptr(g, g.loc, &a.avg_stride);
+                    a.res = ptr(r, r.loc, &a.res_stride);
+                    if (st.horizontal) g.w += r.w; else g.h += r.h;
+                    a.out = ptr(g, out_loc, &a.out_stride);
+                    a.width = g.w; a.height = g.h;
+                    g.loc = out_loc;
+                    if (i16) launch_squeeze<int16_t>(s, st.horizontal, a);
+                    else launch_squeeze<int32_t>(s, st.horizontal, a);
+                }
+            }
+        } else if (tr.kind == JXLGPU_TR_RCT) {
+            RctArgs a;
+            for (int k = 0; k < 3; ++k) a.p[k] = ptr(l[tr.begin_c + k], l[tr.begin_c + k].loc, &a.stride[k]);
+            a.width = l[tr.begin_c].w; a.height = l[tr.begin_c].h; a.rct_type = tr.rct_type;
+            dim3 grid(ceil_div(a.width, 256), a.height);
+            if (i16) rct_kernel<int16_t><<<grid, 256, 0, s>>>(a);
+            else rct_kernel<int32_t><<<grid, 256, 0, s>>>(a);
+        } else {
+            Grid pal = l.front();
+            l.erase(l.begin());
+            Grid& leader = l[tr.begin_c];
+            PalArgs a;
+            memset(&a, 0, sizeof(a));
+            a.palette = ptr(pal, 0, &a.pal_stride);
+            a.idx = ptr(leader, leader.loc, &a.idx_stride);
+            a.dst[0] = a.idx; a.dst_stride[0] = a.idx_stride;
+            for (size_t k = 0; k < leader.members.size(); ++k) {
+                Grid mg{leader.members[k], leader.x0, leader.y0, leader.w, leader.h, 0, {}};
+                a.dst[k + 1] = ptr(mg, 0, &a.dst_stride[k + 1]);
+            }
+            a.width = leader.w; a.height = leader.h; a.num_c = tr.num_c; a.nb_colours = tr.nb_colours;
+            a.not_simple = m->d_flag;
+            HIP_TRY(ctx, hipMemsetAsync(m->d_flag, 0, sizeof(int), s));
+            dim3 grid(ceil_div(a.width, 256), a.height);
+            if (i16) palette_kernel<int16_t><<<grid, 256, 0, s>>>(a);
+            else palette_kernel<int32_t><<<grid, 256, 0, s>>>(a);
+            int flag = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&flag, m->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            if (flag) return fail(ctx, JXLGPU_ERR_UNSUPPORTED,
+                                  "palette with implicit / delta entries (serial predictor pass) stays on the CPU path");
+            std::vector<int> members = leader.members;
+            leader.members.clear();
+            const Grid lead_copy = leader;
+            for (size_t k = 0; k < members.size(); ++k) {
+                Grid mg{members[k], lead_copy.x0, lead_copy.y0, lead_copy.w, lead_copy.h, 0, {}};
+                l.insert(l.begin() + tr.begin_c + 1 + k, mg);
+            }
+        }
+    }
+    m->final_loc.assign(nch, 0);
+    for (const Grid& g : l)
+        if (g.buf >= 0 && g.x0 == 0 && g.y0 == 0 && g.w == m->cw[g.buf] && g.h == m->ch[g.buf]) m->final_loc[g.buf] = g.loc;
+    HIP_TRY(ctx, hipGetLastError());
+    return JXLGPU_OK;
+}
+
+}  // namespace
+
 extern "C" {
-int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* desc, jxlgpu_frame** out_frame) {
-    if (ctx) ctx->last_error = "modular path not built yet";
-    return JXLGPU_ERR_UNSUPPORTED;
+
+int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_frame** out_frame) {
+    if (!ctx || !d || !out_frame) return JXLGPU_ERR_INVALID_ARG;
+    *out_frame = nullptr;
+    if (d->abi != JXLGPU_ABI_VERSION) return fail(ctx, JXLGPU_ERR_ABI, "descriptor ABI version mismatch");
+    if (d->num_channels == 0 || !d->channels) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "no channels");
+    if (d->residual_predictor != 0xFFFFFFFFu && d->residual_predictor != 5)
+        return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "only Gradient (5) residuals are separable on the device; others stay with the entropy decoder");
+    if (d->residual_predictor == 5 && d->group_dim > 256) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "gradient tiles larger than 256");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    jxlgpu_frame* f = new (std::nothrow) jxlgpu_frame();
+    ModularState* m = new (std::nothrow) ModularState();
+    if (!f || !m) { delete f; delete m; return JXLGPU_ERR_OOM; }
+    f->kind_of_frame = 1;
+    f->modular = m;
+    f->modular_free = [](void* p) { delete static_cast<ModularState*>(p); };
+    struct Guard {
+        jxlgpu_ctx* c; jxlgpu_frame* f; bool armed = true;
+        ~Guard() { if (armed) jxlgpu_frame_free(c, f); }
+    } guard{ctx, f};
+    m->desc = *d;
+    m->esz = d->sample_type == JXLGPU_SAMPLE_I16 ? 2 : 4;
+    for (uint32_t c = 0; c < d->num_channels; ++c) {
+        const JxlGpuModularChannel& ch = d->channels[c];
+        if (!ch.data || ch.width == 0 || ch.height == 0) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "empty channel");
+        size_t bytes = (size_t)ch.width * ch.height * m->esz;
+        void* p = nullptr;
+        int rc;
+        if ((rc = malloc_dev(ctx, f, &p, bytes))) return rc;
+        HIP_TRY(ctx, hipMemcpy(p, ch.data, bytes, hipMemcpyHostToDevice));
+        m->orig.push_back(p);
+        m->cw.push_back(ch.width);
+        m->ch.push_back(ch.height);
+        for (int k = 0; k < 3; ++k) {
+            if ((rc = malloc_dev(ctx, f, &p, bytes))) return rc;
+            m->work[k].push_back(p);
+        }
+    }
+    for (uint32_t c = 0; c < d->num_meta_channels; ++c) {
+        const JxlGpuModularChannel& ch = d->meta_channels[c];
+        size_t bytes = (size_t)ch.width * ch.height * m->esz;
+        void* p = nullptr;
+        int rc;
+        if ((rc = malloc_dev(ctx, f, &p, bytes))) return rc;
+        HIP_TRY(ctx, hipMemcpy(p, ch.data, bytes, hipMemcpyHostToDevice));
+        m->meta.push_back(p);
+        m->mw.push_back(ch.width);
+        m->mh.push_back(ch.height);
+    }
+    for (uint32_t t = 0; t < d->num_transforms; ++t) {
+        m->transforms.push_back(d->transforms[t]);
+        const JxlGpuTransform& tr = d->transforms[t];
+        // explicit squeeze parameters are copied now (the descriptor may be released after the call)
+        if (tr.kind == JXLGPU_TR_SQUEEZE && tr.num_sq && tr.sq) m->explicit_steps.emplace_back(tr.sq, tr.sq + tr.num_sq);
+        else m->explicit_steps.emplace_back();
+        m->transforms.back().sq = nullptr;
+    }
+    int rc;
+    if ((rc = malloc_dev(ctx, f, &m->d_flag, sizeof(int)))) return rc;
+
+    // geometry of the colour image for the float tail
+    f->width = d->channels[0].width;
+    f->height = d->channels[0].height;
+    f->w8 = ceil_div(f->width, 8); f->h8 = ceil_div(f->height, 8);
+    f->wr = f->w8 * 8; f->hr = f->h8 * 8;
+    f->desc.filter = d->filter;
+    f->desc.upsampling = d->upsampling;
+    f->desc.color = d->color;
+    if (!d->xyb_encoded) f->desc.color.enabled = 0;
+    fill_color_args_public(f->desc.color, &f->color);
+    if (d->num_channels >= 3) {
+        const size_t npix = (size_t)f->wr * f->hr;
+        for (int c = 0; c < 3; ++c) {
+            if ((rc = malloc_dev(ctx, f, &m->fpix[c], npix * 4))) return rc;
+            if ((rc = malloc_dev(ctx, f, &f->buf_a[c], npix * 4))) return rc;
+            if ((rc = malloc_dev(ctx, f, &f->buf_b[c], npix * 4))) return rc;
+        }
+        std::vector<float> sigma((size_t)f->w8 * f->h8, d->filter.epf_sigma_for_modular);
+        if ((rc = malloc_dev(ctx, f, &f->sigma, sigma.size() * 4))) return rc;
+        HIP_TRY(ctx, hipMemcpy(f->sigma, sigma.data(), sigma.size() * 4, hipMemcpyHostToDevice));
+        const uint32_t upf = d->upsampling.factor ? d->upsampling.factor : 1;
+        if (upf > 1) {
+            for (int c = 0; c < 3; ++c)
+                if ((rc = malloc_dev(ctx, f, &f->up[c], (size_t)f->width * upf * f->height * upf * 4))) return rc;
+            if ((rc = upload_post_params(ctx, f, d->upsampling))) return rc;
+        }
+    }
+    guard.armed = false;
+    *out_frame = f;
+    return JXLGPU_OK;
 }
-int jxlgpu_modular_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* frame, void* const* planes_or_null) {
-    return JXLGPU_ERR_UNSUPPORTED;
+
+int jxlgpu_modular_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f, void* const* planes) {
+    if (!ctx || !f || f->kind_of_frame != 1) return JXLGPU_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ModularState* m = static_cast<ModularState*>(f->modular);
+    ctx->prof_begin(PROF_MODULAR);
+    int rc = run_inverse(ctx, f);
+    ctx->prof_end(PROF_MODULAR);
+    if (rc) return rc;
+    if (planes) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t c = 0; c < m->orig.size(); ++c)
+            if (planes[c])
+                HIP_TRY(ctx, hipMemcpy(planes[c], m->work[m->final_loc[c]][c], (size_t)m->cw[c] * m->ch[c] * m->esz,
+                                       hipMemcpyDeviceToHost));
+    }
+    return JXLGPU_OK;
 }
-int jxlgpu_modular_render(jxlgpu_ctx* ctx, jxlgpu_frame* frame, uint32_t stages, const JxlGpuOut* out) {
-    return JXLGPU_ERR_UNSUPPORTED;
+
+int jxlgpu_modular_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuOut* out) {
+    if (!ctx || !f || f->kind_of_frame != 1) return JXLGPU_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ModularState* m = static_cast<ModularState*>(f->modular);
+    if (m->orig.size() < 3) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "grayscale Modular frames are not rendered on the device yet");
+    for (int c = 1; c < 3; ++c)
+        if (m->cw[c] != m->cw[0] || m->ch[c] != m->ch[0]) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "subsampled colour channels");
+    if (!(stages & JXLGPU_STAGE_MODULAR_TO_FLOAT)) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "render needs JXLGPU_STAGE_MODULAR_TO_FLOAT");
+    ctx->prof_begin(PROF_MODULAR);
+    int rc = run_inverse(ctx, f);
+    ctx->prof_end(PROF_MODULAR);
+    if (rc) return rc;
+    ToFloatArgs a;
+    for (int c = 0; c < 3; ++c) {
+        a.in[c] = m->work[m->final_loc[c]][c];
+        a.in_stride[c] = m->cw[c];
+        a.out[c] = m->fpix[c];
+        a.m[c] = m->desc.m_lf_unscaled[c];
+    }
+    a.out_stride = f->wr; a.width = f->width; a.height = f->height;
+    a.xyb = m->desc.xyb_encoded; a.is_i16 = m->desc.sample_type == JXLGPU_SAMPLE_I16;
+    a.bit_depth = m->desc.bit_depth; a.float_sample = m->desc.float_sample; a.exp_bits = m->desc.exp_bits;
+    to_float_kernel<<<dim3(ceil_div(f->width, 256), f->height), 256, 0, ctx->stream>>>(a);
+    float* cur[3] = {m->fpix[0], m->fpix[1], m->fpix[2]};
+    uint32_t stride = f->wr, ow = f->width, oh = f->height;
+    ctx->prof_begin(PROF_POST);
+    rc = run_post_stages(ctx, f, stages, f->desc.filter, f->desc.upsampling.factor ? f->desc.upsampling.factor : 1,
+                         cur, &stride, &ow, &oh);
+    ctx->prof_end(PROF_POST);
+    if (rc) return rc;
+    return finish_render(ctx, f, cur, stride, ow, oh, out);
 }
-}
+
+}  // extern "C"

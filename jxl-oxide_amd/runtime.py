@@ -104,3 +104,33 @@ class Context:
         arr = (abi.f32p * 3)(*[lf[c].ctypes.data_as(abi.f32p) for c in range(3)])
         self._check(self.lib.jxlgpu_frame_download_lf(self.handle, frame.handle, arr))
         return lf
+
+    # ---- Modular
+    def modular_upload(self, desc):
+        fh = C.c_void_p()
+        self._check(self.lib.jxlgpu_modular_upload(self.handle, C.byref(desc), C.byref(fh)))
+        return Frame(self, fh)
+
+    def modular_inverse(self, frame, shapes, dtype, to_host=True):
+        """Inverse transforms only; returns the reconstructed integer planes (bit-exact contract)."""
+        if not to_host:
+            self._check(self.lib.jxlgpu_modular_inverse(self.handle, frame.handle, None))
+            return None
+        outs = [np.zeros(s, dtype=dtype) for s in shapes]
+        arr = (C.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+        self._check(self.lib.jxlgpu_modular_inverse(self.handle, frame.handle, arr))
+        return outs
+
+    def modular_render(self, frame, stages, to_host=True):
+        if not to_host:
+            self._check(self.lib.jxlgpu_modular_render(self.handle, frame.handle, stages, None))
+            return None
+        w, h = frame.out_size(stages)
+        out = np.zeros((3, h, w), dtype=np.float32)
+        o = abi.Out()
+        for c in range(3):
+            o.planes[c] = out[c].ctypes.data_as(abi.f32p)
+        o.stride = w
+        o.mem = abi.MEM_HOST
+        self._check(self.lib.jxlgpu_modular_render(self.handle, frame.handle, stages, C.byref(o)))
+        return out

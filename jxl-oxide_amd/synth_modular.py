@@ -1,0 +1,302 @@
+"""Synthetic Modular boundary state: channel buffers as they look *after* the per-group entropy
+decode and *before* `modular_image.prepare_subimage().finish(pool)` (jxl-render/src/modular.rs:134),
+i.e. full-resolution buffers holding the squeezed pyramid as nested sub-rectangles
+(jxl-modular/src/transform.rs:343-437).
+
+The forward transforms here (forward Squeeze / RCT / Gradient residuals / palette indexing) are
+written independently of oracle/modular.c, in numpy, from the definitions of the inverse — so
+`inverse(forward(x)) == x` pins both the oracle and the HIP kernels bit-exactly.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .synth import OPSIN_BIAS, OPSIN_INV, SEED_BASE
+
+
+def _trunc_div(x, d):
+    return np.sign(x) * (np.abs(x) // d)
+
+
+def tendency(a, b, c):
+    """jxl-modular/src/transform/squeeze.rs:1104-1137, int64 (no wrapping at test magnitudes)."""
+    a = a.astype(np.int64); b = b.astype(np.int64); c = c.astype(np.int64)
+    out = np.zeros_like(a)
+    m1 = (a >= b) & (b >= c)
+    x = _trunc_div(4 * a - 3 * c - b + 6, 12)
+    x = np.where(x - (x & 1) > 2 * (a - b), 2 * (a - b) + 1, x)
+    x = np.where(x + (x & 1) > 2 * (b - c), 2 * (b - c), x)
+    out = np.where(m1, x, out)
+    m2 = (a <= b) & (b <= c) & ~m1
+    x = _trunc_div(4 * a - 3 * c - b - 6, 12)
+    x = np.where(x + (x & 1) < 2 * (a - b), 2 * (a - b) - 1, x)
+    x = np.where(x - (x & 1) < 2 * (b - c), 2 * (b - c), x)
+    out = np.where(m2, x, out)
+    return out
+
+
+def forward_squeeze_rows(v):
+    """v: (..., n) int64 along the last axis -> (avg (..., ceil(n/2)), residual (..., n//2)).
+    Derived from the inverse (squeeze.rs:59-88): first = avg + trunc(diff/2), second = first - diff,
+    diff = residual + tendency(left, avg, next_avg), left = previous `second`."""
+    n = v.shape[-1]
+    pairs = n // 2
+    A = v[..., 0:2 * pairs:2]
+    B = v[..., 1:2 * pairs:2]
+    avg = (A + B + (A > B)) >> 1
+    if n & 1:
+        avg = np.concatenate([avg, v[..., -1:]], axis=-1)
+    if pairs == 0:
+        return avg, np.zeros(v.shape[:-1] + (0,), dtype=np.int64)
+    next_avg = np.concatenate([avg[..., 1:], avg[..., -1:]], axis=-1)[..., :pairs]
+    if avg.shape[-1] == pairs:  # even n: the last pair has no next avg -> itself
+        next_avg[..., -1] = avg[..., pairs - 1]
+    left = np.concatenate([avg[..., :1], B[..., :-1]], axis=-1)
+    res = (A - B) - tendency(left, avg[..., :pairs], next_avg)
+    return avg, res
+
+
+class _Grid:
+    def __init__(self, buf, x0, y0, w, h):
+        self.buf, self.x0, self.y0, self.w, self.h = buf, x0, y0, w, h
+
+
+def default_squeeze_params(grids):
+    """Squeeze::set_default_params (jxl-modular/src/transform.rs:285-341), no meta channels."""
+    sp = []
+    w, h = grids[0].w, grids[0].h
+    if len(grids) >= 3 and grids[1].w == w and grids[1].h == h:
+        sp.append((1, 0, 1, 2))
+        sp.append((0, 0, 1, 2))
+    num_c = len(grids)
+    if h >= w and h > 8:
+        sp.append((0, 1, 0, num_c)); h = (h + 1) // 2
+    while w > 8 or h > 8:
+        if w > 8:
+            sp.append((1, 1, 0, num_c)); w = (w + 1) // 2
+        if h > 8:
+            sp.append((0, 1, 0, num_c)); h = (h + 1) // 2
+    return sp  # (horizontal, in_place, begin_c, num_c)
+
+
+def forward_squeeze(bufs, grids, steps, quant=None):
+    """Applies the steps in order on the int64 working buffers, carving sub-rectangles exactly as
+    transform_channel_info does; `quant(level, residual)` optionally quantises residuals (lossy)."""
+    for level, (horizontal, in_place, begin, num_c) in enumerate(steps):
+        end = begin + num_c
+        residuals = []
+        for g in grids[begin:end]:
+            view = bufs[g.buf][g.y0:g.y0 + g.h, g.x0:g.x0 + g.w]
+            if horizontal:
+                avg, res = forward_squeeze_rows(view.copy())
+                aw = avg.shape[1]
+                if quant is not None:
+                    res = quant(level, res)
+                view[:, :aw] = avg
+                view[:, aw:] = res
+                r = _Grid(g.buf, g.x0 + aw, g.y0, g.w - aw, g.h)
+                g.w = aw
+            else:
+                avg, res = forward_squeeze_rows(view.T.copy())
+                ah = avg.shape[1]
+                if quant is not None:
+                    res = quant(level, res)
+                view[:ah, :] = avg.T
+                view[ah:, :] = res.T
+                r = _Grid(g.buf, g.x0, g.y0 + ah, g.w, g.h - ah)
+                g.h = ah
+            residuals.append(r)
+        at = end if in_place else len(grids)
+        grids[at:at] = residuals
+    return grids
+
+
+def forward_rct(a, b, c, rct_type):
+    """Inverse of inverse_row_*_base + inverse_permute (jxl-modular/src/transform/rct.rs:154-256):
+    given output planes (d, e, f) after un-permutation, produce the coded (a, b, c)."""
+    permutation, ty = rct_type // 7, rct_type % 7
+    planes = [a, b, c]
+    # inverse_permute maps coded rows (d,e,f) -> output; undo it first
+    inv = {0: (0, 1, 2), 1: (1, 2, 0), 2: (2, 0, 1), 3: (0, 2, 1), 4: (1, 0, 2), 5: (2, 1, 0)}
+    # output[k] = coded[src[k]]: derive from the swap sequences in inverse_permute
+    src = {0: [0, 1, 2], 1: [2, 0, 1], 2: [1, 2, 0], 3: [0, 2, 1], 4: [1, 0, 2], 5: [2, 1, 0]}[permutation]
+    coded = [None, None, None]
+    for k in range(3):
+        coded[src[k]] = planes[k]
+    d, e, f = coded
+    if ty == 6:
+        # d = f + b ; f = tmp - (b>>1) ; e = c + tmp ; tmp = a - (c>>1)
+        bb = d - f
+        tmp = f + (bb >> 1)
+        cc = e - tmp
+        aa = tmp + (cc >> 1)
+        return aa, bb, cc
+    aa = d
+    cc = f - aa if (ty & 1) else f
+    if (ty >> 1) == 1:
+        bb = e - aa
+    elif (ty >> 1) == 2:
+        bb = e - ((aa + f) >> 1)
+    else:
+        bb = e
+    return aa, bb, cc
+
+
+def gradient_residuals(img, group_dim):
+    """Residuals such that decode_simple_grad's arithmetic (image.rs:821-872) rebuilds `img`,
+    independently per group_dim x group_dim tile."""
+    H, W = img.shape
+    out = np.zeros_like(img)
+    for y0 in range(0, H, group_dim):
+        for x0 in range(0, W, group_dim):
+            t = img[y0:y0 + group_dim, x0:x0 + group_dim].astype(np.int64)
+            h, w = t.shape
+            pred = np.zeros_like(t)
+            pred[0, 1:] = t[0, :-1]
+            pred[1:, 0] = t[:-1, 0]
+            n = t[:-1, 1:]; wv = t[1:, :-1]; nw = t[:-1, :-1]
+            pred[1:, 1:] = np.clip(n + wv - nw, np.minimum(n, wv), np.maximum(n, wv))
+            out[y0:y0 + h, x0:x0 + w] = t - pred
+    return out
+
+
+class ModularWorkload:
+    """kind: 'lossless_rgb8' (cfg 1: Gradient residuals + RCT), 'squeeze' (cfg 3: RCT/XYB ints +
+    default Squeeze, optional lossy quantisation), 'palette', 'raw' (random data through explicit
+    transforms, exercises wrapping)."""
+
+    def __init__(self, width, height, kind="squeeze", seed=0, i16=True, lossy=True, rct_type=None,
+                 xyb=True, epf_iters=0, gabor=False, bit_depth=8):
+        rng = np.random.default_rng(SEED_BASE + 0x100 + seed)
+        self.width, self.height, self.kind = width, height, kind
+        self.dtype = np.int16 if i16 else np.int32
+        self.sample_type = abi.SAMPLE_I16 if i16 else abi.SAMPLE_I32
+        self.bit_depth = bit_depth
+        self.xyb = xyb and kind == "squeeze"
+        H, W = height, width
+        yy, xx = np.mgrid[0:H, 0:W]
+        base = [np.rint(110 + 90 * np.sin(xx / (17.0 + 5 * c)) * np.cos(yy / (23.0 - 3 * c)) +
+                        6 * rng.normal(size=(H, W))).astype(np.int64) for c in range(3)]
+        self.transforms = []
+        self.meta = []
+        self.residual_predictor = 0xFFFFFFFF
+        self.expected = None  # exact integer result when the chain is lossless
+
+        if kind == "lossless_rgb8":
+            rgb = [np.clip(p, 0, 255) for p in base]
+            self.expected = [p.astype(self.dtype) for p in rgb]
+            t = 6 if rct_type is None else rct_type
+            a, b, c = forward_rct(rgb[0], rgb[1], rgb[2], t)
+            self.transforms.append(("rct", 0, t))
+            chans = [gradient_residuals(p, 256) for p in (a, b, c)]
+            self.residual_predictor = 5
+            self.buffers = [p.astype(self.dtype) for p in chans]
+        elif kind == "squeeze":
+            planes = base
+            if self.xyb:
+                # XYB-ish integers in Modular channel order Y, X, B (B stored as B - Y)
+                yv = np.clip(base[0], 0, 255) * 4
+                xv = np.rint((base[1] - 110) / 6.0).astype(np.int64)
+                bv = np.clip(base[2], 0, 255) * 2 - yv
+                planes = [yv, xv, bv]
+            if rct_type is not None:
+                planes = list(forward_rct(planes[0], planes[1], planes[2], rct_type))
+                self.transforms.append(("rct", 0, rct_type))
+            if not lossy:
+                # expected = what the inverse chain must reproduce (before the RCT is undone the
+                # planes are `planes`; after, the originals)
+                orig = base if not self.xyb else [yv, xv, bv]
+                self.expected = [p.astype(self.dtype) for p in orig]
+            bufs = [p.copy() for p in planes]
+            grids = [_Grid(i, 0, 0, W, H) for i in range(3)]
+            steps = default_squeeze_params(grids)
+            nsteps = len(steps)
+
+            def quant(level, res):
+                if not lossy:
+                    return res
+                q = 1 << max(0, (nsteps - level) // 5)  # coarser for the finest levels
+                return _trunc_div(res, q) * 1  # quantised residuals (dequantised form is what is coded)
+            forward_squeeze(bufs, grids, steps, quant)
+            self.transforms.append(("squeeze", None))
+            self.buffers = [b.astype(self.dtype) for b in bufs]
+        elif kind == "palette":
+            ncol = 37
+            pal = rng.integers(0, 256, size=(3, ncol)).astype(np.int64)
+            idx = rng.integers(0, ncol, size=(H, W)).astype(np.int64)
+            self.expected = [pal[c][idx].astype(self.dtype) for c in range(3)]
+            self.transforms.append(("palette", 0, 3, ncol))
+            self.meta.append(pal.astype(self.dtype))
+            self.buffers = [idx.astype(self.dtype), np.zeros((H, W), self.dtype), np.zeros((H, W), self.dtype)]
+        elif kind == "raw":
+            # arbitrary data straight into the inverse chain: wrapping arithmetic included
+            info = np.iinfo(self.dtype)
+            self.buffers = [rng.integers(info.min // 2, info.max // 2, size=(H, W)).astype(self.dtype) for _ in range(3)]
+            self.transforms.append(("rct", 0, 6 if rct_type is None else rct_type))
+            self.transforms.append(("squeeze", None))
+        else:
+            raise ValueError(kind)
+
+        self.filter = abi.FilterParams()
+        self.filter.gab_enabled = 1 if gabor else 0
+        for c in range(3):
+            self.filter.gab_weights[c][0] = 0.115169525
+            self.filter.gab_weights[c][1] = 0.061248592
+        self.filter.epf_iters = epf_iters
+        self.filter.epf_channel_scale[:] = [40.0, 5.0, 3.5]
+        self.filter.epf_pass0_sigma_scale = 0.9
+        self.filter.epf_pass2_sigma_scale = 6.5
+        self.filter.epf_border_sad_mul = 2.0 / 3.0
+        self.filter.epf_sigma_for_modular = 1.0
+        self.color = abi.ColorParams()
+        self.color.enabled = 1
+        self.color.opsin_bias[:] = [OPSIN_BIAS] * 3
+        self.color.intensity_target = 255.0
+        self.color.matrix[:] = list(OPSIN_INV)
+        self.color.transfer_function = abi.TF_SRGB
+        self._keep = None
+
+    def shapes(self):
+        return [b.shape for b in self.buffers]
+
+    def desc(self):
+        d = abi.ModularDesc()
+        d.abi = abi.ABI_VERSION
+        d.sample_type = self.sample_type
+        d.bit_depth = self.bit_depth
+        n = len(self.buffers)
+        chans = (abi.ModularChannel * n)()
+        for i, b in enumerate(self.buffers):
+            chans[i].data = b.ctypes.data
+            chans[i].width, chans[i].height = b.shape[1], b.shape[0]
+        d.num_channels = n
+        d.channels = C.cast(chans, C.POINTER(abi.ModularChannel))
+        metas = (abi.ModularChannel * max(1, len(self.meta)))()
+        for i, m in enumerate(self.meta):
+            metas[i].data = m.ctypes.data
+            metas[i].width, metas[i].height = m.shape[1], m.shape[0]
+        d.num_meta_channels = len(self.meta)
+        d.meta_channels = C.cast(metas, C.POINTER(abi.ModularChannel))
+        trs = (abi.Transform * len(self.transforms))()
+        for i, t in enumerate(self.transforms):
+            if t[0] == "rct":
+                trs[i].kind = abi.TR_RCT
+                trs[i].begin_c, trs[i].rct_type = t[1], t[2]
+            elif t[0] == "squeeze":
+                trs[i].kind = abi.TR_SQUEEZE
+                trs[i].num_sq = 0
+            else:
+                trs[i].kind = abi.TR_PALETTE
+                trs[i].begin_c, trs[i].num_c, trs[i].nb_colours = t[1], t[2], t[3]
+        d.num_transforms = len(self.transforms)
+        d.transforms = C.cast(trs, C.POINTER(abi.Transform))
+        d.residual_predictor = self.residual_predictor
+        d.group_dim = 256
+        d.xyb_encoded = 1 if self.xyb else 0
+        d.m_lf_unscaled[:] = [(1.0 / 32.0) / 128.0, (1.0 / 4.0) / 128.0, (1.0 / 2.0) / 128.0]
+        d.filter = self.filter
+        d.upsampling.factor = 1
+        d.color = self.color
+        self._keep = [chans, metas, trs]
+        return d

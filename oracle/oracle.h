@@ -34,6 +34,11 @@ void orc_vardct_lf(const JxlGpuVardctDesc* d, float* const lf[3]);
 int jxl_oracle_vardct_render(const JxlGpuVardctDesc* d, uint32_t stages, float* const out[3],
                              uint32_t out_stride, float* const lf_out[3]);
 
+/* ---- modular.c ---- */
+int jxl_oracle_modular_inverse(const JxlGpuModularDesc* d, void* const* out);
+int jxl_oracle_modular_render(const JxlGpuModularDesc* d, uint32_t stages, float* const out[3],
+                              uint32_t out_stride);
+
 /* ---- filters.c ---- */
 /* apply_gabor_like on one width x height plane (in -> out, both tight stride `stride_*`). */
 void orc_gabor_plane(const float* in, size_t in_stride, float* out, size_t out_stride, size_t width,

@@ -39,6 +39,10 @@ def lib():
         _lib.orc_gabor_plane.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
         _lib.orc_upsample_inner.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_int, f32p]
         _lib.orc_color_transform.argtypes = [f32p * 3, C.c_size_t, C.c_void_p]
+        _lib.jxl_oracle_modular_inverse.restype = C.c_int
+        _lib.jxl_oracle_modular_inverse.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        _lib.jxl_oracle_modular_render.restype = C.c_int
+        _lib.jxl_oracle_modular_render.argtypes = [C.c_void_p, C.c_uint32, f32p * 3, C.c_uint32]
     return _lib
 
 
@@ -79,3 +83,22 @@ def vardct_render(desc, stages, out_w, out_h, want_lf=False, w8=0, h8=0):
     if rc != 0:
         raise RuntimeError(f"oracle vardct_render failed: {rc}")
     return out, lf
+
+
+def modular_inverse(desc, shapes, dtype):
+    """shapes: [(h, w)] per channel.  Returns the list of reconstructed integer planes."""
+    outs = [np.zeros(s, dtype=dtype) for s in shapes]
+    arr = (C.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+    rc = lib().jxl_oracle_modular_inverse(C.byref(desc), arr)
+    if rc != 0:
+        raise RuntimeError(f"oracle modular_inverse failed: {rc}")
+    return outs
+
+
+def modular_render(desc, stages, out_w, out_h):
+    out = np.zeros((3, out_h, out_w), dtype=np.float32)
+    outp = (f32p * 3)(*[_p(out[c]) for c in range(3)])
+    rc = lib().jxl_oracle_modular_render(C.byref(desc), stages, outp, out_w)
+    if rc != 0:
+        raise RuntimeError(f"oracle modular_render failed: {rc}")
+    return out

@@ -1,0 +1,94 @@
+"""GPU parity for the Modular stage: integer results must be bit-exact against the oracle (and,
+for lossless chains, against the original integers); the float tail within 1 ULP."""
+import numpy as np
+import pytest
+
+from jxl_oxide_amd import abi
+from jxl_oxide_amd.synth_modular import ModularWorkload
+from util import assert_ulp
+
+pytestmark = pytest.mark.gpu
+
+
+def _inverse_both(gpu_ctx, oracle, wl):
+    d = wl.desc()
+    exp = oracle.modular_inverse(d, wl.shapes(), wl.dtype)
+    f = gpu_ctx.modular_upload(d)
+    try:
+        got = gpu_ctx.modular_inverse(f, wl.shapes(), wl.dtype)
+        again = gpu_ctx.modular_inverse(f, wl.shapes(), wl.dtype)  # re-runnable from the uploaded state
+    finally:
+        f.free()
+    for c in range(len(exp)):
+        assert np.array_equal(got[c], exp[c]), f"channel {c} differs from the oracle"
+        assert np.array_equal(again[c], exp[c]), f"channel {c} differs on the second run"
+    return got
+
+
+@pytest.mark.parametrize("i16", [True, False])
+@pytest.mark.parametrize("size", [(256, 256), (70, 45), (9, 200), (1, 17), (33, 1), (600, 333)])
+def test_squeeze_lossless(gpu_ctx, oracle, size, i16):
+    w, h = size
+    wl = ModularWorkload(w, h, kind="squeeze", lossy=False, xyb=False, i16=i16, seed=w + h)
+    got = _inverse_both(gpu_ctx, oracle, wl)
+    for c in range(3):
+        assert np.array_equal(got[c], wl.expected[c])
+
+
+@pytest.mark.parametrize("i16", [True, False])
+def test_squeeze_lossy_and_wrapping(gpu_ctx, oracle, i16):
+    _inverse_both(gpu_ctx, oracle, ModularWorkload(333, 200, kind="squeeze", lossy=True, i16=i16))
+    _inverse_both(gpu_ctx, oracle, ModularWorkload(130, 97, kind="raw", i16=i16, seed=5))
+
+
+@pytest.mark.parametrize("rct_type", [0, 6, 10, 19, 23, 34, 36, 41])
+def test_rct_types(gpu_ctx, oracle, rct_type):
+    wl = ModularWorkload(120, 90, kind="squeeze", lossy=False, xyb=False, rct_type=rct_type, seed=rct_type)
+    got = _inverse_both(gpu_ctx, oracle, wl)
+    for c in range(3):
+        assert np.array_equal(got[c], wl.expected[c])
+
+
+@pytest.mark.parametrize("i16", [True, False])
+def test_config1_lossless_rgb8(gpu_ctx, oracle, i16):
+    wl = ModularWorkload(256, 256, kind="lossless_rgb8", i16=i16)
+    got = _inverse_both(gpu_ctx, oracle, wl)
+    for c in range(3):
+        assert np.array_equal(got[c], wl.expected[c])
+    wl = ModularWorkload(300, 270, kind="lossless_rgb8", seed=3, i16=i16)
+    _inverse_both(gpu_ctx, oracle, wl)
+
+
+def test_palette(gpu_ctx, oracle):
+    wl = ModularWorkload(64, 48, kind="palette")
+    got = _inverse_both(gpu_ctx, oracle, wl)
+    for c in range(3):
+        assert np.array_equal(got[c], wl.expected[c])
+
+
+@pytest.mark.parametrize("cfg", [dict(epf_iters=0), dict(epf_iters=1), dict(epf_iters=2, gabor=True)])
+def test_render_xyb_tail(gpu_ctx, oracle, cfg):
+    wl = ModularWorkload(200, 136, kind="squeeze", lossy=True, **cfg)
+    d = wl.desc()
+    stages = abi.STAGE_ALL | abi.STAGE_MODULAR_TO_FLOAT
+    exp = oracle.modular_render(d, stages, 200, 136)
+    f = gpu_ctx.modular_upload(d)
+    try:
+        got = gpu_ctx.modular_render(f, stages)
+    finally:
+        f.free()
+    assert_ulp(got, exp, 1, f"modular render {cfg}")
+
+
+def test_render_rgb8_no_colour_transform(gpu_ctx, oracle):
+    wl = ModularWorkload(256, 256, kind="lossless_rgb8")
+    d = wl.desc()
+    stages = abi.STAGE_ALL | abi.STAGE_MODULAR_TO_FLOAT
+    exp = oracle.modular_render(d, stages, 256, 256)
+    f = gpu_ctx.modular_upload(d)
+    try:
+        got = gpu_ctx.modular_render(f, stages)
+    finally:
+        f.free()
+    assert_ulp(got, exp, 0, "rgb8 -> float")
+    assert np.array_equal(got[0], wl.expected[0].astype(np.float32) / np.float32(255))
