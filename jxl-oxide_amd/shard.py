@@ -1,0 +1,84 @@
+"""Multi-GPU sharding of the render path (one process per GPU, torch.distributed; backend "nccl"
+is RCCL over xGMI on MI355X, "gloo" in the CPU tests).
+
+The reference has no distributed code at all; what shards is the work unit it hands to rayon:
+  * frames are independent (BASELINE config 4): contiguous blocks of frames per rank, no
+    communication on the data path;
+  * inside one VarDCT frame, groups are independent through the inverse DCT
+    (jxl-render/src/vardct/mod.rs:319; varblocks never cross a 256-px group,
+    jxl-vardct/src/hf_metadata.rs:144-158) and the filters reach <= 7 px (+2 coded px for
+    upsampling) across a boundary (jxl-render/src/util.rs:60-110).  A rank therefore renders a band
+    of whole group rows extended by ONE halo group row on each side (recomputed, not exchanged:
+    cheaper than a halo exchange) and keeps only its own rows — bit-identical to the
+    unsharded render.
+The only collective is the final gather of finished planes to the root (`gather_planes`).
+"""
+import numpy as np
+
+
+def frame_shard(n_frames, rank, world):
+    """Contiguous block of frame indices owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n_frames, world)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+def band_plan(height, world, group_dim=256):
+    """[(y0, y1, ext_y0, ext_y1)] per rank: rows [y0, y1) owned, [ext_y0, ext_y1) rendered.
+    Bands are whole group rows; ranks beyond the number of group rows get empty bands."""
+    n_rows = -(-height // group_dim)
+    plan = []
+    for r in range(world):
+        rows = frame_shard(n_rows, r, world)
+        if len(rows) == 0:
+            plan.append((0, 0, 0, 0))
+            continue
+        y0, y1 = rows.start * group_dim, min(rows.stop * group_dim, height)
+        ext0 = max(0, y0 - group_dim)
+        ext1 = min(height, y1 + group_dim)
+        plan.append((y0, y1, ext0, ext1))
+    return plan
+
+
+def slice_vardct_band(wl, ext_y0, ext_y1):
+    """A shallow copy of a synth.VardctWorkload restricted to coded rows [ext_y0, ext_y1)
+    (multiples of the group size, except the frame's last row): every per-frame array is cut along
+    y; geometry-free parameters are shared."""
+    import copy
+    assert ext_y0 % 256 == 0
+    b = copy.copy(wl)
+    b.height = ext_y1 - ext_y0
+    c0, c1 = ext_y0 // 8, -(-ext_y1 // 8)
+    b.h8 = c1 - c0
+    b.hr = b.h8 * 8
+    b.coeff = np.ascontiguousarray(wl.coeff[:, c0 * 8:c1 * 8, :])
+    b.kind = np.ascontiguousarray(wl.kind[c0:c1])
+    b.hf_mul = np.ascontiguousarray(wl.hf_mul[c0:c1])
+    b.sigma = np.ascontiguousarray(wl.sigma[c0:c1])
+    b.lfq = [np.ascontiguousarray(p[c0:c1]) for p in wl.lfq]
+    t0, t1 = ext_y0 // 64, -(-ext_y1 // 64)
+    b.xfy = np.ascontiguousarray(wl.xfy[t0:t1])
+    b.bfy = np.ascontiguousarray(wl.bfy[t0:t1])
+    b._keep = []
+    # LF groups are 2048 px: a band that starts inside one keeps the per-LF-group extra_precision
+    # of the rows it came from (desc() derives it from the LF group index)
+    b.lf_group_row0 = ext_y0 // (wl.group_dim * 8)
+    return b
+
+
+def gather_planes(local, dst=0, group=None):
+    """Gathers equally-shaped tensors (one per rank) to `dst`.  Returns the list on `dst`, None
+    elsewhere.  One collective; RCCL when the tensors live on GPUs."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return [local]
+    bufs = [local.new_empty(local.shape) for _ in range(world)] if rank == dst else None
+    dist.gather(local, bufs, dst=dst, group=group)
+    return bufs
+
+
+def render_frames_sharded(n_frames, render_fn, rank, world):
+    """Each rank renders its block of frames with `render_fn(frame_index) -> array/tensor`."""
+    return {i: render_fn(i) for i in frame_shard(n_frames, rank, world)}

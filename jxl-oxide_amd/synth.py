@@ -259,7 +259,7 @@ class VardctWorkload:
                 keep.append(arrs)
                 for c in range(3):
                     g.lf_quant[c] = arrs["lfq"][c].ctypes.data
-                g.extra_precision = (gx + gy) % 2  # exercise per-LF-group precision
+                g.extra_precision = (gx + gy + getattr(self, 'lf_group_row0', 0)) % 2  # exercise per-LF-group precision
                 g.has_hf_meta = 1
                 g.block_kind = arrs["kind"].ctypes.data_as(abi.u8p)
                 g.hf_mul = arrs["mul"].ctypes.data_as(abi.i32p)

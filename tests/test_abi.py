@@ -1,0 +1,63 @@
+"""The C-ABI library loads (no GPU needed) and exports every symbol include/jxlgpu.h declares;
+the ctypes mirror in abi.py stays in sync with the header."""
+import ctypes as C
+import os
+import re
+
+from jxl_oxide_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "jxlgpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(jxlgpu_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_ctypes_mirror_agree():
+    assert _declared_symbols() == sorted(abi.SYMBOL_NAMES)
+    src = open(os.path.join(ROOT, "include", "jxlgpu.h")).read()
+    assert int(re.search(r"#define JXLGPU_ABI_VERSION (\d+)u", src).group(1)) == abi.ABI_VERSION
+
+
+def test_library_loads_and_exports_everything():
+    lib = abi.load_library()  # raises if the .so or any declared export is missing
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.jxlgpu_abi_version() == abi.ABI_VERSION
+
+
+def test_struct_sizes_match_the_compiler():
+    """sizeof() of every POD struct as the C compiler sees it == the ctypes mirror."""
+    import subprocess
+    import tempfile
+    prog = r'''
+#include <stdio.h>
+#include "jxlgpu.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(JxlGpuFilterParams), sizeof(JxlGpuColorParams),
+           sizeof(JxlGpuUpsampling), sizeof(JxlGpuLfGroup), sizeof(JxlGpuVardctDesc), sizeof(JxlGpuOut),
+           sizeof(JxlGpuSqueezeStep), sizeof(JxlGpuTransform), sizeof(JxlGpuModularChannel), sizeof(JxlGpuModularDesc));
+    return 0;
+}'''
+    with tempfile.TemporaryDirectory() as td:
+        cfile = os.path.join(td, "s.c")
+        open(cfile, "w").write(prog)
+        exe = os.path.join(td, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), cfile, "-o", exe])
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    mirror = [abi.FilterParams, abi.ColorParams, abi.Upsampling, abi.LfGroup, abi.VardctDesc, abi.Out,
+              abi.SqueezeStep, abi.Transform, abi.ModularChannel, abi.ModularDesc]
+    assert sizes == [C.sizeof(m) for m in mirror]
+
+
+def test_no_gpu_means_a_loud_error():
+    """Without a visible GPU jxlgpu_create must fail with an error code (never fall back)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    lib = abi.load_library()
+    h = C.c_void_p()
+    assert lib.jxlgpu_create(0, C.byref(h)) != abi.OK
+    assert not h.value
