@@ -12,6 +12,8 @@
 // across lanes).  Parallelism is what the transform allows: one lane per row (horizontal step) or
 // per column (vertical step), each lane a serial chain because `tendency` needs the previous
 // output sample.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -89,9 +91,20 @@ struct SqzArgs {
     uint32_t width, height;                       // merged size
 };
 
-// inverse_v_*_base, squeeze.rs:803-862: one lane per column, coalesced row accesses
+template <typename S>
+__device__ __forceinline__ void squeeze_pair(S residu, S next_avg, S& avg, S& prev, S& first, S& second) {
+    S diff = Wrap<S>::add(residu, tendency<S>(prev, avg, next_avg));
+    first = Wrap<S>::add(avg, (S)(diff / 2));
+    second = Wrap<S>::sub(first, diff);
+    avg = next_avg;
+    prev = second;
+}
+
+// inverse_v_*_base, squeeze.rs:803-862: one lane per column, coalesced row accesses, PF rows of
+// residuals / averages in flight per lane (the chain itself is serial in y).
 template <typename S>
 __global__ __launch_bounds__(64) void squeeze_v_kernel(SqzArgs a) {
+    constexpr int PF = 16;
     uint32_t x = blockIdx.x * 64 + threadIdx.x;
     if (x >= a.width) return;
     const S* avgp = (const S*)a.avg + x;
@@ -100,95 +113,103 @@ __global__ __launch_bounds__(64) void squeeze_v_kernel(SqzArgs a) {
     const uint32_t avg_h = (a.height + 1) / 2, pairs = a.height / 2;
     S avg = avgp[0];
     S top = avg;
-    S nxt = avg_h > 1 ? avgp[a.avg_stride] : avg;
     uint32_t y = 0;
-    // software pipeline: 4 residuals / next-avgs in flight per lane
-    for (; y + 4 <= pairs; y += 4) {
-        S r[4], n[4];
+    for (; y + PF <= pairs; y += PF) {
+        S r[PF], n[PF];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PF; ++k) {
             r[k] = resp[(size_t)(y + k) * a.res_stride];
-            uint32_t ny = y + k + 2;
+            uint32_t ny = y + k + 1;
             n[k] = ny < avg_h ? avgp[(size_t)ny * a.avg_stride] : (S)0;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            S next_avg = (y + k + 1 < avg_h) ? nxt : avg;
-            S diff = Wrap<S>::add(r[k], tendency<S>(top, avg, next_avg));
-            S first = Wrap<S>::add(avg, (S)(diff / 2));
-            S second = Wrap<S>::sub(first, diff);
+        for (int k = 0; k < PF; ++k) {
+            S next_avg = (y + k + 1 < avg_h) ? n[k] : avg;
+            S first, second;
+            squeeze_pair<S>(r[k], next_avg, avg, top, first, second);
             out[(size_t)(2 * (y + k)) * a.out_stride] = first;
             out[(size_t)(2 * (y + k) + 1) * a.out_stride] = second;
-            avg = next_avg;
-            top = second;
-            nxt = n[k];
         }
     }
     for (; y < pairs; ++y) {
         S r = resp[(size_t)y * a.res_stride];
-        S next_avg = (y + 1 < avg_h) ? nxt : avg;
-        S n2 = (y + 2 < avg_h) ? avgp[(size_t)(y + 2) * a.avg_stride] : (S)0;
-        S diff = Wrap<S>::add(r, tendency<S>(top, avg, next_avg));
-        S first = Wrap<S>::add(avg, (S)(diff / 2));
-        S second = Wrap<S>::sub(first, diff);
+        S next_avg = (y + 1 < avg_h) ? avgp[(size_t)(y + 1) * a.avg_stride] : avg;
+        S first, second;
+        squeeze_pair<S>(r, next_avg, avg, top, first, second);
         out[(size_t)(2 * y) * a.out_stride] = first;
         out[(size_t)(2 * y + 1) * a.out_stride] = second;
-        avg = next_avg;
-        top = second;
-        nxt = n2;
     }
     if (a.height & 1) out[(size_t)(a.height - 1) * a.out_stride] = avgp[(size_t)(avg_h - 1) * a.avg_stride];
 }
 
-// inverse_h_*_base, squeeze.rs:59-120: 64 rows per wave.  Rows are staged through LDS in
-// 64 x CH tiles so global accesses stay coalesced along x while every lane walks its own row.
-template <typename S>
+// inverse_h_*_base, squeeze.rs:59-120: one lane per row.  Each lane streams its own row with
+// 16-byte vector loads / stores when the rectangles are 16-byte aligned (every 128-byte line a
+// lane touches is consumed over the next iterations out of L1/L2), scalar accesses otherwise.
+template <typename S, bool VEC>
 __global__ __launch_bounds__(64) void squeeze_h_kernel(SqzArgs a) {
-    constexpr int CH = 32;                       // pairs per chunk
-    __shared__ S s_avg[64][CH + 2];
-    __shared__ S s_res[64][CH + 1];
-    __shared__ S s_out[64][2 * CH + 1];
-    const int lane = threadIdx.x;
-    const uint32_t y0 = blockIdx.x * 64;
-    const uint32_t rows = min(64u, a.height - y0);
+    constexpr int N = 16 / sizeof(S);            // pairs per step on the vector path
+    using V = int4;
+    const uint32_t y = blockIdx.x * 64 + threadIdx.x;
+    if (y >= a.height) return;
     const uint32_t avg_w = (a.width + 1) / 2, pairs = a.width / 2;
-    const S* avgp = (const S*)a.avg + (size_t)y0 * a.avg_stride;
-    const S* resp = (const S*)a.res + (size_t)y0 * a.res_stride;
-    S* outp = (S*)a.out + (size_t)y0 * a.out_stride;
-
-    S avg = 0, left = 0;
-    for (uint32_t x0 = 0; x0 < pairs; x0 += CH) {
-        const uint32_t n = min((uint32_t)CH, pairs - x0);
-        // cooperative, row-major loads: lane = column within the chunk
-        for (uint32_t r = 0; r < rows; ++r) {
-            for (uint32_t c = lane; c < n + 1; c += 64) {
-                uint32_t ax = x0 + c;
-                s_avg[r][c] = ax < avg_w ? avgp[(size_t)r * a.avg_stride + ax] : (S)0;
+    const S* avgp = (const S*)a.avg + (size_t)y * a.avg_stride;
+    const S* resp = (const S*)a.res + (size_t)y * a.res_stride;
+    S* outp = (S*)a.out + (size_t)y * a.out_stride;
+    S avg = avgp[0];
+    S left = avg;
+    uint32_t x = 0;
+    if constexpr (VEC) {
+        union Pack { V v; S s[N]; };
+        // avg[x+1 .. x+N] is needed for the N pairs at x: keep the next vector of averages loaded
+        Pack cur_a;
+        if (avg_w >= (uint32_t)N) cur_a.v = *reinterpret_cast<const V*>(avgp);
+        // the loop needs the next vector of averages fully inside the avg rectangle; the last
+        // couple of vectors of a row fall through to the scalar loops below
+        if (avg_w < (uint32_t)N) cur_a.v = V{0, 0, 0, 0};
+        for (; x + N <= pairs && x + 2 * N <= avg_w; x += N) {
+            Pack r, nxt_a, o0, o1;
+            r.v = *reinterpret_cast<const V*>(resp + x);
+            nxt_a.v = *reinterpret_cast<const V*>(avgp + x + N);
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                uint32_t nx = x + k + 1;
+                S cand = k + 1 < N ? cur_a.s[k + 1] : nxt_a.s[0];
+                S next_avg = nx < avg_w ? cand : avg;
+                S first, second;
+                squeeze_pair<S>(r.s[k], next_avg, avg, left, first, second);
+                if (2 * k < N) { o0.s[2 * k] = first; o0.s[2 * k + 1] = second; }
+                else { o1.s[2 * k - N] = first; o1.s[2 * k + 1 - N] = second; }
             }
-            for (uint32_t c = lane; c < n; c += 64) s_res[r][c] = resp[(size_t)r * a.res_stride + x0 + c];
+            *reinterpret_cast<V*>(outp + 2 * x) = o0.v;
+            *reinterpret_cast<V*>(outp + 2 * x + N) = o1.v;
+            cur_a.v = nxt_a.v;
         }
-        __syncthreads();
-        if ((uint32_t)lane < rows) {
-            if (x0 == 0) { avg = s_avg[lane][0]; left = avg; }
-            for (uint32_t c = 0; c < n; ++c) {
-                S residu = s_res[lane][c];
-                S next_avg = (x0 + c + 1 < avg_w) ? s_avg[lane][c + 1] : avg;
-                S diff = Wrap<S>::add(residu, tendency<S>(left, avg, next_avg));
-                S first = Wrap<S>::add(avg, (S)(diff / 2));
-                S second = Wrap<S>::sub(first, diff);
-                s_out[lane][2 * c] = first;
-                s_out[lane][2 * c + 1] = second;
-                avg = next_avg;
-                left = second;
-            }
-        }
-        __syncthreads();
-        for (uint32_t r = 0; r < rows; ++r)
-            for (uint32_t c = lane; c < 2 * n; c += 64) outp[(size_t)r * a.out_stride + 2 * x0 + c] = s_out[r][c];
-        __syncthreads();
     }
-    if ((a.width & 1) && (uint32_t)lane < rows)
-        outp[(size_t)lane * a.out_stride + a.width - 1] = avgp[(size_t)lane * a.avg_stride + avg_w - 1];
+    constexpr int PF = 8;
+    for (; x + PF <= pairs; x += PF) {
+        S r[PF], n[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            r[k] = resp[x + k];
+            n[k] = (x + k + 1 < avg_w) ? avgp[x + k + 1] : (S)0;
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            S next_avg = (x + k + 1 < avg_w) ? n[k] : avg;
+            S first, second;
+            squeeze_pair<S>(r[k], next_avg, avg, left, first, second);
+            outp[2 * (x + k)] = first;
+            outp[2 * (x + k) + 1] = second;
+        }
+    }
+    for (; x < pairs; ++x) {
+        S next_avg = (x + 1 < avg_w) ? avgp[x + 1] : avg;
+        S first, second;
+        squeeze_pair<S>(resp[x], next_avg, avg, left, first, second);
+        outp[2 * x] = first;
+        outp[2 * x + 1] = second;
+    }
+    if (a.width & 1) outp[a.width - 1] = avgp[avg_w - 1];
 }
 
 // ---------------------------------------------------------------- device: RCT, palette, gradient
@@ -407,8 +428,14 @@ int fail(jxlgpu_ctx* ctx, int code, const char* msg) {
 
 template <typename S>
 void launch_squeeze(hipStream_t s, bool horizontal, const SqzArgs& a) {
-    if (horizontal) squeeze_h_kernel<S><<<ceil_div(a.height, 64), 64, 0, s>>>(a);
-    else squeeze_v_kernel<S><<<ceil_div(a.width, 64), 64, 0, s>>>(a);
+    if (horizontal) {
+        auto al = [](const void* p, uint32_t stride) { return ((uintptr_t)p % 16 == 0) && ((stride * sizeof(S)) % 16 == 0); };
+        const bool vec = al(a.avg, a.avg_stride) && al(a.res, a.res_stride) && al(a.out, a.out_stride);
+        if (vec) squeeze_h_kernel<S, true><<<ceil_div(a.height, 64), 64, 0, s>>>(a);
+        else squeeze_h_kernel<S, false><<<ceil_div(a.height, 64), 64, 0, s>>>(a);
+    } else {
+        squeeze_v_kernel<S><<<ceil_div(a.width, 64), 64, 0, s>>>(a);
+    }
 }
 
 // Runs predictor application + all inverse transforms on the working copies.
@@ -517,6 +544,12 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     g.loc = out_loc;
                     if (i16) launch_squeeze<int16_t>(s, st.horizontal, a);
                     else launch_squeeze<int32_t>(s, st.horizontal, a);
+                    if (getenv("JXLGPU_DEBUG_SYNC")) {
+                        hipError_t e = hipStreamSynchronize(s);
+                        fprintf(stderr, "squeeze %s ch%d %ux%u avg=%p(%u) res=%p(%u) out=%p(%u) -> %s\n", st.horizontal ? "H" : "V",
+                                begin + k, a.width, a.height, a.avg, a.avg_stride, a.res, a.res_stride, a.out, a.out_stride,
+                                hipGetErrorString(e));
+                    }
                 }
             }
         } else if (tr.kind == JXLGPU_TR_RCT) {

@@ -159,8 +159,9 @@ class VardctWorkload:
             k = np.ones(9) / 9.0
             g = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, g)
             g = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 0, g)
-            g = g[4:4 + h8, 4:4 + w8] + 0.15 * rng.normal(size=(h8, w8))
-            return np.rint(offset + amp * g)
+            g = g[4:4 + h8, 4:4 + w8]
+            # ~0.6 quantisation steps of noise: small enough that adaptive LF smoothing engages
+            return np.rint(offset + amp * g + 0.6 * rng.normal(size=(h8, w8)))
         lf_dtype = np.int16 if lf_i16 else np.int32
         self.lf_sample_type = abi.SAMPLE_I16 if lf_i16 else abi.SAMPLE_I32
         self.lfq = [smooth(180.0, 220.0).astype(lf_dtype),   # Y
