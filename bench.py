@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--prof-group", type=int, default=None, help="force the event-bracketed kernel group")
+    ap.add_argument("--streams", type=int, default=4, help="contexts (HIP streams) per rank; frames round-robin over them")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -62,22 +63,24 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    ctx = runtime.Context(local_rank)
+    ctxs = [runtime.Context(local_rank) for _ in range(max(1, args.streams))]
+    ctx = ctxs[0]
     stages = abi.STAGE_ALL
 
     # ---- synthetic frames (decoded state), uploaded once; untimed
     wls = [VardctWorkload(args.width, args.height, seed=2 * 1000 + rank * 64 + i) for i in range(args.distinct)]
     frames = []
     for i in range(args.frames_per_gpu):
-        frames.append(ctx.vardct_upload(wls[i % args.distinct].desc()))  # own device copy each
+        frames.append(ctxs[i % len(ctxs)].vardct_upload(wls[i % args.distinct].desc()))  # own device copy each
     mp_per_frame = args.width * args.height / 1e6
 
     def step():
         for f in frames:
-            ctx.vardct_render(f, stages, to_host=False)
+            f.ctx.vardct_render(f, stages, to_host=False)
 
     def barrier():
-        ctx.synchronize()
+        for c in ctxs:
+            c.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -163,6 +166,7 @@ def main():
             "config": {
                 "workload": f"{args.width}x{args.height} VarDCT d1 XYB, Gabor + EPF iters 2, XYB->sRGB f32 planar",
                 "frames_per_gpu_per_step": args.frames_per_gpu,
+                "streams_per_gpu": len(ctxs),
                 "distinct_frames_per_gpu": args.distinct,
                 "sharding": "frames across ranks, no data-path collective",
                 "input": "decoded state resident in HBM (i32 coefficients, LF quant, block map)",
@@ -172,7 +176,8 @@ def main():
         }
     for f in frames:
         f.free()
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

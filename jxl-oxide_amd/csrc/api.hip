@@ -12,7 +12,8 @@
 #include "common.h"
 
 void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
-                       float* const out[3], uint32_t out_stride, bool gabor, int epf_iters, bool color);
+                       float* const out[3], uint32_t out_stride, bool gabor, int epf_iters, bool color,
+                       jxlgpu_ctx* ctx);
 bool fused_post_supported(const jxlgpu_frame* f, bool gabor, int epf_iters);
 
 namespace {
@@ -509,7 +510,7 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
     if ((do_gab || epf_iters) && fused_post_supported(f, do_gab, epf_iters)) {
         const float* in[3] = {cur[0], cur[1], cur[2]};
         float** dst = (cur[0] == f->buf_a[0]) ? f->buf_b : f->buf_a;
-        launch_fused_post(s, f, in, *cur_stride, dst, f->wr, do_gab, epf_iters, do_color && !do_up);
+        launch_fused_post(s, f, in, *cur_stride, dst, f->wr, do_gab, epf_iters, do_color && !do_up, ctx);
         for (int c = 0; c < 3; ++c) cur[c] = dst[c];
         *cur_stride = f->wr;
         if (do_color && !do_up) {

@@ -231,6 +231,8 @@ struct StreamState {
     float I[4][3], G[4][3], V[4][3], H[4][3], E[4][3], Wd[4][3];
     float nxt[3];
     float sig_nxt, sig_e, sig_f;  // sigma for rows e(next), e, f = e-1 (one load per row, prefetched)
+    float inv_nxt, inv_e, inv_f;  // K / sigma for the same rows (recomputed when the 8x8 cell row changes)
+    float d1_dn, d2_dn;           // scaled distance of the (0,+1) tap of the previous row == (0,-1) tap of this one
 };
 
 struct StreamConst {
@@ -244,7 +246,8 @@ struct StreamConst {
 // One row step; P = (j - j_start) & 3 is a compile-time phase so every ring slot below is a
 // fixed register (no rotation moves).
 template <int P, int TF>
-__device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst& k, StreamState& st, int j) {
+__device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst& k, StreamState& st, int j,
+                                           const uint32_t* srgb_lut) {
     constexpr int s0 = P & 3, sm1 = (P + 3) & 3, sm2 = (P + 2) & 3, sm3 = (P + 1) & 3;  // rows j, j-1, j-2, j-3 (== j-4 -> s0)
     // ---- take the prefetched input row j, prefetch row j+1
 #pragma unroll
@@ -255,9 +258,12 @@ __device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst
 #pragma unroll
         for (int c = 0; c < 3; ++c) st.nxt[c] = a.in[c][gi];
         // sigma of row e+1 = j-2 for the next step; this step's f = e-1 reuses the previous e
-        st.sig_f = st.sig_e;
-        st.sig_e = st.sig_nxt;
-        st.sig_nxt = a.sigma[(size_t)((j - 2) >> 3) * a.sigma_stride + (k.xl >> 3)];
+        st.sig_f = st.sig_e; st.inv_f = st.inv_e;
+        st.sig_e = st.sig_nxt; st.inv_e = st.inv_nxt;
+        if (((j - 2) & 7) == 0) {  // wave-uniform: a new row of 8x8 cells starts
+            st.sig_nxt = a.sigma[(size_t)((j - 2) >> 3) * a.sigma_stride + (k.xl >> 3)];
+            st.inv_nxt = k.K / st.sig_nxt;
+        }
     }
     // ---- Gabor row g = j-1 (run_gabor_row_generic interior expression, gabor.rs:135-147):
     //      t = I(j-2), c = I(j-1), b = I(j).  G(g) -> slot sm1; G(g-1) is slot sm2.
@@ -278,35 +284,40 @@ __device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst
         float sigma_val = st.sig_e;
         bool y_bd = ((e + 1) & 6) == 0;
         float sm = (y_bd || k.x_bd) ? k.sm1_bd : k.sm1_in;
-        float neg_inv_sigma = k.K / sigma_val * sm;
-        float acc[4][3], tapv[4][3];
+        float neg_inv_sigma = st.inv_e * sm;
+        // The five |differences| of tap (0,+1) at row e are exactly those of tap (0,-1) at row e+1
+        // (same values, same order), and tap (+1,0) at x is tap (-1,0) at x+1: only the "down"
+        // and "left" distances are computed; "up" comes from the previous step, "right" from lane+1.
+        float acc_dn[3], acc_lf[3], tapv[4][3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float Va = st.V[s0][c], Vb = st.V[sm3][c], Vc = st.V[sm2][c], Vd = st.V[sm1][c];
+            float Vb = st.V[sm3][c], Vc = st.V[sm2][c], Vd = st.V[sm1][c];
             float Ha = st.H[s0][c], Hb = st.H[sm3][c], Hc = st.H[sm2][c];
-            // tap (0,-1): V(x,y-1) V(x,y) V(x,y+1) V(x-1,y) V(x+1,y)
-            acc[0][c] = Va + Vb + Vc + from_left(Vb) + from_right(Vb);
             // tap (0,1):  V(x,y) V(x,y+1) V(x,y+2) V(x-1,y+1) V(x+1,y+1)
-            acc[1][c] = Vb + Vc + Vd + from_left(Vc) + from_right(Vc);
+            acc_dn[c] = Vb + Vc + Vd + from_left(Vc) + from_right(Vc);
             // tap (-1,0): H(x,y-1) H(x,y) H(x,y+1) H(x-1,y) H(x+1,y)
-            float hbr = from_right(Hb);
-            acc[2][c] = Ha + Hb + Hc + from_left(Hb) + hbr;
-            // tap (1,0):  H(x+1,y-1) H(x+1,y) H(x+1,y+1) H(x,y) H(x+2,y)
-            acc[3][c] = from_right(Ha) + hbr + from_right(Hc) + Hb + from_right(hbr);
+            acc_lf[c] = Ha + Hb + Hc + from_left(Hb) + from_right(Hb);
             float Gc = st.G[sm3][c];
             tapv[0][c] = st.G[s0][c];
             tapv[1][c] = st.G[sm2][c];
             tapv[2][c] = from_left(Gc);
             tapv[3][c] = from_right(Gc);
         }
+        float dist[4];
+        dist[1] = k.cs0 * acc_dn[0];
+        dist[1] += k.cs1 * acc_dn[1];
+        dist[1] += k.cs2 * acc_dn[2];
+        dist[2] = k.cs0 * acc_lf[0];
+        dist[2] += k.cs1 * acc_lf[1];
+        dist[2] += k.cs2 * acc_lf[2];
+        dist[0] = st.d1_dn;
+        st.d1_dn = dist[1];
+        dist[3] = from_right(dist[2]);
         float sum_w = 1.0f;
         float sum_c[3] = {st.G[sm3][0], st.G[sm3][1], st.G[sm3][2]};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            float dist = k.cs0 * acc[t][0];
-            dist += k.cs1 * acc[t][1];
-            dist += k.cs2 * acc[t][2];
-            float w = fmaxf(1.0f + dist * neg_inv_sigma, 0.0f);
+            float w = fmaxf(1.0f + dist[t] * neg_inv_sigma, 0.0f);
             sum_w += w;
 #pragma unroll
             for (int c = 0; c < 3; ++c) sum_c[c] += w * tapv[t][c];
@@ -327,30 +338,34 @@ __device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst
         float sigma_val = st.sig_f;
         bool y_bd = ((f + 1) & 6) == 0;
         float sm = (y_bd || k.x_bd) ? k.sm2_bd : k.sm2_in;
-        float neg_inv_sigma = k.K / sigma_val * sm;
-        float d[4][3], tapv[4][3];
+        float neg_inv_sigma = st.inv_f * sm;
+        float d_dn[3], d_lf[3], tapv[4][3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float Ec = st.E[s0][c];
             float el = from_left(Ec);
-            float hl = fabsf(el - Ec);            // |E(x-1,f) - E(x,f)|
-            d[0][c] = st.Wd[s0][c];               // |E(f) - E(f-1)|
-            d[1][c] = st.Wd[sm3][c];              // |E(f+1) - E(f)|
-            d[2][c] = hl;
-            d[3][c] = from_right(hl);             // |E(x+1,f) - E(x,f)|
+            d_dn[c] = st.Wd[sm3][c];              // |E(f+1) - E(f)|
+            d_lf[c] = fabsf(el - Ec);             // |E(x-1,f) - E(x,f)|
             tapv[0][c] = st.E[sm1][c];
             tapv[1][c] = st.E[sm3][c];
             tapv[2][c] = el;
             tapv[3][c] = from_right(Ec);
         }
+        float dist[4];
+        dist[1] = k.cs0 * d_dn[0];
+        dist[1] += k.cs1 * d_dn[1];
+        dist[1] += k.cs2 * d_dn[2];
+        dist[2] = k.cs0 * d_lf[0];
+        dist[2] += k.cs1 * d_lf[1];
+        dist[2] += k.cs2 * d_lf[2];
+        dist[0] = st.d2_dn;                       // |E(f) - E(f-1)| terms: the previous row's "down"
+        st.d2_dn = dist[1];
+        dist[3] = from_right(dist[2]);            // |E(x+1,f) - E(x,f)| terms: lane+1's "left"
         float sum_w = 1.0f;
         float sum_c[3] = {st.E[s0][0], st.E[s0][1], st.E[s0][2]};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            float dist = k.cs0 * d[t][0];
-            dist += k.cs1 * d[t][1];
-            dist += k.cs2 * d[t][2];
-            float w = fmaxf(1.0f + dist * neg_inv_sigma, 0.0f);
+            float w = fmaxf(1.0f + dist[t] * neg_inv_sigma, 0.0f);
             sum_w += w;
 #pragma unroll
             for (int c = 0; c < 3; ++c) sum_c[c] += w * tapv[t][c];
@@ -361,7 +376,7 @@ __device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst
     }
     if (f >= k.yb && k.store_lane) {
         if (a.do_color) {
-            if constexpr (TF == JXLGPU_TF_SRGB) color_pixel_srgb(a.color, o);
+            if constexpr (TF == JXLGPU_TF_SRGB) color_pixel_srgb_lut(a.color, o, srgb_lut);
             else color_pixel(a.color, o);
         }
         size_t go = (size_t)f * a.out_stride + k.x;
@@ -372,6 +387,9 @@ __device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst
 
 template <int TF>
 __global__ __launch_bounds__(256) void post_stream_kernel(FusedArgs a) {
+    __shared__ uint32_t srgb_lut[16];
+    if (threadIdx.x < 16) srgb_lut[threadIdx.x] = kSrgbMulBits[threadIdx.x];
+    __syncthreads();
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int strip = wave % a.strips, seg = wave / a.strips;
@@ -407,14 +425,17 @@ __global__ __launch_bounds__(256) void post_stream_kernel(FusedArgs a) {
         for (int c = 0; c < 3; ++c) st.nxt[c] = a.in[c][gi];
         // first step is j = yb-SH with e = j-3: sig_nxt must hold sigma(row j-3) when it rotates in
         st.sig_e = st.sig_f = 1.0f;
+        st.inv_e = st.inv_f = 0.0f;
+        st.d1_dn = st.d2_dn = 0.0f;
         st.sig_nxt = a.sigma[(size_t)((k.yb - SH - 3) >> 3) * a.sigma_stride + (k.xl >> 3)];
+        st.inv_nxt = k.K / st.sig_nxt;
     }
     // (ye - yb) and 2*SH are multiples of 4: whole groups of four phases
     for (int j = k.yb - SH; j < ye + SH; j += 4) {
-        stream_row<0, TF>(a, k, st, j);
-        stream_row<1, TF>(a, k, st, j + 1);
-        stream_row<2, TF>(a, k, st, j + 2);
-        stream_row<3, TF>(a, k, st, j + 3);
+        stream_row<0, TF>(a, k, st, j, srgb_lut);
+        stream_row<1, TF>(a, k, st, j + 1, srgb_lut);
+        stream_row<2, TF>(a, k, st, j + 2, srgb_lut);
+        stream_row<3, TF>(a, k, st, j + 3, srgb_lut);
     }
 }
 
@@ -439,7 +460,8 @@ bool fused_post_supported(const jxlgpu_frame* f, bool gabor, int epf_iters) {
 }
 
 void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
-                       float* const out[3], uint32_t out_stride, bool gabor, int epf_iters, bool color) {
+                       float* const out[3], uint32_t out_stride, bool gabor, int epf_iters, bool color,
+                       jxlgpu_ctx* ctx) {
     FusedArgs a;
     memset(&a, 0, sizeof(a));
     for (int c = 0; c < 3; ++c) { a.in[c] = in[c]; a.out[c] = out[c]; }
@@ -479,11 +501,20 @@ void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3],
         const int waves = a.strips * a.segs;
         // plain XYB -> sRGB (no gamut map / second matrix) gets a branch-free colour epilogue
         const bool plain_srgb = a.color.tf == JXLGPU_TF_SRGB && !a.color.gamut_map && !a.color.has_matrix2;
+        if (ctx && ctx->stream2) (void)hipEventRecord(ctx->ev_fork, s);  // inputs are ready here
         if (plain_srgb) post_stream_kernel<JXLGPU_TF_SRGB><<<(waves + 3) / 4, 256, 0, s>>>(a);
         else post_stream_kernel<-1><<<(waves + 3) / 4, 256, 0, s>>>(a);
         a.tiles = f->ring_tiles;
         constexpr size_t lds_bytes = 2 * 3 * PostCfg<true, 2>::PLANE * sizeof(float);
-        fused_post_kernel<true, 2><<<f->n_ring_tiles, 256, lds_bytes, s>>>(a);
+        // the border ring (a few hundred long-latency tiles) runs beside the streaming kernel
+        if (ctx && ctx->stream2) {
+            (void)hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
+            fused_post_kernel<true, 2><<<f->n_ring_tiles, 256, lds_bytes, ctx->stream2>>>(a);
+            (void)hipEventRecord(ctx->ev_join, ctx->stream2);
+            (void)hipStreamWaitEvent(s, ctx->ev_join, 0);
+        } else {
+            fused_post_kernel<true, 2><<<f->n_ring_tiles, 256, lds_bytes, s>>>(a);
+        }
         return;
     }
     switch ((gabor ? 4 : 0) + epf_iters) {

@@ -246,3 +246,44 @@ __device__ __forceinline__ void color_pixel_srgb(const ColorArgs& cp, float (&v)
 #pragma unroll
     for (int c = 0; c < 3; ++c) v[c] = linear_to_srgb_dev(v[c]);
 }
+
+// 2^(e/2.4)-style multipliers of linear_to_srgb (srgb.rs:4-9 tables expanded): 0x40000000 |
+// upper[idx] << 18 | lower[idx] << 10, looked up from a 16-word LDS table instead of two 64-bit
+// shift/select sequences.
+__device__ constexpr uint32_t kSrgbMulBits[16] = {
+    0x40000000u | (0x00u << 18) | (0x00u << 10), 0x40000000u | (0x0au << 18) | (0xb7u << 10),
+    0x40000000u | (0x19u << 18) | (0x04u << 10), 0x40000000u | (0x26u << 18) | (0x0du << 10),
+    0x40000000u | (0x32u << 18) | (0xcbu << 10), 0x40000000u | (0x41u << 18) | (0xe7u << 10),
+    0x40000000u | (0x4du << 18) | (0x41u << 10), 0x40000000u | (0x5cu << 18) | (0x68u << 10),
+    0x40000000u | (0x68u << 18) | (0x51u << 10), 0x40000000u | (0x75u << 18) | (0xd1u << 10),
+    0x40000000u | (0x83u << 18) | (0xebu << 10), 0x40000000u | (0x8fu << 18) | (0xf2u << 10),
+    0x40000000u | (0xa0u << 18) | (0x00u << 10), 0x40000000u | (0xaau << 18) | (0xb7u << 10),
+    0x40000000u | (0xb9u << 18) | (0x04u << 10), 0x40000000u | (0xc6u << 18) | (0x0du << 10)};
+
+__device__ __forceinline__ float linear_to_srgb_lut(float s, const uint32_t* lut) {
+    uint32_t v = __float_as_uint(s) & 0x7fffffffu;
+    float v_adj = __uint_as_float((v | 0x3e800000u) & 0x3effffffu);
+    float pow = 0.059914046f;
+    pow = pow * v_adj - 0.10889456f;
+    pow = pow * v_adj + 0.107963754f;
+    pow = pow * v_adj + 0.018092343f;
+    uint32_t idx = ((v >> 23) - 118u) & 0xfu;
+    float vf = __uint_as_float(v);
+    float small = vf * 12.92f;
+    float acc = pow * __uint_as_float(lut[idx]) - 0.055f;
+    return copysignf(vf <= 0.0031308f ? small : acc, s);
+}
+
+__device__ __forceinline__ void color_pixel_srgb_lut(const ColorArgs& cp, float (&v)[3], const uint32_t* lut) {
+    float x = v[0], y = v[1], b = v[2];
+    float g_l = y + x, g_m = y - x, g_s = b;
+    g_l = g_l - cp.cbrt_opsin_bias[0];
+    g_m = g_m - cp.cbrt_opsin_bias[1];
+    g_s = g_s - cp.cbrt_opsin_bias[2];
+    v[0] = __builtin_fmaf(g_l * g_l, g_l, cp.opsin_bias[0]) * cp.itscale;
+    v[1] = __builtin_fmaf(g_m * g_m, g_m, cp.opsin_bias[1]) * cp.itscale;
+    v[2] = __builtin_fmaf(g_s * g_s, g_s, cp.opsin_bias[2]) * cp.itscale;
+    matmul3vec_dev(cp.matrix, v);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = linear_to_srgb_lut(v[c], lut);
+}

@@ -298,11 +298,11 @@ struct VbCfg {
     static constexpr int LDS_WORDS = 3 * CH + NB;  // tiles + per-block cell position
 };
 
-template <int W, int H, bool SPECIAL>
+template <int W, int H, bool SPECIAL, int NT = 256, int NBX = VbCfg<W, H>::NB>
 __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* __restrict__ entries,
                                           int nvalid, float* lds) {
     using Cfg = VbCfg<W, H>;
-    constexpr int NB = Cfg::NB, S = Cfg::S, BLK = Cfg::BLK, CH = Cfg::CH, BW = Cfg::BW, BH = Cfg::BH;
+    constexpr int NB = NBX, S = Cfg::S, BLK = Cfg::BLK, CH = NB * BLK, BW = Cfg::BW, BH = Cfg::BH;
     float* tile = lds;
     uint32_t* s_cell = reinterpret_cast<uint32_t*>(lds + 3 * CH);
 
@@ -314,7 +314,7 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
     constexpr int VEC_PER_BLK = W * H / 4;
     constexpr int VECS = NB * VEC_PER_BLK;
 #pragma unroll 2
-    for (int v4 = t; v4 < VECS; v4 += 256) {
+    for (int v4 = t; v4 < VECS; v4 += NT) {
         int blk = v4 / VEC_PER_BLK;
         if (blk >= nvalid) break;
         int r = v4 % VEC_PER_BLK;
@@ -410,7 +410,7 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
     } else {
         // ---- P2: 1-D inverse DCT of every row (dct_2d, dct.rs:93-96), one row per lane
         constexpr int ROWS = 3 * NB * H;
-        for (int r = t; r < ROWS; r += 256) {
+        for (int r = t; r < ROWS; r += NT) {
             int c = r / (NB * H), rb = r % (NB * H);
             int blk = rb / H, y = rb % H;
             if (blk >= nvalid) continue;
@@ -425,7 +425,7 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
         __syncthreads();
         // ---- P3: 1-D inverse DCT of every column (dct.rs:109-130), one column per lane
         constexpr int COLS = 3 * NB * W;
-        for (int r = t; r < COLS; r += 256) {
+        for (int r = t; r < COLS; r += NT) {
             int c = r / (NB * W), rb = r % (NB * W);
             int blk = rb / W, x = rb % W;
             if (blk >= nvalid) continue;
@@ -441,7 +441,7 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
     __syncthreads();
 
     // ---- P4: 16-byte stores of the finished samples
-    for (int v4 = t; v4 < VECS; v4 += 256) {
+    for (int v4 = t; v4 < VECS; v4 += NT) {
         int blk = v4 / VEC_PER_BLK;
         if (blk >= nvalid) break;
         int r = v4 % VEC_PER_BLK;
@@ -498,31 +498,125 @@ void launch_transform_small(hipStream_t s, const TransformArgs& a, const uint4* 
 // The 8x8 non-DCT family (Hornuss, DCT2, DCT4, 4x8, 8x4, AFV): register-hungry serial code per
 // block, kept out of the kernel above so it does not drag its occupancy down; runs on the side
 // stream together with the 64-pixel shapes.
-__global__ __launch_bounds__(256) void transform_special_kernel(TransformArgs a, const uint4* __restrict__ entries,
-                                                                uint32_t count) {
+constexpr int kSpecialNB = 8;   // 8 blocks x 3 channels = 24 serial transforms per 64-lane workgroup
+__global__ __launch_bounds__(64) void transform_special_kernel(TransformArgs a, const uint4* __restrict__ entries,
+                                                               uint32_t count) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NB = VbCfg<8, 8>::NB;
-    const uint32_t first = blockIdx.x * NB;
-    run_class<8, 8, true>(a, entries + first, (int)min((uint32_t)NB, count - first), lds);
+    const uint32_t first = blockIdx.x * kSpecialNB;
+    run_class<8, 8, true, 64, kSpecialNB>(a, entries + first, (int)min((uint32_t)kSpecialNB, count - first), lds);
 }
 
-// 64-pixel shapes: one varblock per workgroup (49 KiB of LDS, 64-point butterflies in registers).
+// 64-pixel shapes: one wave per (varblock, channel).  The tile of one channel (<= 16.6 KiB) is
+// staged in LDS; X and B recompute the dequantised Y coefficient for chroma-from-luma instead of
+// sharing it through LDS, which buys 3x more independent waves for these rare, long blocks.  The
+// LF -> LLF forward DCT (up to 8x8) runs one row / one column per lane.
 template <int W, int H>
-__global__ __launch_bounds__(256) void transform_kernel64(TransformArgs a, const uint4* __restrict__ entries) {
+__global__ __launch_bounds__(64) void transform_kernel64(TransformArgs a, const uint4* __restrict__ entries) {
+    constexpr int S = W + 1, BW = W / 8, BH = H / 8;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    run_class<W, H, false>(a, entries + blockIdx.x, 1, lds);
+    float* tile = lds;                 // H x S
+    float* llf = lds + H * S;          // BH x (BW + 1)
+    constexpr int LS = BW + 1;
+    const SecLarge sl{a.sec64, a.sec128, a.sec256};
+    const int t = threadIdx.x;
+    const int c = blockIdx.y;
+    const uint4 e = entries[blockIdx.x];
+    const uint32_t px0 = (e.x & 0xffffu) * 8, py0 = (e.x >> 16) * 8;
+    const size_t cell = (size_t)(e.x >> 16) * a.w8 + (e.x & 0xffffu);
+    const float mul_base = 65536.0f / (a.global_scale * (float)(int32_t)e.z);
+    const float mul_c = mul_base * a.qm_scale[c], mul_y = mul_base * a.qm_scale[1];
+    const float* mat_c = a.dequant + a.deq_off[e.y * 3 + c];
+    const float* mat_y = a.dequant + a.deq_off[e.y * 3 + 1];
+
+    // LF samples of this varblock -> LDS
+    for (int i = t; i < BW * BH; i += 64) {
+        int y = i / BW, x = i % BW;
+        llf[y * LS + x] = a.lf[c][cell + (size_t)y * a.w8 + x];
+    }
+    // V4 + V5: dequantise + chroma-from-luma, 4 coefficients per lane-iteration
+    constexpr int VECS = W * H / 4;
+#pragma unroll 4
+    for (int v4 = t; v4 < VECS; v4 += 64) {
+        int y = v4 / (W / 4), x = (v4 % (W / 4)) * 4;
+        uint32_t px = px0 + x, py = py0 + y;
+        size_t goff = (size_t)py * a.cstride + px;
+        int4 q = *reinterpret_cast<const int4*>(a.coeff[c] + goff);
+        float4 m = *reinterpret_cast<const float4*>(mat_c + y * W + x);
+        float d[4];
+        d[0] = dequant_one(q.x, a.quant_bias[c], a.quant_bias_numerator, m.x, mul_c);
+        d[1] = dequant_one(q.y, a.quant_bias[c], a.quant_bias_numerator, m.y, mul_c);
+        d[2] = dequant_one(q.z, a.quant_bias[c], a.quant_bias_numerator, m.z, mul_c);
+        d[3] = dequant_one(q.w, a.quant_bias[c], a.quant_bias_numerator, m.w, mul_c);
+        if (c != 1) {
+            int4 qy = *reinterpret_cast<const int4*>(a.coeff[1] + goff);
+            float4 my = *reinterpret_cast<const float4*>(mat_y + y * W + x);
+            uint32_t ti = (py >> 6) * a.w64 + (px >> 6);
+            float k = c == 0 ? a.kx_map[ti] : a.kb_map[ti];
+            d[0] += k * dequant_one(qy.x, a.quant_bias[1], a.quant_bias_numerator, my.x, mul_y);
+            d[1] += k * dequant_one(qy.y, a.quant_bias[1], a.quant_bias_numerator, my.y, mul_y);
+            d[2] += k * dequant_one(qy.z, a.quant_bias[1], a.quant_bias_numerator, my.z, mul_y);
+            d[3] += k * dequant_one(qy.w, a.quant_bias[1], a.quant_bias_numerator, my.w, mul_y);
+        }
+        float* dst = tile + y * S + x;
+        const bool corner_row = y < BH && x < BW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (!(corner_row && x + j < BW)) dst[j] = d[j];
+    }
+    __syncthreads();
+    // V6: forward DCT of the BW x BH LF block (dct_2d general case: rows, then columns), scale_f
+    if (t < BH) {
+        float v[BW];
+#pragma unroll
+        for (int x = 0; x < BW; ++x) v[x] = llf[t * LS + x];
+        fdct<BW>(v, sl);
+#pragma unroll
+        for (int x = 0; x < BW; ++x) llf[t * LS + x] = v[x];
+    }
+    __syncthreads();
+    if (t < BW) {
+        float v[BH];
+#pragma unroll
+        for (int y = 0; y < BH; ++y) v[y] = llf[y * LS + t];
+        fdct<BH>(v, sl);
+        constexpr int sy = 5 - __builtin_ctz(BH), sx = 5 - __builtin_ctz(BW);
+#pragma unroll
+        for (int y = 0; y < BH; ++y) tile[y * S + t] = v[y] / (kScaleF[y << sy] * kScaleF[t << sx]);
+    }
+    __syncthreads();
+    // V7: rows, then columns
+    if (t < H) {
+        float* row = tile + t * S;
+        float v[W];
+#pragma unroll
+        for (int x = 0; x < W; ++x) v[x] = row[x];
+        idct<W>(v, sl);
+#pragma unroll
+        for (int x = 0; x < W; ++x) row[x] = v[x];
+    }
+    __syncthreads();
+    if (t < W) {
+        float* col = tile + t;
+        float v[H];
+#pragma unroll
+        for (int y = 0; y < H; ++y) v[y] = col[y * S];
+        idct<H>(v, sl);
+#pragma unroll
+        for (int y = 0; y < H; ++y) col[y * S] = v[y];
+    }
+    __syncthreads();
+    for (int v4 = t; v4 < VECS; v4 += 64) {
+        int y = v4 / (W / 4), x = (v4 % (W / 4)) * 4;
+        const float* src = tile + y * S + x;
+        *reinterpret_cast<float4*>(a.pix[c] + (size_t)(py0 + y) * a.pstride + px0 + x) =
+            make_float4(src[0], src[1], src[2], src[3]);
+    }
 }
 
 template <int W, int H>
 static void launch_tk64(hipStream_t s, const TransformArgs& a, const uint4* entries, uint32_t count) {
-    constexpr int bytes = VbCfg<W, H>::LDS_WORDS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&transform_kernel64<W, H>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        attr_set = true;
-    }
-    transform_kernel64<W, H><<<count, 256, bytes, s>>>(a, entries);
+    constexpr int bytes = (H * (W + 1) + (H / 8) * (W / 8 + 1)) * sizeof(float);
+    transform_kernel64<W, H><<<dim3(count, 3), 64, bytes, s>>>(a, entries);
 }
 
 void launch_big_blocks(hipStream_t s, const TransformArgs& a, const uint4* entries, uint32_t count);
@@ -532,8 +626,8 @@ void launch_transform_class(hipStream_t s, int cls, const TransformArgs& a, cons
     if (count == 0) return;
     switch (cls) {
         case CLS_SPECIAL8:
-            transform_special_kernel<<<ceil_div(count, VbCfg<8, 8>::NB), 256,
-                                       VbCfg<8, 8>::LDS_WORDS * sizeof(float), s>>>(a, entries, count);
+            transform_special_kernel<<<ceil_div(count, kSpecialNB), 64,
+                                       (3 * kSpecialNB * VbCfg<8, 8>::BLK + kSpecialNB) * sizeof(float), s>>>(a, entries, count);
             break;
         case CLS_64x64: launch_tk64<64, 64>(s, a, entries, count); break;
         case CLS_32x64: launch_tk64<32, 64>(s, a, entries, count); break;
