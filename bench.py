@@ -88,18 +88,15 @@ def main():
     # ---- warmup; also find the dominant kernel group with event brackets
     group_ms = {}
     for w in range(max(args.warmup, 1)):
-        g = [abi_group for abi_group in (1, 2)][w % 2]
-        ctx.profile_select(g)
         step()
+    barrier()
+    mine = [f for f in frames if f.ctx is ctx]
+    for g in (1, 2):  # isolated: only ctx 0's frames, one stream busy
+        ctx.profile_select(g)
+        for f in mine:
+            ctx.vardct_render(f, stages, to_host=False)
         ms, n = ctx.profile_read()
-        if n:
-            group_ms[g] = ms / n
-    for g in (1, 2):
-        if g not in group_ms:
-            ctx.profile_select(g)
-            step()
-            ms, n = ctx.profile_read()
-            group_ms[g] = ms / max(n, 1)
+        group_ms[g] = ms / max(n, 1)
     dominant = args.prof_group if args.prof_group is not None else max(group_ms, key=group_ms.get)
     ctx.profile_select(dominant)
 
@@ -135,13 +132,17 @@ def main():
             kname = "transform_kernel<W,H> x varblock shapes (V4-V8)"
         else:
             alg_bytes = npx * 24 + ncell * 4
-            kname = "fused_post_kernel (Gabor+EPF+XYB->sRGB)" if os.environ.get("JXLGPU_NO_FUSED") is None else "staged post kernels"
+            kname = "post_stream_kernel<sRGB> (+ fused_post_kernel<true,2> border ring): Gabor + EPF steps 1,2 + XYB->sRGB"
         avg_ms = prof_ms / max(prof_n, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "kernel": kname, "avg_launch_ms": round(avg_ms, 4), "launches": int(prof_n),
+            "isolated_launch_ms": round(group_ms.get(dominant, 0.0), 4),
+            "frac_isolated": round(alg_bytes / (group_ms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if group_ms.get(dominant) else None,
+            "note": "kernel is VALU-issue bound (scalar f32, bit-exact op order), not HBM bound; with streams_per_gpu > 1 "
+                    "launches of different frames overlap, so avg_launch_ms (timed region) exceeds isolated_launch_ms (warm-up, one stream busy)",
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "other_group_ms": {("transform" if g == 1 else "post"): round(v, 4) for g, v in group_ms.items()},
             "pipeline_algorithmic_frac": round(
@@ -192,11 +193,13 @@ def cpu_baseline(wl, stages, seconds, mp_per_frame):
     from oracle import pyoracle
     cores = len(os.sched_getaffinity(0))
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    import numpy as np
     d = wl.desc()
-    pyoracle.vardct_render(d, stages, wl.width, wl.height)  # warm (page faults, table init)
+    buf = np.zeros((3, wl.height, wl.width), dtype=np.float32)
+    pyoracle.vardct_render(d, stages, wl.width, wl.height, out=buf)  # warm (page faults, table init)
     n, t0 = 0, time.perf_counter()
     while True:
-        pyoracle.vardct_render(d, stages, wl.width, wl.height)
+        pyoracle.vardct_render(d, stages, wl.width, wl.height, out=buf)
         n += 1
         dt = time.perf_counter() - t0
         if dt >= seconds or n >= 64:

@@ -21,8 +21,11 @@ int orc_post_stages(float* const pix[3], size_t stride, size_t width, size_t hei
     for (int c = 0; c < 3; ++c) {
         a[c] = (float*)malloc(sizeof(float) * n);
         b[c] = (float*)malloc(sizeof(float) * n);
-        for (size_t y = 0; y < height; ++y)
-            memcpy(a[c] + y * width, pix[c] + y * stride, sizeof(float) * width);
+#pragma omp parallel for schedule(static)
+        for (long y = 0; y < (long)height; ++y) {
+            memcpy(a[c] + (size_t)y * width, pix[c] + (size_t)y * stride, sizeof(float) * width);
+            memset(b[c] + (size_t)y * width, 0, sizeof(float) * width);  /* first touch in parallel */
+        }
     }
 #define SWAP_AB() do { for (int c_ = 0; c_ < 3; ++c_) { float* t_ = a[c_]; a[c_] = b[c_]; b[c_] = t_; } } while (0)
     if ((stages & JXLGPU_STAGE_GABOR) && fp->gab_enabled) {
@@ -65,8 +68,9 @@ int orc_post_stages(float* const pix[3], size_t stride, size_t width, size_t hei
     }
     if (stages & JXLGPU_STAGE_COLOR) orc_color_transform(a, ow * oh, cp);
     for (int c = 0; c < 3; ++c) {
-        for (size_t y = 0; y < oh; ++y)
-            memcpy(out[c] + y * out_stride, a[c] + y * ow, sizeof(float) * ow);
+#pragma omp parallel for schedule(static)
+        for (long y = 0; y < (long)oh; ++y)
+            memcpy(out[c] + (size_t)y * out_stride, a[c] + (size_t)y * ow, sizeof(float) * ow);
         free(a[c]);
         free(b[c]);
     }

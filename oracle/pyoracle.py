@@ -70,9 +70,11 @@ def transform_block(coeff, dct_select):
     return io
 
 
-def vardct_render(desc, stages, out_w, out_h, want_lf=False, w8=0, h8=0):
-    """Returns (planes[3][h,w] or None, lf[3][h8,w8] or None)."""
-    out = np.zeros((3, out_h, out_w), dtype=np.float32)
+def vardct_render(desc, stages, out_w, out_h, want_lf=False, w8=0, h8=0, out=None):
+    """Returns (planes[3][h,w] or None, lf[3][h8,w8] or None).  `out` may be a preallocated
+    (3, out_h, out_w) float32 array (the CPU-baseline timing loop reuses one)."""
+    if out is None:
+        out = np.zeros((3, out_h, out_w), dtype=np.float32)
     outp = (f32p * 3)(*[_p(out[c]) for c in range(3)])
     lf = None
     lfp = (f32p * 3)()

@@ -511,8 +511,9 @@ int jxl_oracle_vardct_render(const JxlGpuVardctDesc* d, uint32_t stages, float* 
     float* pix[3];
     for (int c = 0; c < 3; ++c) {
         pix[c] = (float*)malloc(sizeof(float) * wr * hr);
-        for (size_t y = 0; y < hr; ++y)
-            memcpy(pix[c] + y * wr, d->coeff[c] + y * d->coeff_stride, sizeof(float) * wr);
+#pragma omp parallel for schedule(static)
+        for (long y = 0; y < (long)hr; ++y)
+            memcpy(pix[c] + (size_t)y * wr, d->coeff[c] + (size_t)y * d->coeff_stride, sizeof(float) * wr);
     }
     size_t gpr = (d->width + d->group_dim - 1) / d->group_dim;
     size_t gpc = (d->height + d->group_dim - 1) / d->group_dim;
