@@ -220,7 +220,7 @@ _SYMBOLS = [
 SYMBOL_NAMES = [s[0] for s in _SYMBOLS]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libjxlgpu.so")
+LIB_PATH = os.environ.get("JXLGPU_LIB") or os.path.join(_HERE, "csrc", "libjxlgpu.so")
 
 _lib = None
 

@@ -387,7 +387,12 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
     {
         // one entry array (classes concatenated) + one descriptor per workgroup of the <=32 kernel,
         // widest shapes first so the long workgroups start early
-        static const int kNB[CLS_COUNT] = {32, 32, 8, 16, 16, 2, 8, 8, 4, 4, 1, 1, 1, 1};
+#ifndef JXL_VB_TILE
+#define JXL_VB_TILE 2048
+#endif
+        auto nb = [](int w, int h) { return w * h >= JXL_VB_TILE ? 1 : JXL_VB_TILE / (w * h); };
+        const int kNB[CLS_COUNT] = {nb(8, 8), nb(8, 8), nb(16, 16), nb(8, 16), nb(16, 8), nb(32, 32), nb(8, 32),
+                                    nb(32, 8), nb(16, 32), nb(32, 16), 1, 1, 1, 1};
         static const int kOrder[] = {CLS_32x32, CLS_16x32, CLS_32x16, CLS_8x32, CLS_32x8, CLS_16x16,
                                      CLS_8x16, CLS_16x8, CLS_DCT8};
         std::vector<uint4> entries, wgs;

@@ -212,6 +212,204 @@ __global__ __launch_bounds__(64) void squeeze_h_kernel(SqzArgs a) {
     if (a.width & 1) outp[a.width - 1] = avgp[avg_w - 1];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Segment-parallel Squeeze.  The inverse is a serial chain along the scan direction only through
+// `prev` (the previous output sample, fed to `tendency`), and a wrong `prev` is forgotten within a
+// few pairs (the error shrinks ~6x per pair and `tendency` is 0 off monotone runs).  So a row /
+// column is cut into segments: every segment starts OV pairs early from a guessed `prev`, and
+// records (a) the `prev` it had reached at its real start and (b) the `prev` it ends with.  A
+// check kernel then walks the chain of segments: segment 0 is exact by construction, segment s is
+// exact iff its (a) equals segment s-1's (b); if any link of a line fails, that line is redone
+// serially.  Bit-exactness never depends on the guess — only speed does.  This turns ~13 k long
+// chains (8K image) into ~400 k short ones, which is what fills 256 CUs.
+struct SegArgs {
+    SqzArgs a;
+    uint32_t seg_pairs;  // pairs per segment (multiple of the chunk size)
+    uint32_t nseg;
+    void* chk;           // S[nseg][2][lines]: [.][0] = prev at the segment's start, [.][1] = prev at its end
+    uint32_t runin;      // 1 = start OV pairs early (normal); 0 = no run-in (tests: forces the serial fix-up)
+};
+
+template <typename S>
+__global__ __launch_bounds__(64) void squeeze_v_seg_kernel(SegArgs g) {
+    constexpr int PF = 16, OV = 16;
+    const SqzArgs& a = g.a;
+    const uint32_t x = blockIdx.x * 64 + threadIdx.x;
+    if (x >= a.width) return;
+    const uint32_t seg = blockIdx.y;
+    const S* avgp = (const S*)a.avg + x;
+    const S* resp = (const S*)a.res + x;
+    S* out = (S*)a.out + x;
+    S* chk = (S*)g.chk;
+    const uint32_t avg_h = (a.height + 1) / 2, pairs = a.height / 2;
+    const uint32_t y_s = seg * g.seg_pairs;
+    const uint32_t y_e = (seg + 1 == g.nseg) ? pairs : y_s + g.seg_pairs;
+    uint32_t y = (seg == 0 || !g.runin) ? y_s : y_s - OV;
+    S avg = avgp[(size_t)y * a.avg_stride];
+    S top = y == 0 ? avg : avgp[(size_t)(y - 1) * a.avg_stride];  // guess: previous pair's average (exact at y == 0)
+    for (; y + PF <= y_e; y += PF) {
+        if (y == y_s) chk[((size_t)seg * 2 + 0) * a.width + x] = top;
+        S r[PF], n[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            r[k] = resp[(size_t)(y + k) * a.res_stride];
+            uint32_t ny = y + k + 1;
+            n[k] = ny < avg_h ? avgp[(size_t)ny * a.avg_stride] : (S)0;
+        }
+        const bool store = y >= y_s;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            S next_avg = (y + k + 1 < avg_h) ? n[k] : avg;
+            S first, second;
+            squeeze_pair<S>(r[k], next_avg, avg, top, first, second);
+            if (store) {
+                out[(size_t)(2 * (y + k)) * a.out_stride] = first;
+                out[(size_t)(2 * (y + k) + 1) * a.out_stride] = second;
+            }
+        }
+    }
+    for (; y < y_e; ++y) {  // tail of the last segment
+        S r = resp[(size_t)y * a.res_stride];
+        S next_avg = (y + 1 < avg_h) ? avgp[(size_t)(y + 1) * a.avg_stride] : avg;
+        S first, second;
+        squeeze_pair<S>(r, next_avg, avg, top, first, second);
+        out[(size_t)(2 * y) * a.out_stride] = first;
+        out[(size_t)(2 * y + 1) * a.out_stride] = second;
+    }
+    chk[((size_t)seg * 2 + 1) * a.width + x] = top;
+    if (seg + 1 == g.nseg && (a.height & 1))
+        out[(size_t)(a.height - 1) * a.out_stride] = avgp[(size_t)(avg_h - 1) * a.avg_stride];
+}
+
+// whole column, serially (the fix-up path and the small-rectangle path share this)
+template <typename S>
+__device__ __forceinline__ void squeeze_v_line(const SqzArgs& a, uint32_t x) {
+    constexpr int PF = 16;
+    const S* avgp = (const S*)a.avg + x;
+    const S* resp = (const S*)a.res + x;
+    S* out = (S*)a.out + x;
+    const uint32_t avg_h = (a.height + 1) / 2, pairs = a.height / 2;
+    S avg = avgp[0];
+    S top = avg;
+    uint32_t y = 0;
+    for (; y + PF <= pairs; y += PF) {
+        S r[PF], n[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            r[k] = resp[(size_t)(y + k) * a.res_stride];
+            uint32_t ny = y + k + 1;
+            n[k] = ny < avg_h ? avgp[(size_t)ny * a.avg_stride] : (S)0;
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            S next_avg = (y + k + 1 < avg_h) ? n[k] : avg;
+            S first, second;
+            squeeze_pair<S>(r[k], next_avg, avg, top, first, second);
+            out[(size_t)(2 * (y + k)) * a.out_stride] = first;
+            out[(size_t)(2 * (y + k) + 1) * a.out_stride] = second;
+        }
+    }
+    for (; y < pairs; ++y) {
+        S r = resp[(size_t)y * a.res_stride];
+        S next_avg = (y + 1 < avg_h) ? avgp[(size_t)(y + 1) * a.avg_stride] : avg;
+        S first, second;
+        squeeze_pair<S>(r, next_avg, avg, top, first, second);
+        out[(size_t)(2 * y) * a.out_stride] = first;
+        out[(size_t)(2 * y + 1) * a.out_stride] = second;
+    }
+    if (a.height & 1) out[(size_t)(a.height - 1) * a.out_stride] = avgp[(size_t)(avg_h - 1) * a.avg_stride];
+}
+
+// Horizontal, vector path only (16-byte aligned rectangles): lane = row, blockIdx.y = segment.
+template <typename S>
+__global__ __launch_bounds__(64) void squeeze_h_seg_kernel(SegArgs g) {
+    constexpr int N = 16 / sizeof(S);
+    constexpr int OV = 8;  // pairs of run-in (multiple of N)
+    using V = int4;
+    union Pack { V v; S s[N]; };
+    const SqzArgs& a = g.a;
+    const uint32_t y = blockIdx.x * 64 + threadIdx.x;
+    if (y >= a.height) return;
+    const uint32_t seg = blockIdx.y;
+    const uint32_t avg_w = (a.width + 1) / 2, pairs = a.width / 2;
+    const S* avgp = (const S*)a.avg + (size_t)y * a.avg_stride;
+    const S* resp = (const S*)a.res + (size_t)y * a.res_stride;
+    S* outp = (S*)a.out + (size_t)y * a.out_stride;
+    S* chk = (S*)g.chk;
+    const uint32_t x_s = seg * g.seg_pairs;
+    const uint32_t x_e = (seg + 1 == g.nseg) ? pairs : x_s + g.seg_pairs;
+    uint32_t x = (seg == 0 || !g.runin) ? x_s : x_s - OV;
+    S avg = avgp[x];
+    S left = x == 0 ? avg : avgp[x - 1];  // guess: previous pair's average (exact at x == 0)
+    Pack cur_a;
+    cur_a.v = *reinterpret_cast<const V*>(avgp + x);  // segments are only used when avg_w >= 2N
+    for (; x + N <= x_e && x + 2 * N <= avg_w; x += N) {
+        if (x == x_s) chk[((size_t)seg * 2 + 0) * a.height + y] = left;
+        Pack r, nxt_a, o0, o1;
+        r.v = *reinterpret_cast<const V*>(resp + x);
+        nxt_a.v = *reinterpret_cast<const V*>(avgp + x + N);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            S next_avg = k + 1 < N ? cur_a.s[k + 1] : nxt_a.s[0];  // x+k+1 < avg_w holds in this loop
+            S first, second;
+            squeeze_pair<S>(r.s[k], next_avg, avg, left, first, second);
+            if (2 * k < N) { o0.s[2 * k] = first; o0.s[2 * k + 1] = second; }
+            else { o1.s[2 * k - N] = first; o1.s[2 * k + 1 - N] = second; }
+        }
+        if (x >= x_s) {
+            *reinterpret_cast<V*>(outp + 2 * x) = o0.v;
+            *reinterpret_cast<V*>(outp + 2 * x + N) = o1.v;
+        }
+        cur_a.v = nxt_a.v;
+    }
+    for (; x < x_e; ++x) {  // scalar tail (only the last segment gets here with x >= x_s)
+        if (x == x_s) chk[((size_t)seg * 2 + 0) * a.height + y] = left;
+        S next_avg = (x + 1 < avg_w) ? avgp[x + 1] : avg;
+        S first, second;
+        squeeze_pair<S>(resp[x], next_avg, avg, left, first, second);
+        if (x >= x_s) {
+            outp[2 * x] = first;
+            outp[2 * x + 1] = second;
+        }
+    }
+    chk[((size_t)seg * 2 + 1) * a.height + y] = left;
+    if (seg + 1 == g.nseg && (a.width & 1)) outp[a.width - 1] = avgp[avg_w - 1];
+}
+
+template <typename S>
+__device__ __forceinline__ void squeeze_h_line(const SqzArgs& a, uint32_t y) {
+    const uint32_t avg_w = (a.width + 1) / 2, pairs = a.width / 2;
+    const S* avgp = (const S*)a.avg + (size_t)y * a.avg_stride;
+    const S* resp = (const S*)a.res + (size_t)y * a.res_stride;
+    S* outp = (S*)a.out + (size_t)y * a.out_stride;
+    S avg = avgp[0];
+    S left = avg;
+    for (uint32_t x = 0; x < pairs; ++x) {
+        S next_avg = (x + 1 < avg_w) ? avgp[x + 1] : avg;
+        S first, second;
+        squeeze_pair<S>(resp[x], next_avg, avg, left, first, second);
+        outp[2 * x] = first;
+        outp[2 * x + 1] = second;
+    }
+    if (a.width & 1) outp[a.width - 1] = avgp[avg_w - 1];
+}
+
+// Walk the chain of segments of every line; redo the line serially if a link is broken.
+template <typename S, bool HORIZONTAL>
+__global__ __launch_bounds__(64) void squeeze_check_kernel(SegArgs g, int* redo_count) {
+    const uint32_t lines = HORIZONTAL ? g.a.height : g.a.width;
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= lines) return;
+    const S* chk = (const S*)g.chk;
+    bool ok = true;
+    for (uint32_t s = 1; s < g.nseg; ++s)
+        ok &= chk[((size_t)s * 2 + 0) * lines + i] == chk[((size_t)(s - 1) * 2 + 1) * lines + i];
+    if (ok) return;
+    if (redo_count) atomicAdd(redo_count, 1);
+    if (HORIZONTAL) squeeze_h_line<S>(g.a, i);
+    else squeeze_v_line<S>(g.a, i);
+}
+
 // ---------------------------------------------------------------- device: RCT, palette, gradient
 struct RctArgs {
     void* p[3];
@@ -393,6 +591,9 @@ struct ModularState {
     std::vector<std::vector<JxlGpuSqueezeStep>> steps;
     std::vector<int> final_loc;               // after the last inverse run
     int* d_flag = nullptr;
+    void* chk = nullptr;                      // segment link values of the squeeze step in flight
+    size_t chk_bytes = 0;
+    int* d_redo = nullptr;                    // lines redone serially (diagnostics)
     float* fpix[3] = {};
 };
 
@@ -427,10 +628,31 @@ int fail(jxlgpu_ctx* ctx, int code, const char* msg) {
 }
 
 template <typename S>
-void launch_squeeze(hipStream_t s, bool horizontal, const SqzArgs& a) {
+void launch_squeeze(hipStream_t s, bool horizontal, const SqzArgs& a, void* chk, size_t chk_bytes, int* redo_count) {
+    static const int seg_env = getenv("JXLGPU_SQZ_SEG") ? atoi(getenv("JXLGPU_SQZ_SEG")) : 128;  // pairs per segment
+    auto al = [](const void* p, uint32_t stride) { return ((uintptr_t)p % 16 == 0) && ((stride * sizeof(S)) % 16 == 0); };
+    const bool vec = al(a.avg, a.avg_stride) && al(a.res, a.res_stride) && al(a.out, a.out_stride);
+    const uint32_t len = horizontal ? a.width : a.height, lines = horizontal ? a.height : a.width;
+    const uint32_t pairs = len / 2;
+    // segment length: a multiple of the chunk (16 covers both directions and both sample types)
+    const uint32_t L = seg_env > 0 ? std::max(16u, (uint32_t)seg_env / 16u * 16u) : 0;
+    uint32_t nseg = L ? pairs / L : 0;
+    const bool segmented = nseg >= 2 && (!horizontal || vec) && chk &&
+                           (size_t)nseg * 2 * lines * sizeof(S) <= chk_bytes;
+    if (segmented) {
+        static const uint32_t runin = getenv("JXLGPU_SQZ_RUNIN") ? (uint32_t)atoi(getenv("JXLGPU_SQZ_RUNIN")) : 1u;
+        SegArgs g{a, L, nseg, chk, runin};
+        dim3 grid(ceil_div(lines, 64), nseg);
+        if (horizontal) {
+            squeeze_h_seg_kernel<S><<<grid, 64, 0, s>>>(g);
+            squeeze_check_kernel<S, true><<<ceil_div(lines, 64), 64, 0, s>>>(g, redo_count);
+        } else {
+            squeeze_v_seg_kernel<S><<<grid, 64, 0, s>>>(g);
+            squeeze_check_kernel<S, false><<<ceil_div(lines, 64), 64, 0, s>>>(g, redo_count);
+        }
+        return;
+    }
     if (horizontal) {
-        auto al = [](const void* p, uint32_t stride) { return ((uintptr_t)p % 16 == 0) && ((stride * sizeof(S)) % 16 == 0); };
-        const bool vec = al(a.avg, a.avg_stride) && al(a.res, a.res_stride) && al(a.out, a.out_stride);
         if (vec) squeeze_h_kernel<S, true><<<ceil_div(a.height, 64), 64, 0, s>>>(a);
         else squeeze_h_kernel<S, false><<<ceil_div(a.height, 64), 64, 0, s>>>(a);
     } else {
@@ -542,8 +764,8 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     a.out = ptr(g, out_loc, &a.out_stride);
                     a.width = g.w; a.height = g.h;
                     g.loc = out_loc;
-                    if (i16) launch_squeeze<int16_t>(s, st.horizontal, a);
-                    else launch_squeeze<int32_t>(s, st.horizontal, a);
+                    if (i16) launch_squeeze<int16_t>(s, st.horizontal, a, m->chk, m->chk_bytes, m->d_redo);
+                    else launch_squeeze<int32_t>(s, st.horizontal, a, m->chk, m->chk_bytes, m->d_redo);
                     if (getenv("JXLGPU_DEBUG_SYNC")) {
                         hipError_t e = hipStreamSynchronize(s);
                         fprintf(stderr, "squeeze %s ch%d %ux%u avg=%p(%u) res=%p(%u) out=%p(%u) -> %s\n", st.horizontal ? "H" : "V",
@@ -591,6 +813,13 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 l.insert(l.begin() + tr.begin_c + 1 + k, mg);
             }
         }
+    }
+    if (getenv("JXLGPU_DEBUG_SYNC")) {
+        int redo = 0;
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(&redo, m->d_redo, sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipMemset(m->d_redo, 0, sizeof(int));
+        fprintf(stderr, "[jxlgpu] squeeze lines redone serially in this run: %d\n", redo);
     }
     m->final_loc.assign(nch, 0);
     for (const Grid& g : l)
@@ -661,6 +890,17 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
     }
     int rc;
     if ((rc = malloc_dev(ctx, f, &m->d_flag, sizeof(int)))) return rc;
+    if ((rc = malloc_dev(ctx, f, &m->d_redo, sizeof(int)))) return rc;
+    HIP_TRY(ctx, hipMemset(m->d_redo, 0, sizeof(int)));
+    {   // 2 link values per segment per line; segments are >= 16 pairs, so len/16 bounds nseg
+        size_t worst = 0;
+        for (size_t c = 0; c < m->cw.size(); ++c) {
+            size_t w = m->cw[c], h = m->ch[c];
+            worst = std::max(worst, std::max((w / 32 + 1) * 2 * h, (h / 32 + 1) * 2 * w) * m->esz);
+        }
+        m->chk_bytes = worst;
+        if ((rc = malloc_dev(ctx, f, &m->chk, worst))) return rc;
+    }
 
     // geometry of the colour image for the float tail
     f->width = d->channels[0].width;

@@ -291,7 +291,10 @@ __device__ void transform_afv(Blk<S> c, int n, const SecLarge& sl) {
 template <int W, int H>
 struct VbCfg {
     static constexpr int BW = W / 8, BH = H / 8;
-    static constexpr int NB = (W * H >= 2048) ? 1 : 2048 / (W * H);
+#ifndef JXL_VB_TILE
+#define JXL_VB_TILE 2048
+#endif
+    static constexpr int NB = (W * H >= JXL_VB_TILE) ? 1 : JXL_VB_TILE / (W * H);
     static constexpr int S = W + 1;            // padded LDS row stride (words)
     static constexpr int BLK = H * S;          // words per block per channel
     static constexpr int CH = NB * BLK;        // words per channel
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(256) void transform_small_kernel(TransformArgs a, c
     }
 }
 
-constexpr int kSmallLdsWords = 3 * 2304 + 32;  // max over the classes above (VbCfg::LDS_WORDS)
+constexpr int kSmallLdsWords = VbCfg<8, 8>::LDS_WORDS > VbCfg<32, 32>::LDS_WORDS ? VbCfg<8, 8>::LDS_WORDS : VbCfg<32, 32>::LDS_WORDS;  // max over the classes above
 static_assert(VbCfg<8, 8>::LDS_WORDS <= kSmallLdsWords && VbCfg<16, 16>::LDS_WORDS <= kSmallLdsWords &&
               VbCfg<8, 16>::LDS_WORDS <= kSmallLdsWords && VbCfg<16, 8>::LDS_WORDS <= kSmallLdsWords &&
               VbCfg<32, 32>::LDS_WORDS <= kSmallLdsWords && VbCfg<8, 32>::LDS_WORDS <= kSmallLdsWords &&

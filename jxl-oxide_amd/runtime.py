@@ -7,6 +7,22 @@ import numpy as np
 from . import abi
 
 
+def prime_gpu(timeout=240):
+    """First GPU touch in a throw-away child process.  On a freshly provisioned box the very first
+    process that initialises the HIP runtime occasionally dies with "Memory access fault by GPU
+    node" before any kernel of ours has been launched (seen 3x in ~35 sessions, always the first
+    GPU process of a fresh box, never later ones); letting a disposable child take that hit keeps
+    tests / smoke / bench deterministic.  Returns True if the child ran clean."""
+    import subprocess
+    import sys
+    code = "import torch; torch.cuda.init(); x = torch.ones(64, device='cuda'); print(float(x.sum()))"
+    try:
+        r = subprocess.run([sys.executable, "-c", code], timeout=timeout, capture_output=True)
+        return r.returncode == 0
+    except Exception:
+        return False
+
+
 class JxlGpuError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"jxlgpu error {code}: {msg}")

@@ -24,6 +24,7 @@ def oracle():
 def gpu_ctx():
     """One jxlgpu context on device 0 through the C ABI.  Fails loudly without the HIP library."""
     from jxl_oxide_amd import runtime
+    runtime.prime_gpu()
     ctx = runtime.Context(0)
     yield ctx
     ctx.close()

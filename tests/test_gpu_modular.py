@@ -41,6 +41,18 @@ def test_squeeze_lossy_and_wrapping(gpu_ctx, oracle, i16):
     _inverse_both(gpu_ctx, oracle, ModularWorkload(130, 97, kind="raw", i16=i16, seed=5))
 
 
+@pytest.mark.parametrize("i16", [True, False])
+def test_segment_parallel_squeeze(gpu_ctx, oracle, i16):
+    """Rectangles long enough for the segment-parallel kernels (>= 2 segments of 128 pairs),
+    including random data whose guessed carries fail and take the serial fix-up path."""
+    wl = ModularWorkload(1100, 720, kind="squeeze", lossy=False, xyb=False, i16=i16, seed=11)
+    got = _inverse_both(gpu_ctx, oracle, wl)
+    for c in range(3):
+        assert np.array_equal(got[c], wl.expected[c])
+    _inverse_both(gpu_ctx, oracle, ModularWorkload(1100, 720, kind="squeeze", lossy=True, i16=i16, seed=12))
+    _inverse_both(gpu_ctx, oracle, ModularWorkload(1040, 530, kind="raw", i16=i16, seed=13))
+
+
 @pytest.mark.parametrize("rct_type", [0, 6, 10, 19, 23, 34, 36, 41])
 def test_rct_types(gpu_ctx, oracle, rct_type):
     wl = ModularWorkload(120, 90, kind="squeeze", lossy=False, xyb=False, rct_type=rct_type, seed=rct_type)
@@ -92,3 +104,36 @@ def test_render_rgb8_no_colour_transform(gpu_ctx, oracle):
         f.free()
     assert_ulp(got, exp, 0, "rgb8 -> float")
     assert np.array_equal(got[0], wl.expected[0].astype(np.float32) / np.float32(255))
+
+
+def test_squeeze_fixup_path(oracle):
+    """Without the run-in the guessed carries are usually wrong: the check kernel must catch every
+    broken link and redo those lines serially.  Runs in a child process (the switches are read once
+    per process)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+from jxl_oxide_amd import runtime
+from jxl_oxide_amd.synth_modular import ModularWorkload
+from oracle import pyoracle
+ctx = runtime.Context(0)
+for (w, h, kind, i16) in [(700, 520, "squeeze", True), (520, 700, "squeeze", False), (640, 400, "raw", True)]:
+    wl = ModularWorkload(w, h, kind=kind, lossy=True, i16=i16, seed=w)
+    d = wl.desc()
+    exp = pyoracle.modular_inverse(d, wl.shapes(), wl.dtype)
+    f = ctx.modular_upload(d)
+    got = ctx.modular_inverse(f, wl.shapes(), wl.dtype)
+    f.free()
+    assert all(np.array_equal(g, e) for g, e in zip(got, exp)), (w, h, kind)
+print("FIXUP_OK")
+'''
+    env = dict(os.environ, JXLGPU_SQZ_RUNIN="0", JXLGPU_SQZ_SEG="32", JXLGPU_DEBUG_SYNC="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert "FIXUP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    redone = [int(l.rsplit(":", 1)[1]) for l in r.stderr.splitlines() if "redone serially" in l]
+    assert sum(redone) > 0, "the test did not exercise the serial fix-up path"
