@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 4u
+#define JXLGPU_ABI_VERSION 5u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -215,6 +215,22 @@ const float* jxlgpu_frame_result_plane(const jxlgpu_frame* frame, uint32_t c);
 /* Intermediate buffers for stage-level parity tests: the LF image after V1-V3 (3 planes,
  * ceil(width/8) x ceil(height/8)).  Copies to host.                                                */
 int jxlgpu_frame_download_lf(jxlgpu_ctx* ctx, const jxlgpu_frame* frame, float* const planes[3]);
+
+/* ---- output formatting on the device (the step right after the path) ----
+ * `ImageStream::write_to_buffer` (jxl-oxide/src/fb.rs:309-397, sample conversion :436-527):
+ * planar f32 result of the last render -> interleaved, oriented, f32 / u16 / u8 samples
+ * (`(v * max + 0.5).clamp(0, max) as uN`).  Shrinks the D2H copy / the multi-GPU gather 4x for u8. */
+#define JXLGPU_FMT_F32 0u
+#define JXLGPU_FMT_U16 1u
+#define JXLGPU_FMT_U8 2u
+typedef struct {
+    uint32_t sample_format;   /* JXLGPU_FMT_*                                                     */
+    uint32_t orientation;     /* ImageMetadata.orientation, 1..8 (EXIF numbering)                 */
+} JxlGpuFormatDesc;
+/* Writes out_w*out_h*3 samples (out_w/out_h swap for orientations 5..8) to `out` (host memory when
+ * out_mem == JXLGPU_MEM_HOST, else a device pointer).  Needs a completed render on `frame`.       */
+int jxlgpu_frame_format_output(jxlgpu_ctx* ctx, jxlgpu_frame* frame, const JxlGpuFormatDesc* fmt,
+                               void* out, uint32_t out_mem, uint32_t* out_w, uint32_t* out_h);
 
 /* Bytes the algorithm must move per render for the given stages (compulsory HBM traffic:
  * coefficient read + final write + side data), used by bench.py for the roofline.                 */

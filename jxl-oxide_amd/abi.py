@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -32,6 +32,8 @@ STAGE_COLOR = 0x20
 STAGE_ALL = 0x3F
 STAGE_MODULAR_INVERSE = 0x02
 STAGE_MODULAR_TO_FLOAT = 0x40
+
+FMT_F32, FMT_U16, FMT_U8 = 0, 1, 2
 
 MEM_HOST = 0
 MEM_DEVICE = 1
@@ -147,6 +149,10 @@ class Out(C.Structure):
     _fields_ = [("planes", f32p * 3), ("stride", C.c_uint32), ("mem", C.c_uint32)]
 
 
+class FormatDesc(C.Structure):
+    _fields_ = [("sample_format", C.c_uint32), ("orientation", C.c_uint32)]
+
+
 class SqueezeStep(C.Structure):
     _fields_ = [("horizontal", C.c_uint32), ("in_place", C.c_uint32),
                 ("begin_c", C.c_uint32), ("num_c", C.c_uint32)]
@@ -211,6 +217,8 @@ _SYMBOLS = [
     ("jxlgpu_frame_out_size", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("jxlgpu_frame_result_plane", f32p, [C.c_void_p, C.c_uint32]),
     ("jxlgpu_frame_download_lf", C.c_int, [C.c_void_p, C.c_void_p, f32p * 3]),
+    ("jxlgpu_frame_format_output", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(FormatDesc), C.c_void_p, C.c_uint32,
+                                             C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("jxlgpu_frame_algorithmic_bytes", C.c_uint64, [C.c_void_p, C.c_uint32]),
     ("jxlgpu_modular_upload", C.c_int, [C.c_void_p, C.POINTER(ModularDesc), C.POINTER(C.c_void_p)]),
     ("jxlgpu_modular_inverse", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <string>
 #include <vector>
@@ -176,6 +177,8 @@ struct jxlgpu_frame {
     float kx_lf = 0, kb_lf = 0;
     float lf_div[3] = {};
     ColorArgs color = {};
+    void* fmt_buf = nullptr;             // device staging for jxlgpu_frame_format_output
+    size_t fmt_bytes = 0;
     uint32_t* ring_tiles = nullptr;      // outer ring of 32x32 tiles for the fused tile kernel
     uint32_t n_ring_tiles = 0;
     float* up_weights[3] = {};  // expanded 5x5 kernels per phase for 2x/4x/8x

@@ -1,0 +1,100 @@
+// Output formatting on the device: planar f32 render result -> interleaved, oriented
+// f32 / u16 / u8 samples (ImageStream::write_to_buffer, jxl-oxide/src/fb.rs:309-397; sample
+// conversion fb.rs:487-490, 524-527: `(v * max + 0.5).clamp(0, max) as uN`).  One lane per output
+// pixel (3 samples); the oriented read goes through L2, the interleaved write is contiguous.
+#include "common.h"
+
+namespace {
+
+struct FormatArgs {
+    const float* in[3];
+    void* out;
+    uint32_t in_stride, ow, oh, orientation;
+};
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <int FMT>
+__global__ __launch_bounds__(256) void format_kernel(FormatArgs a) {
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= a.ow) return;
+    uint32_t ox, oy;  // to_original_coord, fb.rs:383-397
+    switch (a.orientation) {
+        case 1: ox = x; oy = y; break;
+        case 2: ox = a.ow - x - 1; oy = y; break;
+        case 3: ox = a.ow - x - 1; oy = a.oh - y - 1; break;
+        case 4: ox = x; oy = a.oh - y - 1; break;
+        case 5: ox = y; oy = x; break;
+        case 6: ox = y; oy = a.ow - x - 1; break;
+        case 7: ox = a.oh - y - 1; oy = a.ow - x - 1; break;
+        default: ox = a.oh - y - 1; oy = x; break;
+    }
+    const size_t gi = (size_t)oy * a.in_stride + ox;
+    const size_t o = ((size_t)y * a.ow + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = a.in[c][gi];
+        if (FMT == JXLGPU_FMT_F32) {
+            ((float*)a.out)[o + c] = v;
+        } else if (FMT == JXLGPU_FMT_U16) {
+            float t = clampf(v * 65535.0f + 0.5f, 0.0f, 65535.0f);
+            ((uint16_t*)a.out)[o + c] = t != t ? (uint16_t)0 : (uint16_t)t;   // Rust `as u16`: NaN -> 0, truncation
+        } else {
+            float t = clampf(v * 255.0f + 0.5f, 0.0f, 255.0f);
+            ((uint8_t*)a.out)[o + c] = t != t ? (uint8_t)0 : (uint8_t)t;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int jxlgpu_frame_format_output(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuFormatDesc* fmt, void* out,
+                                          uint32_t out_mem, uint32_t* out_w, uint32_t* out_h) {
+    if (!ctx || !f || !fmt || !out) return JXLGPU_ERR_INVALID_ARG;
+    if (fmt->orientation < 1 || fmt->orientation > 8 || fmt->sample_format > JXLGPU_FMT_U8) {
+        ctx->last_error = "bad orientation / sample format";
+        return JXLGPU_ERR_INVALID_ARG;
+    }
+    if (!f->result[0]) {
+        ctx->last_error = "format_output needs a completed render on this frame";
+        return JXLGPU_ERR_INVALID_ARG;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t w = f->result_w, h = f->result_h;
+    const uint32_t ow = fmt->orientation <= 4 ? w : h, oh = fmt->orientation <= 4 ? h : w;
+    const size_t esz = fmt->sample_format == JXLGPU_FMT_F32 ? 4 : fmt->sample_format == JXLGPU_FMT_U16 ? 2 : 1;
+    const size_t bytes = (size_t)ow * oh * 3 * esz;
+    void* dst = out;
+    if (out_mem != JXLGPU_MEM_DEVICE) {
+        if (f->fmt_bytes < bytes) {
+            void* p = nullptr;
+            HIP_TRY(ctx, hipMalloc(&p, bytes));
+            f->allocs.push_back(p);
+            f->fmt_buf = p;
+            f->fmt_bytes = bytes;
+        }
+        dst = f->fmt_buf;
+    }
+    FormatArgs a;
+    for (int c = 0; c < 3; ++c) a.in[c] = f->result[c];
+    a.out = dst; a.in_stride = f->result_stride; a.ow = ow; a.oh = oh; a.orientation = fmt->orientation;
+    dim3 grid(ceil_div(ow, 256), oh);
+    if (fmt->sample_format == JXLGPU_FMT_F32) format_kernel<JXLGPU_FMT_F32><<<grid, 256, 0, ctx->stream>>>(a);
+    else if (fmt->sample_format == JXLGPU_FMT_U16) format_kernel<JXLGPU_FMT_U16><<<grid, 256, 0, ctx->stream>>>(a);
+    else format_kernel<JXLGPU_FMT_U8><<<grid, 256, 0, ctx->stream>>>(a);
+    HIP_TRY(ctx, hipGetLastError());
+    if (out_mem != JXLGPU_MEM_DEVICE) {
+        if (ctx->pinned_size < bytes) {
+            if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+            ctx->pinned = nullptr; ctx->pinned_size = 0;
+            HIP_TRY(ctx, hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
+            ctx->pinned_size = bytes;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, dst, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(out, ctx->pinned, bytes);
+    }
+    if (out_w) *out_w = ow;
+    if (out_h) *out_h = oh;
+    return JXLGPU_OK;
+}

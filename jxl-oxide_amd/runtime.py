@@ -115,6 +115,19 @@ class Context:
         self._check(self.lib.jxlgpu_vardct_render_host(self.handle, C.byref(desc), stages, C.byref(o)))
         return out
 
+    def format_output(self, frame, sample_format, orientation=1):
+        """Interleaved, oriented f32/u16/u8 image of the last render (formatted on the device)."""
+        w, h = frame.out_size(abi.STAGE_ALL)
+        ow, oh = (w, h) if orientation <= 4 else (h, w)
+        dt = {abi.FMT_F32: np.float32, abi.FMT_U16: np.uint16, abi.FMT_U8: np.uint8}[sample_format]
+        out = np.zeros((oh, ow, 3), dtype=dt)
+        fmt = abi.FormatDesc(sample_format, orientation)
+        rw, rh = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.jxlgpu_frame_format_output(self.handle, frame.handle, C.byref(fmt), out.ctypes.data,
+                                                        abi.MEM_HOST, C.byref(rw), C.byref(rh)))
+        assert (rw.value, rh.value) == (ow, oh)
+        return out
+
     def download_lf(self, frame, w8, h8):
         lf = np.zeros((3, h8, w8), dtype=np.float32)
         arr = (abi.f32p * 3)(*[lf[c].ctypes.data_as(abi.f32p) for c in range(3)])

@@ -53,6 +53,10 @@ void orc_epf_step(int step, const float* const in[3], size_t in_stride, float* c
 void orc_upsample_inner(const float* in, size_t in_stride, size_t w, size_t h, float* out,
                         size_t out_stride, int k, const float* weights);
 
+/* ---- format.c ---- */
+int orc_format_output(const float* const planes[3], size_t stride, uint32_t width, uint32_t height,
+                      uint32_t sample_format, uint32_t orientation, void* out);
+
 /* ---- color.c ---- */
 void orc_color_transform(float* const ch[3], size_t n, const JxlGpuColorParams* cp);
 

@@ -39,6 +39,8 @@ def lib():
         _lib.orc_gabor_plane.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
         _lib.orc_upsample_inner.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p, C.c_size_t, C.c_int, f32p]
         _lib.orc_color_transform.argtypes = [f32p * 3, C.c_size_t, C.c_void_p]
+        _lib.orc_format_output.restype = C.c_int
+        _lib.orc_format_output.argtypes = [f32p * 3, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         _lib.jxl_oracle_modular_inverse.restype = C.c_int
         _lib.jxl_oracle_modular_inverse.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         _lib.jxl_oracle_modular_render.restype = C.c_int
@@ -103,4 +105,18 @@ def modular_render(desc, stages, out_w, out_h):
     rc = lib().jxl_oracle_modular_render(C.byref(desc), stages, outp, out_w)
     if rc != 0:
         raise RuntimeError(f"oracle modular_render failed: {rc}")
+    return out
+
+
+def format_output(planes, sample_format, orientation):
+    """planes: (3, h, w) float32 -> (oh, ow, 3) interleaved array of f32 / u16 / u8."""
+    planes = np.ascontiguousarray(planes, dtype=np.float32)
+    _, h, w = planes.shape
+    ow, oh = (w, h) if orientation <= 4 else (h, w)
+    dt = {0: np.float32, 1: np.uint16, 2: np.uint8}[sample_format]
+    out = np.zeros((oh, ow, 3), dtype=dt)
+    arr = (f32p * 3)(*[_p(planes[c]) for c in range(3)])
+    rc = lib().orc_format_output(arr, w, w, h, sample_format, orientation, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle format_output failed: {rc}")
     return out

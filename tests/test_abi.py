@@ -36,7 +36,7 @@ def test_struct_sizes_match_the_compiler():
 #include <stdio.h>
 #include "jxlgpu.h"
 int main(void) {
-    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(JxlGpuFilterParams), sizeof(JxlGpuColorParams),
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(JxlGpuFormatDesc), sizeof(JxlGpuFilterParams), sizeof(JxlGpuColorParams),
            sizeof(JxlGpuUpsampling), sizeof(JxlGpuLfGroup), sizeof(JxlGpuVardctDesc), sizeof(JxlGpuOut),
            sizeof(JxlGpuSqueezeStep), sizeof(JxlGpuTransform), sizeof(JxlGpuModularChannel), sizeof(JxlGpuModularDesc));
     return 0;
@@ -47,7 +47,7 @@ int main(void) {
         exe = os.path.join(td, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), cfile, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
-    mirror = [abi.FilterParams, abi.ColorParams, abi.Upsampling, abi.LfGroup, abi.VardctDesc, abi.Out,
+    mirror = [abi.FormatDesc, abi.FilterParams, abi.ColorParams, abi.Upsampling, abi.LfGroup, abi.VardctDesc, abi.Out,
               abi.SqueezeStep, abi.Transform, abi.ModularChannel, abi.ModularDesc]
     assert sizes == [C.sizeof(m) for m in mirror]
 
