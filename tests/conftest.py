@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the oracle opens many tiny OpenMP regions; on a 256-thread host the fork/join cost dominates
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
