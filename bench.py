@@ -135,11 +135,23 @@ def main():
         else:
             alg_bytes = npx * 24 + ncell * 4
             kname = "post_stream_kernel<sRGB> (+ fused_post_kernel<true,2> border ring): Gabor + EPF steps 1,2 + XYB->sRGB"
+        traffic = None
+        try:  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/README.md)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_4k.json")))["kernels"]
+            if dominant == 2 and args.width == W4K and args.height == H4K:
+                kb = 0.0
+                for name, v in pmc.items():
+                    if "post_stream_kernel" in name or "fused_post_kernel" in name:
+                        # gfx950: FETCH_SIZE counts half of wide coalesced reads (MI355X_MICROARCH.md)
+                        kb += 2.0 * v["FETCH_SIZE_KB_mean_per_dispatch"] + v["WRITE_SIZE_KB_mean_per_dispatch"]
+                traffic = int(kb * 1024)
+        except Exception:
+            traffic = None
         avg_ms = prof_ms / max(prof_n, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "kernel": kname, "avg_launch_ms": round(avg_ms, 4), "launches": int(prof_n),
             "isolated_launch_ms": round(group_ms.get(dominant, 0.0), 4),
             "frac_isolated": round(alg_bytes / (group_ms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if group_ms.get(dominant) else None,
@@ -193,8 +205,11 @@ def cpu_baseline(wl, stages, seconds, mp_per_frame):
     reference's rayon decomposition) on this box's host cores, on whole frames of the same
     workload until ~`seconds` of wall time have been spent."""
     from oracle import pyoracle
-    cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    # The box exposes 256 hardware threads but the oracle scales only to ~16 of them (measured on
+    # the GPU box: 16 thr 57.8, 32 thr 41.5, 64 thr 27.7, 256 thr 2.3 MP/s): it opens one small OpenMP
+    # region per stage per frame, mirroring the reference's rayon work units.  Use what helps.
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("JXL_CPU_BASELINE_THREADS", "16")))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     import numpy as np
     d = wl.desc()
     buf = np.zeros((3, wl.height, wl.width), dtype=np.float32)
