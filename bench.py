@@ -209,7 +209,7 @@ def cpu_baseline(wl, stages, seconds, mp_per_frame):
     # the GPU box: 16 thr 57.8, 32 thr 41.5, 64 thr 27.7, 256 thr 2.3 MP/s): it opens one small OpenMP
     # region per stage per frame, mirroring the reference's rayon work units.  Use what helps.
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("JXL_CPU_BASELINE_THREADS", "16")))
-    os.environ["OMP_NUM_THREADS"] = str(cores)
+    cores = pyoracle.set_threads(cores)  # the env var is too late: torch already loaded an OpenMP runtime
     import numpy as np
     d = wl.desc()
     buf = np.zeros((3, wl.height, wl.width), dtype=np.float32)

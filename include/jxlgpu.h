@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 5u
+#define JXLGPU_ABI_VERSION 6u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -79,21 +79,36 @@ typedef struct {
 #define JXLGPU_TF_PQ 2u
 #define JXLGPU_TF_BT709 3u
 #define JXLGPU_TF_GAMMA 4u
-#define JXLGPU_TF_HLG 5u
+#define JXLGPU_TF_HLG 5u   /* rejected with JXLGPU_ERR_UNSUPPORTED: tf.rs:101-160 uses libm powf/ln   */
+/* JxlGpuColorParams.gamut_map: what sits between the two Matrix ops (convert.rs:398-414) */
+#define JXLGPU_GAMUT_NONE 0u
+#define JXLGPU_GAMUT_MAP 1u  /* ColorTransformOp::GamutMap (perceptual intent)                     */
+#define JXLGPU_GAMUT_CLIP 2u /* ColorTransformOp::Clip (other intents)                             */
 typedef struct {
     uint32_t enabled;          /* 0: leave XYB (save_before_ct / stage tests)                   */
     float opsin_bias[3];       /* OpsinInverseMatrix.opsin_bias, jxl-image/src/color.rs:620      */
     float intensity_target;    /* ToneMapping.intensity_target                                  */
     float matrix[9];           /* merged Matrix op after XybToMixedLms (convert.rs:661-690):     */
                                /* opsin inv_mat, or  target_primaries * inv_mat                  */
-    uint32_t gamut_map;        /* insert GamutMap{luminances, saturation_factor} before matrix2  */
+    uint32_t gamut_map;        /* JXLGPU_GAMUT_*: GamutMap{luminances, saturation_factor} or Clip   */
+                               /* before matrix2                                                 */
     float gamut_luminances[3];
     float gamut_saturation_factor;
     uint32_t has_matrix2;      /* second Matrix op (after GamutMap)                              */
     float matrix2[9];
     uint32_t transfer_function;/* JXLGPU_TF_*                                                    */
-    float gamma;               /* for JXLGPU_TF_GAMMA                                            */
-    float hlg_luminances[3];   /* for JXLGPU_TF_HLG inverse OOTF                                 */
+    float gamma;               /* for JXLGPU_TF_GAMMA: the exponent apply_gamma receives         */
+                               /* (convert.rs:979-1020: 1e7/g, g/1e7, or 1/2.6 for DCI)          */
+    float hlg_luminances[3];   /* for JXLGPU_TF_HLG inverse OOTF (unsupported, see above)         */
+    /* ToneMapRec2408 { hdr_params, target_display_luminance, detect_peak: false } and the
+     * GamutMap that follows it for perceptual intent (convert.rs:478-500), between matrix2 and the
+     * transfer function.  detect_peak = true (a whole-image reduction) is not offered.            */
+    uint32_t tone_map;
+    float tm_luminances[3];    /* HdrParams.luminances (row Y of primaries_to_xyz_mat)            */
+    float tm_min_nits;         /* HdrParams.min_nits                                              */
+    float tm_target_display_luminance; /* 255.0 (SDR target) or 1000.0 (PQ -> HLG)                */
+    uint32_t tm_gamut_map;     /* GamutMap{luminances = tm_luminances, saturation_factor}         */
+    float tm_gamut_saturation_factor;
 } JxlGpuColorParams;
 
 /* ---- non-separable upsampling (jxl-render/src/features/upsampling.rs) ---- */

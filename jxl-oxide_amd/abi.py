@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -22,6 +22,7 @@ SAMPLE_I32 = 0
 SAMPLE_I16 = 1
 
 TF_LINEAR, TF_SRGB, TF_PQ, TF_BT709, TF_GAMMA, TF_HLG = range(6)
+GAMUT_NONE, GAMUT_MAP, GAMUT_CLIP = range(3)
 
 STAGE_LF = 0x01
 STAGE_TRANSFORM = 0x02
@@ -85,6 +86,12 @@ class ColorParams(C.Structure):
         ("transfer_function", C.c_uint32),
         ("gamma", C.c_float),
         ("hlg_luminances", C.c_float * 3),
+        ("tone_map", C.c_uint32),
+        ("tm_luminances", C.c_float * 3),
+        ("tm_min_nits", C.c_float),
+        ("tm_target_display_luminance", C.c_float),
+        ("tm_gamut_map", C.c_uint32),
+        ("tm_gamut_saturation_factor", C.c_float),
     ]
 
 

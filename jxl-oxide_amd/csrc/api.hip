@@ -10,6 +10,7 @@
 #include <new>
 
 #include "common.h"
+#include "pixel_device.h"  // linear_to_pq_dev (host+device) for the tone-map constants
 
 void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
                        float* const out[3], uint32_t out_stride, bool gabor, int epf_iters, bool color,
@@ -102,6 +103,26 @@ void fill_color_args(const JxlGpuColorParams& cp, ColorArgs* c) {
     c->gamut_sat = cp.gamut_saturation_factor;
     c->has_matrix2 = cp.has_matrix2;
     c->tf = cp.transfer_function;
+    c->gamma = cp.gamma;
+    c->tone_map = cp.tone_map;
+    if (cp.tone_map) {
+        // convert/tone_map.rs:19-31 (detect_peak = false) and tf/rec2408.rs:10-29: evaluated once
+        // per frame on the host with the same f32 operations (linear_to_pq_dev is host+device).
+        const float it = cp.intensity_target;
+        const float peak = fminf(it, it);
+        float lum[4] = {cp.tm_min_nits / it, peak / it, 0.0f / it, cp.tm_target_display_luminance / it};
+        for (float& y : lum) y = linear_to_pq_dev(y, it);
+        c->tm_lum0_pq = lum[0];
+        c->tm_source_pq_diff = lum[1] - lum[0];
+        c->tm_min_luminance = (lum[2] - lum[0]) / c->tm_source_pq_diff;
+        c->tm_max_luminance = (lum[3] - lum[0]) / c->tm_source_pq_diff;
+        c->tm_ks = 1.5f * c->tm_max_luminance - 0.5f;
+        c->tm_one_sub_ks = 1.0f - c->tm_ks;
+        c->tm_scale = it / cp.tm_target_display_luminance;
+        for (int i = 0; i < 3; ++i) c->tm_lum[i] = cp.tm_luminances[i];
+        c->tm_gamut_map = cp.tm_gamut_map;
+        c->tm_gamut_sat = cp.tm_gamut_saturation_factor;
+    }
 }
 
 // upsample_inner's weights_quarter (features/upsampling.rs:77-93)
@@ -124,6 +145,16 @@ std::vector<float> expand_up_weights(const float* weights, int k) {
 }  // namespace
 
 void fill_color_args_public(const JxlGpuColorParams& cp, ColorArgs* c) { fill_color_args(cp, c); }
+
+// nullptr if the colour op list can run on the device, else why not
+const char* color_params_unsupported(const JxlGpuColorParams& cp) {
+    if (!cp.enabled) return nullptr;
+    if (cp.transfer_function == JXLGPU_TF_HLG)
+        return "HLG transfer function (libm powf/ln in the reference, not bit-reproducible) stays on the CPU path";
+    if (cp.transfer_function > JXLGPU_TF_HLG) return "unknown transfer function";
+    if (cp.gamut_map > JXLGPU_GAMUT_CLIP) return "unknown gamut_map mode";
+    return nullptr;
+}
 
 int upload_post_params(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuUpsampling& up) {
     const float* src[3] = {up.up2_weight, up.up4_weight, up.up8_weight};
@@ -224,6 +255,7 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
     if (d->jpeg_upsampling[0] | d->jpeg_upsampling[1] | d->jpeg_upsampling[2])
         return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "chroma-subsampled (jpeg_upsampling != 0) frames stay on the CPU path");
     if (d->group_dim != 256) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "only group_dim == 256 is supported");
+    if (const char* why = color_params_unsupported(d->color)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, why);
     if (d->width == 0 || d->height == 0 || d->width > (1u << 18) || d->height > (1u << 18))
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "bad frame size");
     if (d->global_scale == 0 || d->quant_lf == 0 || d->colour_factor == 0)

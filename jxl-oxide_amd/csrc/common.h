@@ -96,6 +96,13 @@ struct ColorArgs {
     uint32_t has_matrix2;
     float matrix2[9];
     uint32_t tf;
+    float gamma;
+    // ToneMapRec2408 (detect_peak = false): constants of rec2408_eetf_generic steps 1-2
+    uint32_t tone_map;
+    float tm_lum[3];
+    float tm_lum0_pq, tm_source_pq_diff, tm_min_luminance, tm_max_luminance, tm_ks, tm_one_sub_ks, tm_scale;
+    uint32_t tm_gamut_map;
+    float tm_gamut_sat;
 };
 
 // Kernel groups that can be bracketed with HIP events (jxlgpu_profile_*).

@@ -28,6 +28,7 @@ int finish_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stri
                   const JxlGpuOut* out);
 int upload_post_params(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuUpsampling& up);
 void fill_color_args_public(const JxlGpuColorParams& cp, ColorArgs* c);
+const char* color_params_unsupported(const JxlGpuColorParams& cp);
 
 namespace {
 
@@ -839,6 +840,8 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
     if (d->num_channels == 0 || !d->channels) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "no channels");
     if (d->residual_predictor != 0xFFFFFFFFu && d->residual_predictor != 5)
         return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "only Gradient (5) residuals are separable on the device; others stay with the entropy decoder");
+    if (d->xyb_encoded)
+        if (const char* why = color_params_unsupported(d->color)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, why);
     if (d->residual_predictor == 5 && d->group_dim > 256) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "gradient tiles larger than 256");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     jxlgpu_frame* f = new (std::nothrow) jxlgpu_frame();

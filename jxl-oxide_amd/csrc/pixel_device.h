@@ -149,7 +149,7 @@ __device__ __forceinline__ float linear_to_srgb_dev(float s) {
     return copysignf(vf <= 0.0031308f ? small : acc, s);
 }
 
-__device__ __forceinline__ float rational_poly5_dev(float x, const float (&p)[5], const float (&q)[5]) {
+__host__ __device__ __forceinline__ float rational_poly5_dev(float x, const float (&p)[5], const float (&q)[5]) {
     // jxl-color/src/fastmath/rational_poly.rs:2-6
     float yp = p[4], yq = q[4];
 #pragma unroll
@@ -159,7 +159,7 @@ __device__ __forceinline__ float rational_poly5_dev(float x, const float (&p)[5]
     return yp / yq;
 }
 
-__device__ __forceinline__ float linear_to_pq_dev(float s, float intensity_target) {
+__host__ __device__ __forceinline__ float linear_to_pq_dev(float s, float intensity_target) {
     // jxl-color/src/tf/pq.rs:127-142, tables :26-35
     const float P[5] = {1.351392e-2f, -1.095778f, 5.522776e1f, 1.492516e2f, 4.838434e1f};
     const float Q[5] = {1.012416f, 2.016708e1f, 9.26371e1f, 1.120607e2f, 2.590418e1f};
@@ -171,6 +171,95 @@ __device__ __forceinline__ float linear_to_pq_dev(float s, float intensity_targe
     float a_1_4 = sqrtf(sqrtf(a_scaled));
     float y = a < 1e-4f ? rational_poly5_dev(a_1_4, PS, QS) : rational_poly5_dev(a_1_4, P, Q);
     return copysignf(y, s);
+}
+
+__device__ __forceinline__ float pq_to_linear_dev(float s, float intensity_target) {
+    // jxl-color/src/tf/pq.rs:336-343, tables :10-23
+    const float P[5] = {2.6297566e-4f, -6.235531e-3f, 7.386023e-1f, 2.6455317f, 5.500349e-1f};
+    const float Q[5] = {4.213501e2f, -4.2873682e2f, 1.7436467e2f, -3.3907887e1f, 2.6771877f};
+    float y_mult = 10000.0f / intensity_target;
+    float a = fabsf(s);
+    float x = __builtin_fmaf(a, a, a);
+    float y = rational_poly5_dev(x, P, Q);
+    return copysignf(y * y_mult, s);
+}
+
+// fast_pow2f_generic, jxl-color/src/fastmath/powf.rs:6-24.  `x_floor as i32` saturates in Rust;
+// v_cvt_i32_f32 saturates too (and maps NaN to 0).
+__device__ __forceinline__ float fast_pow2f_dev(float x) {
+    float x_floor = floorf(x);
+    float e = __uint_as_float(((uint32_t)(int32_t)x_floor + 127u) << 23);
+    float frac = x - x_floor;
+    float num = frac + 1.01749063e1f;
+    num = num * frac + 4.88687798e1f;
+    num = num * frac + 9.85506591e1f;
+    num = num * e;
+    float den = 2.10242958e-1f * frac + -2.22328856e-2f;
+    den = den * frac + -1.94414990e1f;
+    den = den * frac + 9.85506633e1f;
+    return num / den;
+}
+
+// fast_log2f_generic, powf.rs:146-156 (tables :134-144)
+__device__ __forceinline__ float fast_log2f_dev(float x) {
+    uint32_t x_bits = __float_as_uint(x);
+    int32_t exp_bits = (int32_t)(x_bits - 0x3f2aaaabu);
+    int32_t exp_shifted = exp_bits >> 23;
+    float mantissa = __uint_as_float(x_bits - ((uint32_t)exp_shifted << 23));
+    float exp_val = (float)exp_shifted;
+    float m = mantissa - 1.0f;
+    float yp = 7.4245873327820566e-1f;
+    yp = yp * m + 1.4287160470083755f;
+    yp = yp * m + -1.8503833400518310e-6f;
+    float yq = 1.7409343003366853e-1f;
+    yq = yq * m + 1.0096718572241148f;
+    yq = yq * m + 9.9032814277590719e-1f;
+    return yp / yq + exp_val;
+}
+
+__device__ __forceinline__ float fast_powf_dev(float base, float e) {  // powf.rs:242-244
+    return fast_pow2f_dev(fast_log2f_dev(base) * e);
+}
+
+__device__ __forceinline__ float linear_to_bt709_dev(float a) {  // tf/bt709.rs:60-68
+    return a <= 0.018f ? 4.5f * a : __builtin_fmaf(fast_powf_dev(a, 0.45f), 1.099f, -0.099f);
+}
+
+__device__ __forceinline__ float apply_gamma_dev(float a, float gamma) {  // tf.rs:60-68
+    return a <= 1e-7f ? 0.0f : fast_powf_dev(a, gamma);
+}
+
+__device__ __forceinline__ float clamp01_dev(float v) {  // f32::clamp(0,1), convert.rs:951
+    v = v < 0.0f ? 0.0f : v;
+    return v > 1.0f ? 1.0f : v;
+}
+
+// tone_map_generic (convert/tone_map.rs:179-211) with rec2408_eetf_generic (tf/rec2408.rs:4-56);
+// the per-frame constants of the EETF (steps 1-2) come precomputed from the host
+// (fill_color_args), evaluated with the same f32 operations in the same order.
+__device__ __forceinline__ void tone_map_dev(const ColorArgs& cp, float (&v)[3]) {
+    float y = v[0] * cp.tm_lum[0] + v[1] * cp.tm_lum[1] + v[2] * cp.tm_lum[2];
+    float y_pq = linear_to_pq_dev(y, cp.intensity_target);
+    float normalized = (y_pq - cp.tm_lum0_pq) / cp.tm_source_pq_diff;
+    float compressed;
+    if (normalized < cp.tm_ks) {
+        compressed = normalized;
+    } else {
+        float t = (normalized - cp.tm_ks) / cp.tm_one_sub_ks;
+        float t_p2 = t * t;
+        float t_p3 = t_p2 * t;
+        compressed = (2.0f * t_p3 - 3.0f * t_p2 + 1.0f) * cp.tm_ks + (t_p3 - 2.0f * t_p2 + t) * cp.tm_one_sub_ks +
+                     (-2.0f * t_p3 + 3.0f * t_p2) * cp.tm_max_luminance;
+    }
+    float x = 1.0f - compressed;
+    float p4 = x * x * x * x;
+    float normalized_target = p4 * cp.tm_min_luminance + compressed;
+    float y_mapped = normalized_target * cp.tm_source_pq_diff + cp.tm_lum0_pq;
+    y_mapped = pq_to_linear_dev(y_mapped, cp.intensity_target);
+    float ratio = fabsf(y) <= 1e-7f ? y_mapped * cp.tm_scale : y_mapped / y * cp.tm_scale;
+    v[0] *= ratio;
+    v[1] *= ratio;
+    v[2] *= ratio;
 }
 
 __device__ __forceinline__ void map_gamut_dev(float (&rgb)[3], const float (&lum)[3], float saturation_factor) {
@@ -221,9 +310,24 @@ __device__ __forceinline__ void color_pixel(const ColorArgs& cp, float (&v)[3]) 
     v[1] = __builtin_fmaf(g_m * g_m, g_m, cp.opsin_bias[1]) * cp.itscale;
     v[2] = __builtin_fmaf(g_s * g_s, g_s, cp.opsin_bias[2]) * cp.itscale;
     matmul3vec_dev(cp.matrix, v);
-    if (cp.gamut_map) map_gamut_dev(v, cp.gamut_lum, cp.gamut_sat);
+    if (cp.gamut_map == JXLGPU_GAMUT_MAP) {
+        map_gamut_dev(v, cp.gamut_lum, cp.gamut_sat);
+    } else if (cp.gamut_map == JXLGPU_GAMUT_CLIP) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = clamp01_dev(v[c]);
+    }
     if (cp.has_matrix2) matmul3vec_dev(cp.matrix2, v);
-    if (cp.tf == JXLGPU_TF_SRGB) {
+    if (cp.tone_map) {
+        tone_map_dev(cp, v);
+        if (cp.tm_gamut_map) map_gamut_dev(v, cp.tm_lum, cp.tm_gamut_sat);
+    }
+    if (cp.tf == JXLGPU_TF_BT709) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = linear_to_bt709_dev(v[c]);
+    } else if (cp.tf == JXLGPU_TF_GAMMA) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = apply_gamma_dev(v[c], cp.gamma);
+    } else if (cp.tf == JXLGPU_TF_SRGB) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = linear_to_srgb_dev(v[c]);
     } else if (cp.tf == JXLGPU_TF_PQ) {

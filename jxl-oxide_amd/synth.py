@@ -106,12 +106,59 @@ def draw_tiling(rng, w8, h8, mix=_MIX, types=None, group_cells=32):
     return kind, hf_mul
 
 
+SRGB_LUMINANCES = [0.2126, 0.7152, 0.0722]
+# linear sRGB -> Display P3 (D65), the merged `primaries_to_xyz * xyz_to_primaries` Matrix op
+SRGB_TO_P3 = [0.8224621, 0.1775380, 0.0000000,
+              0.0331941, 0.9668058, 0.0000000,
+              0.0170827, 0.0723974, 0.9105199]
+
+
+def configure_color(cp, mode):
+    """Op lists `ColorTransform::new` builds for a few XYB -> target encodings besides the sRGB
+    and PQ ones (jxl-color/src/convert.rs:208-549).  `cp` already holds XybToMixedLms + Matrix."""
+    if mode == "tone_map_srgb":
+        # HDR image (intensity_target > 255) shown on an SDR sRGB target, perceptual intent:
+        # ToneMapRec2408{target 255} -> GamutMap{0.3} -> sRGB  (convert.rs:478-500)
+        assert cp.intensity_target > 255.0
+        cp.tone_map = 1
+        cp.tm_luminances[:] = SRGB_LUMINANCES
+        cp.tm_min_nits = 0.0
+        cp.tm_target_display_luminance = 255.0
+        cp.tm_gamut_map = 1
+        cp.tm_gamut_saturation_factor = 0.3
+        cp.transfer_function = abi.TF_SRGB
+    elif mode == "tone_map_min_nits":
+        # same, relative intent (no GamutMap after the tone map), non-zero black level, linear out
+        assert cp.intensity_target > 255.0
+        cp.tone_map = 1
+        cp.tm_luminances[:] = SRGB_LUMINANCES
+        cp.tm_min_nits = 0.05
+        cp.tm_target_display_luminance = 255.0
+        cp.tm_gamut_map = 0
+        cp.transfer_function = abi.TF_LINEAR
+    elif mode == "bt709":
+        cp.transfer_function = abi.TF_BT709
+    elif mode == "clip_p3_dci":
+        # relative intent to Display P3 primaries with the DCI gamma: Clip -> Matrix -> Gamma(1/2.6)
+        cp.gamut_map = abi.GAMUT_CLIP
+        cp.has_matrix2 = 1
+        cp.matrix2[:] = SRGB_TO_P3
+        cp.transfer_function = abi.TF_GAMMA
+        cp.gamma = float(np.float32(1.0) / np.float32(2.6))
+    elif mode == "gamma22":
+        cp.transfer_function = abi.TF_GAMMA
+        cp.gamma = float(np.float32(1e7) / np.float32(22000000))  # Gamma{g: 22000000, inverted: false}
+    else:
+        raise ValueError(mode)
+
+
 class VardctWorkload:
     """Holds numpy arrays (kept alive) + builds the C descriptor."""
 
     def __init__(self, width, height, seed=0, epf_iters=2, gabor=True, tf=abi.TF_SRGB,
                  intensity_target=255.0, upsampling=1, types=None, lf_i16=True,
-                 zero_fraction=0.85, skip_lf_smoothing=False, hdr_pq=False, group_dim=256):
+                 zero_fraction=0.85, skip_lf_smoothing=False, hdr_pq=False, group_dim=256,
+                 color_mode=None):
         rng = np.random.default_rng(SEED_BASE + seed)
         self.width, self.height = width, height
         self.group_dim = group_dim
@@ -212,6 +259,8 @@ class VardctWorkload:
                                      0.0690973, 0.9195404, 0.0113623,
                                      0.0163914, 0.0880133, 0.8955953]
             self.color.transfer_function = abi.TF_PQ
+        if color_mode is not None:
+            configure_color(self.color, color_mode)
 
         self.up_factor = upsampling
         self.up_w = None

@@ -10,6 +10,16 @@
  *   linear_to_pq_generic        jxl-color/src/tf/pq.rs:127-142, tables :26-35
  *   rational_poly::eval_generic jxl-color/src/fastmath/rational_poly.rs:2-6
  *   map_gamut_generic           jxl-color/src/gamut.rs:4-46
+ *   pq_to_linear_generic        jxl-color/src/tf/pq.rs:336-343, tables :10-23
+ *   rec2408_eetf_generic        jxl-color/src/tf/rec2408.rs:4-56
+ *   tone_map_generic            jxl-color/src/convert/tone_map.rs:179-211 (detect_peak = false)
+ *   fast_pow2f/log2f/powf_generic  jxl-color/src/fastmath/powf.rs:6-24, :134-156, :242-244
+ *   linear_to_bt709 (scalar)    jxl-color/src/tf/bt709.rs:60-68
+ *   apply_gamma (scalar)        jxl-color/src/tf.rs:60-68
+ *   Clip                        jxl-color/src/convert.rs:948-955
+ * Not restated: HLG (tf.rs:101-160 goes through libm powf/ln/log2, which is not reproducible
+ * bit-for-bit across platforms) and peak detection (a whole-image reduction ahead of the per-sample
+ * pass; ColorTransformBuilder's default is detect_peak = false, convert.rs:141).
  * Op order of the pipeline: jxl-color/src/convert.rs:208-549.
  */
 #include <math.h>
@@ -72,6 +82,133 @@ static float linear_to_pq(float s, float intensity_target) {
     return copysignf(y, s);
 }
 
+/* tf/pq.rs:10-23 (data tables) */
+static const float EOTF_P[5] = {2.6297566e-4f, -6.235531e-3f, 7.386023e-1f, 2.6455317f, 5.500349e-1f};
+static const float EOTF_Q[5] = {4.213501e2f, -4.2873682e2f, 1.7436467e2f, -3.3907887e1f, 2.6771877f};
+
+/* tf/pq.rs:336-343 */
+static float pq_to_linear(float s, float intensity_target) {
+    float y_mult = 10000.0f / intensity_target;
+    float a = fabsf(s);
+    float x = fmaf(a, a, a);
+    float y = rational_poly5(x, EOTF_P, EOTF_Q);
+    return copysignf(y * y_mult, s);
+}
+
+/* tf/rec2408.rs:4-56 */
+static float rec2408_eetf(float from_pq_sample, float intensity_target, const float from_range[2],
+                          const float to_range[2]) {
+    float lum[4] = {from_range[0] / intensity_target, from_range[1] / intensity_target,
+                    to_range[0] / intensity_target, to_range[1] / intensity_target};
+    for (int i = 0; i < 4; ++i) lum[i] = linear_to_pq(lum[i], intensity_target);
+    /* Step 1 */
+    float source_pq_diff = lum[1] - lum[0];
+    float normalized = (from_pq_sample - lum[0]) / source_pq_diff;
+    float min_luminance = (lum[2] - lum[0]) / source_pq_diff;
+    float max_luminance = (lum[3] - lum[0]) / source_pq_diff;
+    /* Step 2 */
+    float ks = 1.5f * max_luminance - 0.5f;
+    float b = min_luminance;
+    /* Step 3, 4 */
+    float compressed;
+    if (normalized < ks) {
+        compressed = normalized;
+    } else {
+        float one_sub_ks = 1.0f - ks;
+        float t = (normalized - ks) / one_sub_ks;
+        float t_p2 = t * t;
+        float t_p3 = t_p2 * t;
+        compressed = (2.0f * t_p3 - 3.0f * t_p2 + 1.0f) * ks + (t_p3 - 2.0f * t_p2 + t) * one_sub_ks +
+                     (-2.0f * t_p3 + 3.0f * t_p2) * max_luminance;
+    }
+    float x = 1.0f - compressed;
+    float one_sub_compressed_p4 = x * x * x * x;
+    float normalized_target = one_sub_compressed_p4 * b + compressed;
+    /* Step 5 */
+    return normalized_target * source_pq_diff + lum[0];
+}
+
+/* convert/tone_map.rs:8-31 (detect_peak = false: peak = intensity_target) and :179-211 */
+static void tone_map(float rgb[3], const float lum[3], float intensity_target, float min_nits,
+                     float target_display_luminance) {
+    float peak_luminance = fminf(intensity_target, intensity_target);
+    float from_range[2] = {min_nits, peak_luminance};
+    float to_range[2] = {0.0f, target_display_luminance};
+    float scale = intensity_target / to_range[1];
+    float y = rgb[0] * lum[0] + rgb[1] * lum[1] + rgb[2] * lum[2];
+    float y_pq = linear_to_pq(y, intensity_target);
+    float y_mapped = rec2408_eetf(y_pq, intensity_target, from_range, to_range);
+    y_mapped = pq_to_linear(y_mapped, intensity_target);
+    float ratio = fabsf(y) <= 1e-7f ? y_mapped * scale : y_mapped / y * scale;
+    rgb[0] *= ratio;
+    rgb[1] *= ratio;
+    rgb[2] *= ratio;
+}
+
+/* fastmath/powf.rs:3-4, :134-144 (data tables) */
+static const float POW2F_NUMER[3] = {1.01749063e1f, 4.88687798e1f, 9.85506591e1f};
+static const float POW2F_DENOM[4] = {2.10242958e-1f, -2.22328856e-2f, -1.94414990e1f, 9.85506633e1f};
+static const float LOG2F_P[3] = {-1.8503833400518310e-6f, 1.4287160470083755f, 7.4245873327820566e-1f};
+static const float LOG2F_Q[3] = {9.9032814277590719e-1f, 1.0096718572241148f, 1.7409343003366853e-1f};
+
+/* Rust `f32 as i32`: saturating, NaN -> 0 */
+static int32_t f32_as_i32(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return INT32_MAX;
+    if (f <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)f;
+}
+
+/* fastmath/powf.rs:6-24 */
+static float fast_pow2f(float x) {
+    float x_floor = floorf(x);
+    float exp = u2f(((uint32_t)f32_as_i32(x_floor) + 127u) << 23);
+    float frac = x - x_floor;
+    float num = frac + POW2F_NUMER[0];
+    num = num * frac + POW2F_NUMER[1];
+    num = num * frac + POW2F_NUMER[2];
+    num = num * exp;
+    float den = POW2F_DENOM[0] * frac + POW2F_DENOM[1];
+    den = den * frac + POW2F_DENOM[2];
+    den = den * frac + POW2F_DENOM[3];
+    return num / den;
+}
+
+/* fastmath/powf.rs:146-156 (+ rational_poly.rs:2-6 with P = Q = 3) */
+static float fast_log2f(float x) {
+    uint32_t x_bits = f2u(x);
+    int32_t exp_bits = (int32_t)(x_bits - 0x3f2aaaabu);
+    int32_t exp_shifted = exp_bits >> 23;
+    float mantissa = u2f(x_bits - ((uint32_t)exp_shifted << 23));
+    float exp_val = (float)exp_shifted;
+    float m = mantissa - 1.0f;
+    float yp = LOG2F_P[2];
+    yp = yp * m + LOG2F_P[1];
+    yp = yp * m + LOG2F_P[0];
+    float yq = LOG2F_Q[2];
+    yq = yq * m + LOG2F_Q[1];
+    yq = yq * m + LOG2F_Q[0];
+    return yp / yq + exp_val;
+}
+
+/* fastmath/powf.rs:242-244 */
+static float fast_powf(float base, float exp) { return fast_pow2f(fast_log2f(base) * exp); }
+
+/* tf/bt709.rs:60-68 */
+static float linear_to_bt709(float a) {
+    return a <= 0.018f ? 4.5f * a : fmaf(fast_powf(a, 0.45f), 1.099f, -0.099f);
+}
+
+/* tf.rs:60-68 */
+static float apply_gamma(float a, float gamma) { return a <= 1e-7f ? 0.0f : fast_powf(a, gamma); }
+
+/* f32::clamp(0.0, 1.0) (convert.rs:951): NaN stays NaN */
+static float clamp01(float v) {
+    if (v < 0.0f) v = 0.0f;
+    if (v > 1.0f) v = 1.0f;
+    return v;
+}
+
 /* f32::max / f32::min semantics (IEEE maxNum: NaN loses) == fmaxf/fminf */
 
 /* gamut.rs:4-46 */
@@ -128,12 +265,19 @@ void orc_color_transform(float* const ch[3], size_t n, const JxlGpuColorParams* 
         v[1] = fmaf(g_m * g_m, g_m, cp->opsin_bias[1]) * itscale;
         v[2] = fmaf(g_s * g_s, g_s, cp->opsin_bias[2]) * itscale;
         matmul3vec(cp->matrix, v);
-        if (cp->gamut_map) map_gamut(v, cp->gamut_luminances, cp->gamut_saturation_factor);
+        if (cp->gamut_map == JXLGPU_GAMUT_MAP) map_gamut(v, cp->gamut_luminances, cp->gamut_saturation_factor);
+        else if (cp->gamut_map == JXLGPU_GAMUT_CLIP) for (int c = 0; c < 3; ++c) v[c] = clamp01(v[c]);
         if (cp->has_matrix2) matmul3vec(cp->matrix2, v);
+        if (cp->tone_map) {
+            tone_map(v, cp->tm_luminances, cp->intensity_target, cp->tm_min_nits, cp->tm_target_display_luminance);
+            if (cp->tm_gamut_map) map_gamut(v, cp->tm_luminances, cp->tm_gamut_saturation_factor);
+        }
         for (int c = 0; c < 3; ++c) {
             switch (cp->transfer_function) {
                 case JXLGPU_TF_SRGB: v[c] = linear_to_srgb(v[c]); break;
                 case JXLGPU_TF_PQ: v[c] = linear_to_pq(v[c], cp->intensity_target); break;
+                case JXLGPU_TF_BT709: v[c] = linear_to_bt709(v[c]); break;
+                case JXLGPU_TF_GAMMA: v[c] = apply_gamma(v[c], cp->gamma); break;
                 default: break;
             }
         }

@@ -66,4 +66,7 @@ int orc_post_stages(float* const pix[3], size_t stride, size_t width, size_t hei
                     const JxlGpuUpsampling* up, const JxlGpuColorParams* cp, uint32_t stages,
                     float* const out[3], uint32_t out_stride);
 
+/* OpenMP thread count of the oracle's parallel loops (returns the value in effect). */
+int jxl_oracle_set_threads(int n);
+
 #endif

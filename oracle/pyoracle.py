@@ -72,6 +72,13 @@ def transform_block(coeff, dct_select):
     return io
 
 
+def set_threads(n):
+    """omp_set_num_threads for the oracle's loops; returns the thread count in effect."""
+    f = lib().jxl_oracle_set_threads
+    f.argtypes, f.restype = [C.c_int], C.c_int
+    return int(f(int(n)))
+
+
 def vardct_render(desc, stages, out_w, out_h, want_lf=False, w8=0, h8=0, out=None):
     """Returns (planes[3][h,w] or None, lf[3][h8,w8] or None).  `out` may be a preallocated
     (3, out_h, out_w) float32 array (the CPU-baseline timing loop reuses one)."""

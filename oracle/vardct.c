@@ -529,3 +529,19 @@ int jxl_oracle_vardct_render(const JxlGpuVardctDesc* d, uint32_t stages, float* 
     free_frame_meta(&m);
     return rc;
 }
+
+
+/* Measurement helper for bench.py's cpu_baseline: libgomp reads OMP_NUM_THREADS once, when the
+ * first OpenMP runtime in the process is loaded (torch loads one long before this library). */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int jxl_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}

@@ -103,6 +103,32 @@ def test_hdr_pq_chain(gpu_ctx, oracle):
     assert_ulp(got, exp, MAX_ULP, "PQ chain")
 
 
+@pytest.mark.parametrize("mode,it", [("tone_map_srgb", 4000.0), ("tone_map_min_nits", 1000.0), ("bt709", 255.0),
+                                     ("clip_p3_dci", 255.0), ("gamma22", 255.0)])
+def test_colour_op_lists(gpu_ctx, oracle, mode, it):
+    """C4: Rec.2408 tone map (+ GamutMap), Clip, BT.709 and gamma transfer functions, through both
+    the fused post path and the staged colour kernel."""
+    wl = VardctWorkload(200, 136, seed=31, epf_iters=1, intensity_target=it, color_mode=mode)
+    got, exp = _both(gpu_ctx, oracle, wl, S_ALL)
+    assert_ulp(got, exp, MAX_ULP, f"colour {mode} (fused)")
+    d = wl.desc()
+    exp2, _ = oracle.vardct_render(d, abi.STAGE_LF | abi.STAGE_TRANSFORM | abi.STAGE_COLOR, wl.width, wl.height)
+    frame = gpu_ctx.vardct_upload(d)
+    try:
+        got2 = gpu_ctx.vardct_render(frame, abi.STAGE_LF | abi.STAGE_TRANSFORM | abi.STAGE_COLOR)
+    finally:
+        frame.free()
+    assert_ulp(got2, exp2, MAX_ULP, f"colour {mode} (colour-only stage)")
+
+
+def test_hlg_is_refused(gpu_ctx):
+    wl = VardctWorkload(64, 64, seed=5)
+    wl.color.transfer_function = abi.TF_HLG
+    with pytest.raises(Exception) as e:
+        gpu_ctx.vardct_upload(wl.desc())
+    assert e.value.code == abi.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("factor", [2, 4, 8])
 def test_upsampling(gpu_ctx, oracle, factor):
     wl = VardctWorkload(72, 56, seed=20 + factor, upsampling=factor, epf_iters=1)

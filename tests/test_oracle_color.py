@@ -1,11 +1,11 @@
 """The oracle's colour chain against exact f64 formulas: XYB cube + opsin inverse, IEC 61966-2-1
-sRGB, SMPTE ST 2084 (PQ)."""
+sRGB, SMPTE ST 2084 (PQ), BT.709 OETF, pure gamma, and the Rec. ITU-R BT.2408 EETF tone map."""
 import ctypes as C
 
 import numpy as np
 
 from jxl_oxide_amd import abi
-from jxl_oxide_amd.synth import OPSIN_BIAS, OPSIN_INV
+from jxl_oxide_amd.synth import OPSIN_BIAS, OPSIN_INV, SRGB_LUMINANCES, SRGB_TO_P3, configure_color
 
 
 def _run(oracle, xyb, cp):
@@ -67,3 +67,98 @@ def test_pq_transfer(oracle):
     exp = np.sign(lin) * ((c1 + c2 * a ** m1) / (1 + c3 * a ** m1)) ** m2
     ok = np.abs(lin) > 1e-4
     assert np.allclose(got[ok], exp[ok], atol=2e-4)
+
+
+def _oracle_linear(oracle, xyb, cp):
+    """The f32 linear values the transfer function receives (same chain, TF switched off)."""
+    lin_cp = abi.ColorParams.from_buffer_copy(cp)
+    lin_cp.transfer_function = abi.TF_LINEAR
+    return _run(oracle, xyb, lin_cp).astype(np.float64)
+
+
+def test_bt709_transfer(oracle):
+    xyb = _xyb_samples(seed=3)
+    cp = _params(abi.TF_LINEAR)
+    configure_color(cp, "bt709")
+    got = _run(oracle, xyb, cp)
+    lin = _oracle_linear(oracle, xyb, cp)
+    with np.errstate(invalid="ignore"):
+        exp = np.where(lin <= 0.018, 4.5 * lin, 1.099 * np.abs(lin) ** 0.45 - 0.099)
+    assert np.allclose(got, exp, rtol=2e-6, atol=2e-6)  # fast_powf: rational 2^x / log2 x, ~3e-7 relative
+
+
+def test_gamma_transfer(oracle):
+    xyb = _xyb_samples(seed=4)
+    for mode, g in (("gamma22", 1 / 2.2), ("clip_p3_dci", 1 / 2.6)):
+        cp = _params(abi.TF_LINEAR)
+        configure_color(cp, mode)
+        got = _run(oracle, xyb, cp)
+        lin = _oracle_linear(oracle, xyb, cp)
+        if mode == "clip_p3_dci":  # Clip -> Matrix against the f64 chain
+            ref = np.tensordot(np.array(SRGB_TO_P3).reshape(3, 3), np.clip(_linear_rgb_f64(xyb, 255.0), 0.0, 1.0), axes=1)
+            assert np.allclose(lin, ref, atol=2e-5)
+        exp = np.where(lin <= 1e-7, 0.0, np.abs(lin) ** g)
+        assert np.allclose(got, exp, rtol=2e-6, atol=1e-7), mode
+        assert (got[lin <= 0] == 0).all()
+
+
+def _pq_oetf(y):  # y in units of 10000 nits
+    m1, m2, c1, c2, c3 = 2610 / 16384, 2523 / 4096 * 128, 3424 / 4096, 2413 / 4096 * 32, 2392 / 4096 * 32
+    return ((c1 + c2 * y ** m1) / (1 + c3 * y ** m1)) ** m2
+
+
+def _pq_eotf(e):
+    m1, m2, c1, c2, c3 = 2610 / 16384, 2523 / 4096 * 128, 3424 / 4096, 2413 / 4096 * 32, 2392 / 4096 * 32
+    with np.errstate(invalid="ignore"):
+        p = e ** (1 / m2)
+    return (np.maximum(p - c1, 0) / (c2 - c3 * p)) ** (1 / m1)
+
+
+def _bt2408_f64(lin, it, min_nits, target, lum):
+    """Rec. ITU-R BT.2408 annex 5 EETF on luminance, RGB scaled by the luminance ratio."""
+    y = np.tensordot(np.array(lum), lin, axes=1)  # 1.0 = intensity_target nits
+    lb, lw, lmin, lmax = [_pq_oetf(v / 10000.0) for v in (min_nits, it, 0.0, target)]
+    e1 = (_pq_oetf(np.abs(y) * it / 10000.0) - lb) / (lw - lb)
+    mn, mx = (lmin - lb) / (lw - lb), (lmax - lb) / (lw - lb)
+    ks = 1.5 * mx - 0.5
+    t = (e1 - ks) / (1 - ks)
+    spline = (2 * t ** 3 - 3 * t ** 2 + 1) * ks + (t ** 3 - 2 * t ** 2 + t) * (1 - ks) + (-2 * t ** 3 + 3 * t ** 2) * mx
+    e2 = np.where(e1 < ks, e1, spline)
+    e3 = e2 + mn * (1 - e2) ** 4
+    y_mapped = _pq_eotf(e3 * (lw - lb) + lb) * 10000.0 / it
+    ratio = y_mapped / y * (it / target)
+    return lin * ratio, y
+
+
+def test_tone_map_rec2408(oracle):
+    xyb = _xyb_samples(seed=5)
+    it = 4000.0
+    cp = _params(abi.TF_LINEAR, it)
+    configure_color(cp, "tone_map_min_nits")
+    got = _run(oracle, xyb, cp)
+    lin = _linear_rgb_f64(xyb, it)
+    exp, y = _bt2408_f64(lin, it, 0.05, 255.0, SRGB_LUMINANCES)
+    ok = y > 1e-3
+    assert ok.sum() > 10000
+    assert np.allclose(got[:, ok], exp[:, ok], rtol=3e-3, atol=3e-4)
+    # mapped luminance never exceeds the 255-nit display (1.0 after the rescale), monotone in y
+    ym = np.tensordot(np.array(SRGB_LUMINANCES), got.astype(np.float64), axes=1)[ok]
+    assert ym.max() <= 1.0 + 1e-3
+    order = np.argsort(y[ok])
+    assert (np.diff(ym[order]) > -1e-4).all()
+
+
+def test_tone_map_then_gamut_map_in_gamut(oracle):
+    xyb = _xyb_samples(seed=6)
+    cp = _params(abi.TF_LINEAR, 1000.0)
+    configure_color(cp, "tone_map_srgb")
+    got = _run(oracle, xyb, cp)
+    assert np.isfinite(got).all()
+    # GamutMap divides by max(1, r, g, b): nothing above 1 is left before the sRGB curve
+    assert got.max() <= 1.0 + 1e-3
+    # and with saturation_factor 0.3 it pulls negative components towards grey, never away from it
+    cp2 = _params(abi.TF_LINEAR, 1000.0)
+    configure_color(cp2, "tone_map_srgb")
+    cp2.tm_gamut_map = 0
+    raw = _run(oracle, xyb, cp2)
+    assert got.min() >= min(raw.min(), 0.0) - 1e-6
