@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 6u
+#define JXLGPU_ABI_VERSION 7u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -119,6 +119,14 @@ typedef struct {
     const float* up8_weight;   /* 210 floats                                                      */
 } JxlGpuUpsampling;
 
+/* ---- noise synthesis (jxl-render/src/features/noise.rs, LfGlobal.noise) ---- */
+typedef struct {
+    uint32_t enabled;          /* lf_global.noise.is_some() (render.rs:207)                        */
+    float lut[8];              /* NoiseParameters.lut (jxl-frame/src/data/noise.rs:2-4)            */
+    uint32_t visible_frames;   /* rng_seed0 = visible << 32 + invisible (noise.rs:168-170)         */
+    uint32_t invisible_frames;
+} JxlGpuNoiseParams;
+
 /* ---- one LF group's decoded state (jxl-frame LfGroup + jxl-vardct HfMetadata) ---- */
 typedef struct {
     uint32_t width_px, height_px; /* LF group size in colour samples (<= group_dim*8)            */
@@ -141,7 +149,12 @@ typedef struct {
 #define JXLGPU_STAGE_EPF 0x08u
 #define JXLGPU_STAGE_UPSAMPLE 0x10u
 #define JXLGPU_STAGE_COLOR 0x20u
-#define JXLGPU_STAGE_ALL 0x3Fu
+#define JXLGPU_STAGE_NOISE 0x80u     /* between UPSAMPLE and COLOR (render.rs:207-222); no-op unless  */
+                                     /* noise.enabled                                               */
+#define JXLGPU_STAGE_ALL 0xBFu
+
+#define JXLGPU_COEFF_DENSE 0u
+#define JXLGPU_COEFF_SPARSE 1u
 
 typedef struct {
     uint32_t abi;                 /* = JXLGPU_ABI_VERSION                                         */
@@ -151,9 +164,20 @@ typedef struct {
     uint32_t jpeg_upsampling[3];  /* must be 0 (else JXLGPU_ERR_UNSUPPORTED)                       */
     /* HF coefficients as `write_hf_coeff` leaves them (jxl-vardct/src/hf_coeff.rs:207-244):
      * planes in framebuffer order [0]=X,[1]=Y,[2]=B, width_rounded x height_rounded (ceil to 8),
-     * row stride `coeff_stride` elements (jxl-render/src/vardct/mod.rs:206-222, 262-265).         */
-    const int32_t* coeff[3];
+     * row stride `coeff_stride` elements (jxl-render/src/vardct/mod.rs:206-222, 262-265).
+     *   JXLGPU_COEFF_DENSE : coeff[c] = the plane, elements of `coeff_sample_type` (i32 is the
+     *                        reference's own framebuffer; i16 halves the H2D volume and is valid
+     *                        whenever every |coefficient| < 32768).
+     *   JXLGPU_COEFF_SPARSE: the non-zero stores of hf_coeff.rs:234 as lists.  coeff[c] = values
+     *                        (`coeff_sample_type`), sparse_pos[c][i] = y * coeff_stride + x,
+     *                        sparse_count[c] entries; entries accumulate (`+=`, as the passes of a
+     *                        progressive frame do), everything not listed is 0.                  */
+    const void* coeff[3];
     uint32_t coeff_stride;
+    uint32_t coeff_format;        /* JXLGPU_COEFF_*                                                */
+    uint32_t coeff_sample_type;   /* JXLGPU_SAMPLE_I32 / JXLGPU_SAMPLE_I16                         */
+    const uint32_t* sparse_pos[3];
+    uint64_t sparse_count[3];
     uint32_t num_lf_groups;       /* frame_header.num_lf_groups(), raster order                    */
     const JxlGpuLfGroup* lf_groups;
     /* Quantizer / LfChannelDequantization / LfChannelCorrelation (jxl-vardct/src/lf.rs:11-34) */
@@ -176,6 +200,7 @@ typedef struct {
     const float* sec_half_large[3];
     JxlGpuFilterParams filter;
     JxlGpuUpsampling upsampling;
+    JxlGpuNoiseParams noise;
     JxlGpuColorParams color;
 } JxlGpuVardctDesc;
 
@@ -304,6 +329,7 @@ typedef struct {
     uint32_t exp_bits;
     JxlGpuFilterParams filter;
     JxlGpuUpsampling upsampling;
+    JxlGpuNoiseParams noise;
     JxlGpuColorParams color;
 } JxlGpuModularDesc;
 

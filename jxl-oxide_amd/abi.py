@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -23,6 +23,7 @@ SAMPLE_I16 = 1
 
 TF_LINEAR, TF_SRGB, TF_PQ, TF_BT709, TF_GAMMA, TF_HLG = range(6)
 GAMUT_NONE, GAMUT_MAP, GAMUT_CLIP = range(3)
+COEFF_DENSE, COEFF_SPARSE = range(2)
 
 STAGE_LF = 0x01
 STAGE_TRANSFORM = 0x02
@@ -30,7 +31,8 @@ STAGE_GABOR = 0x04
 STAGE_EPF = 0x08
 STAGE_UPSAMPLE = 0x10
 STAGE_COLOR = 0x20
-STAGE_ALL = 0x3F
+STAGE_NOISE = 0x80
+STAGE_ALL = 0xBF
 STAGE_MODULAR_INVERSE = 0x02
 STAGE_MODULAR_TO_FLOAT = 0x40
 
@@ -95,6 +97,15 @@ class ColorParams(C.Structure):
     ]
 
 
+class NoiseParams(C.Structure):
+    _fields_ = [
+        ("enabled", C.c_uint32),
+        ("lut", C.c_float * 8),
+        ("visible_frames", C.c_uint32),
+        ("invisible_frames", C.c_uint32),
+    ]
+
+
 class Upsampling(C.Structure):
     _fields_ = [
         ("factor", C.c_uint32),
@@ -127,8 +138,12 @@ class VardctDesc(C.Structure):
         ("group_dim", C.c_uint32),
         ("lf_sample_type", C.c_uint32),
         ("jpeg_upsampling", C.c_uint32 * 3),
-        ("coeff", i32p * 3),
+        ("coeff", C.c_void_p * 3),
         ("coeff_stride", C.c_uint32),
+        ("coeff_format", C.c_uint32),
+        ("coeff_sample_type", C.c_uint32),
+        ("sparse_pos", C.POINTER(C.c_uint32) * 3),
+        ("sparse_count", C.c_uint64 * 3),
         ("num_lf_groups", C.c_uint32),
         ("lf_groups", C.POINTER(LfGroup)),
         ("global_scale", C.c_uint32),
@@ -148,6 +163,7 @@ class VardctDesc(C.Structure):
         ("sec_half_large", f32p * 3),
         ("filter", FilterParams),
         ("upsampling", Upsampling),
+        ("noise", NoiseParams),
         ("color", ColorParams),
     ]
 
@@ -203,6 +219,7 @@ class ModularDesc(C.Structure):
         ("exp_bits", C.c_uint32),
         ("filter", FilterParams),
         ("upsampling", Upsampling),
+        ("noise", NoiseParams),
         ("color", ColorParams),
     ]
 

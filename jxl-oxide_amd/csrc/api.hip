@@ -77,6 +77,17 @@ int dev_upload(jxlgpu_ctx* ctx, jxlgpu_frame* f, T** out, const std::vector<T>& 
     return JXLGPU_OK;
 }
 
+// temporaries of the upload (freed when it returns, after a stream sync)
+struct Scratch {
+    std::vector<void*> ptrs;
+    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+    int alloc(jxlgpu_ctx* ctx, void** out, size_t bytes) {
+        HIP_TRY(ctx, hipMalloc(out, std::max<size_t>(bytes, 16)));
+        ptrs.push_back(*out);
+        return JXLGPU_OK;
+    }
+};
+
 #define TRY(expr)                 \
     do {                          \
         int rc_ = (expr);         \
@@ -86,6 +97,40 @@ int dev_upload(jxlgpu_ctx* ctx, jxlgpu_frame* f, T** out, const std::vector<T>& 
 int fail(jxlgpu_ctx* ctx, int code, const char* msg) {
     ctx->last_error = msg;
     return code;
+}
+
+// HF coefficients of channel c into the dense i32 device plane f->coeff[c] (coeff_kernels.hip).
+int upload_coeff_plane(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuVardctDesc* d, int c, Scratch& tmp,
+                       uint32_t* d_bad) {
+    const size_t npix = (size_t)f->wr * f->hr;
+    const bool v16 = d->coeff_sample_type == JXLGPU_SAMPLE_I16;
+    const size_t vsz = v16 ? 2 : 4;
+    if (d->coeff_format == JXLGPU_COEFF_DENSE) {
+        if (!v16) {
+            HIP_TRY(ctx, hipMemcpy2D(f->coeff[c], (size_t)f->wr * 4, d->coeff[c], (size_t)d->coeff_stride * 4,
+                                     (size_t)f->wr * 4, f->hr, hipMemcpyHostToDevice));
+            return JXLGPU_OK;
+        }
+        void* t = nullptr;
+        TRY(tmp.alloc(ctx, &t, npix * 2));
+        HIP_TRY(ctx, hipMemcpy2D(t, (size_t)f->wr * 2, d->coeff[c], (size_t)d->coeff_stride * 2, (size_t)f->wr * 2,
+                                 f->hr, hipMemcpyHostToDevice));
+        launch_widen_i16(ctx->stream, static_cast<const int16_t*>(t), f->coeff[c], npix);
+        HIP_TRY(ctx, hipGetLastError());
+        return JXLGPU_OK;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(f->coeff[c], 0, npix * 4, ctx->stream));
+    const size_t n = (size_t)d->sparse_count[c];
+    if (n == 0) return JXLGPU_OK;
+    void *dp = nullptr, *dv = nullptr;
+    TRY(tmp.alloc(ctx, &dp, n * 4));
+    TRY(tmp.alloc(ctx, &dv, n * vsz));
+    HIP_TRY(ctx, hipMemcpy(dp, d->sparse_pos[c], n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dv, d->coeff[c], n * vsz, hipMemcpyHostToDevice));
+    launch_coeff_scatter(ctx->stream, static_cast<const uint32_t*>(dp), dv, v16, n, d->coeff_stride, f->wr, f->hr,
+                         f->coeff[c], d_bad);
+    HIP_TRY(ctx, hipGetLastError());
+    return JXLGPU_OK;
 }
 
 void fill_color_args(const JxlGpuColorParams& cp, ColorArgs* c) {
@@ -199,6 +244,7 @@ void jxlgpu_destroy(jxlgpu_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->noise_jump) (void)hipFree(ctx->noise_jump);
     for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete ctx;
 }
@@ -263,8 +309,14 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
     if (d->filter.epf_iters > 3) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "epf_iters > 3");
     const uint32_t upf = d->upsampling.factor ? d->upsampling.factor : 1;
     if (upf != 1 && upf != 2 && upf != 4 && upf != 8) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "bad upsampling factor");
-    for (int c = 0; c < 3; ++c)
-        if (!d->coeff[c]) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null coefficient plane");
+    if (d->coeff_format > JXLGPU_COEFF_SPARSE || d->coeff_sample_type > JXLGPU_SAMPLE_I16)
+        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "bad coeff_format / coeff_sample_type");
+    for (int c = 0; c < 3; ++c) {
+        if (d->coeff_format == JXLGPU_COEFF_DENSE && !d->coeff[c])
+            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null coefficient plane");
+        if (d->coeff_format == JXLGPU_COEFF_SPARSE && d->sparse_count[c] && (!d->coeff[c] || !d->sparse_pos[c]))
+            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null sparse coefficient list");
+    }
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     jxlgpu_frame* f = new (std::nothrow) jxlgpu_frame();
@@ -395,10 +447,14 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
     }
 
     // ---- device buffers + H2D
+    Scratch tmp;
+    void* d_bad_v = nullptr;
+    TRY(tmp.alloc(ctx, &d_bad_v, 4));
+    uint32_t* d_bad = static_cast<uint32_t*>(d_bad_v);
+    HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
     for (int c = 0; c < 3; ++c) {
         TRY(dev_alloc(ctx, f, &f->coeff[c], npix));
-        HIP_TRY(ctx, hipMemcpy2D(f->coeff[c], (size_t)f->wr * 4, d->coeff[c], (size_t)d->coeff_stride * 4,
-                                 (size_t)f->wr * 4, f->hr, hipMemcpyHostToDevice));
+        TRY(upload_coeff_plane(ctx, f, d, c, tmp, d_bad));
         uint8_t* p = nullptr;
         TRY(dev_upload(ctx, f, &p, lfq_host[c]));
         f->lfq[c] = p;
@@ -481,8 +537,16 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
     }
     for (int c = 0; c < 3; ++c) f->lf_div[c] = (float)(512.0 * (double)d->m_lf[c] / (double)scale_inv);
     fill_color_args(d->color, &f->color);
+    f->noise_group_dim = d->group_dim;
+    f->noise_corr_x = d->base_correlation_x;  // render.rs:175-180
+    f->noise_corr_b = d->base_correlation_b;
 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // descriptor memory may be released now
+    if (d->coeff_format == JXLGPU_COEFF_SPARSE) {
+        uint32_t bad = 0;
+        HIP_TRY(ctx, hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
+        if (bad) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "sparse coefficient position outside the frame");
+    }
     // pointers inside the descriptor copy are dead from here on
     for (int c = 0; c < 3; ++c) f->desc.coeff[c] = nullptr;
     f->desc.lf_groups = nullptr;
@@ -542,15 +606,17 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
     const int epf_iters = (stages & JXLGPU_STAGE_EPF) ? (int)fp.epf_iters : 0;
     const bool do_up = (stages & JXLGPU_STAGE_UPSAMPLE) && up_factor > 1;
     const bool do_color = (stages & JXLGPU_STAGE_COLOR) && f->desc.color.enabled;
+    const bool do_noise = (stages & JXLGPU_STAGE_NOISE) && f->desc.noise.enabled;
+    const bool fuse_color = do_color && !do_up && !do_noise;  // noise sits between upsampling and colour
 
     // Fast path: everything after the transform in one tile kernel (fused_kernels.hip)
     if ((do_gab || epf_iters) && fused_post_supported(f, do_gab, epf_iters)) {
         const float* in[3] = {cur[0], cur[1], cur[2]};
         float** dst = (cur[0] == f->buf_a[0]) ? f->buf_b : f->buf_a;
-        launch_fused_post(s, f, in, *cur_stride, dst, f->wr, do_gab, epf_iters, do_color && !do_up, ctx);
+        launch_fused_post(s, f, in, *cur_stride, dst, f->wr, do_gab, epf_iters, fuse_color, ctx);
         for (int c = 0; c < 3; ++c) cur[c] = dst[c];
         *cur_stride = f->wr;
-        if (do_color && !do_up) {
+        if (fuse_color) {
             *ow = W; *oh = H;
             return JXLGPU_OK;
         }
@@ -582,6 +648,31 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
         for (int c = 0; c < 3; ++c) launch_upsample(s, cur[c], *cur_stride, W, H, f->up[c], W * k, k, kern);
         for (int c = 0; c < 3; ++c) cur[c] = f->up[c];
         *ow = W * k; *oh = H * k; *cur_stride = W * k;
+    }
+    if (do_noise) {
+        // render.rs:207-222: after upsampling, on the frame's final size
+        if (noise_geometry_unsupported(*oh, f->noise_group_dim))
+            return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "noise on a frame whose last group row is one sample high (the reference panics there)");
+        if (!ctx->noise_jump) {
+            HIP_TRY(ctx, hipMalloc(&ctx->noise_jump, noise_jump_table_bytes()));
+            HIP_TRY(ctx, hipMemcpy(ctx->noise_jump, noise_jump_table_host(), noise_jump_table_bytes(), hipMemcpyHostToDevice));
+        }
+        if (!f->noise_raw[0] || f->noise_w != *ow || f->noise_h != *oh) {
+            for (int c = 0; c < 3; ++c) TRY(dev_alloc(ctx, f, &f->noise_raw[c], (size_t)*ow * *oh));
+            f->noise_w = *ow; f->noise_h = *oh;
+        }
+        if (cur[0] != f->buf_a[0] && cur[0] != f->buf_b[0] && cur[0] != f->up[0]) {
+            // the noise is added in place: never into the transform output, which a later render of
+            // the same frame with other stages would read again
+            float** dst = f->buf_a;
+            for (int c = 0; c < 3; ++c)
+                HIP_TRY(ctx, hipMemcpy2DAsync(dst[c], (size_t)f->wr * 4, cur[c], (size_t)*cur_stride * 4, (size_t)*ow * 4,
+                                              *oh, hipMemcpyDeviceToDevice, s));
+            for (int c = 0; c < 3; ++c) cur[c] = dst[c];
+            *cur_stride = f->wr;
+        }
+        launch_noise(s, f->desc.noise, ctx->noise_jump, f->noise_raw, cur, *cur_stride, *ow, *oh, f->noise_group_dim,
+                     f->noise_corr_x, f->noise_corr_b);
     }
     if (getenv("JXLGPU_DEBUG_SYNC")) (void)hipStreamSynchronize(s);
     if (do_color) launch_color(s, f->color, cur, *cur_stride, *ow, *oh);

@@ -114,6 +114,7 @@ struct jxlgpu_ctx {
     hipStream_t stream2 = nullptr;  // side stream: 64-pixel varblock kernels overlap the <=32 kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string last_error;
+    void* noise_jump = nullptr; // device copy of the xorshift128+ jump matrices (noise_kernels.hip)
     void* pinned = nullptr;     // pinned staging buffer (grown on demand)
     size_t pinned_size = 0;
     // event-pair profiling of one kernel group on the ctx stream
@@ -186,6 +187,10 @@ struct jxlgpu_frame {
     ColorArgs color = {};
     void* fmt_buf = nullptr;             // device staging for jxlgpu_frame_format_output
     size_t fmt_bytes = 0;
+    float* noise_raw[3] = {};            // raw noise planes (allocated on the first noise render)
+    uint32_t noise_w = 0, noise_h = 0;
+    uint32_t noise_group_dim = 256;
+    float noise_corr_x = 0.0f, noise_corr_b = 1.0f;  // base_correlations_xb (render.rs:175-180)
     uint32_t* ring_tiles = nullptr;      // outer ring of 32x32 tiles for the fused tile kernel
     uint32_t n_ring_tiles = 0;
     float* up_weights[3] = {};  // expanded 5x5 kernels per phase for 2x/4x/8x
@@ -219,6 +224,15 @@ void launch_nometa_groups(hipStream_t s, const TransformArgs& a, const uint32_t*
                           uint32_t count, uint32_t group_dim, uint32_t groups_per_row);
 void launch_gabor(hipStream_t s, const FilterArgs& a);
 void launch_epf(hipStream_t s, int step, const FilterArgs& a);
+size_t noise_jump_table_bytes();
+const void* noise_jump_table_host();
+bool noise_geometry_unsupported(uint32_t height, uint32_t group_dim);
+void launch_noise(hipStream_t s, const JxlGpuNoiseParams& np, const void* jump_dev, float* const raw[3],
+                  float* const ch[3], uint32_t stride, uint32_t width, uint32_t height, uint32_t group_dim,
+                  float corr_x, float corr_b);
+void launch_widen_i16(hipStream_t s, const int16_t* src, int32_t* dst, size_t count);
+void launch_coeff_scatter(hipStream_t s, const uint32_t* pos, const void* val, bool val_i16, size_t count,
+                          uint32_t src_stride, uint32_t wr, uint32_t hr, int32_t* dst, uint32_t* bad);
 void launch_color(hipStream_t s, const ColorArgs& c, float* const planes[3], uint32_t stride,
                   uint32_t width, uint32_t height);
 void launch_upsample(hipStream_t s, const float* in, uint32_t in_stride, uint32_t w, uint32_t h,

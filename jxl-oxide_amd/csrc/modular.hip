@@ -912,6 +912,10 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
     f->wr = f->w8 * 8; f->hr = f->h8 * 8;
     f->desc.filter = d->filter;
     f->desc.upsampling = d->upsampling;
+    f->desc.noise = d->noise;
+    f->noise_group_dim = d->group_dim ? d->group_dim : 256;
+    f->noise_corr_x = 0.0f;  // no VarDCT LfGlobal: base_correlations_xb = None -> (0, 1), noise.rs:35
+    f->noise_corr_b = 1.0f;
     f->desc.color = d->color;
     if (!d->xyb_encoded) f->desc.color.enabled = 0;
     fill_color_args_public(f->desc.color, &f->color);

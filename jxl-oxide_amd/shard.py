@@ -46,6 +46,7 @@ def slice_vardct_band(wl, ext_y0, ext_y1):
     y; geometry-free parameters are shared."""
     import copy
     assert ext_y0 % 256 == 0
+    assert not wl.noise.enabled, "noise seeds depend on absolute group positions: shard noisy frames by frame, not by band"
     b = copy.copy(wl)
     b.height = ext_y1 - ext_y0
     c0, c1 = ext_y0 // 8, -(-ext_y1 // 8)

@@ -113,6 +113,18 @@ SRGB_TO_P3 = [0.8224621, 0.1775380, 0.0000000,
               0.0170827, 0.0723974, 0.9105199]
 
 
+def make_noise_params(seed):
+    """LfGlobal.noise as a photon-noise encode would write it: 8 strengths in 1/1024 steps
+    (jxl-frame/src/data/noise.rs:9-15), frame counters for rng_seed0."""
+    rng = np.random.default_rng(SEED_BASE + 7919 * (seed + 1))
+    p = abi.NoiseParams()
+    p.enabled = 1
+    p.lut[:] = [float(v) / 1024.0 for v in rng.integers(20, 400, 8)]
+    p.visible_frames = int(rng.integers(0, 5))
+    p.invisible_frames = int(rng.integers(0, 3))
+    return p
+
+
 def configure_color(cp, mode):
     """Op lists `ColorTransform::new` builds for a few XYB -> target encodings besides the sRGB
     and PQ ones (jxl-color/src/convert.rs:208-549).  `cp` already holds XybToMixedLms + Matrix."""
@@ -158,7 +170,7 @@ class VardctWorkload:
     def __init__(self, width, height, seed=0, epf_iters=2, gabor=True, tf=abi.TF_SRGB,
                  intensity_target=255.0, upsampling=1, types=None, lf_i16=True,
                  zero_fraction=0.85, skip_lf_smoothing=False, hdr_pq=False, group_dim=256,
-                 color_mode=None):
+                 color_mode=None, noise=False):
         rng = np.random.default_rng(SEED_BASE + seed)
         self.width, self.height = width, height
         self.group_dim = group_dim
@@ -262,6 +274,7 @@ class VardctWorkload:
         if color_mode is not None:
             configure_color(self.color, color_mode)
 
+        self.noise = make_noise_params(seed) if noise else abi.NoiseParams()
         self.up_factor = upsampling
         self.up_w = None
         if upsampling > 1:
@@ -273,15 +286,46 @@ class VardctWorkload:
         self._keep = []
 
     # ---- descriptor
-    def desc(self):
+    def desc(self, coeff_transport="dense_i32", sparse_split=False):
+        """`coeff_transport`: "dense_i32" (the reference's framebuffer), "dense_i16", "sparse_i32",
+        "sparse_i16" (SURVEY §8f rank 2).  `sparse_split` splits every value over two list entries
+        at the same position, as two passes of a progressive frame would (hf_coeff.rs:234 `+=`)."""
         d = abi.VardctDesc()
         d.abi = abi.ABI_VERSION
         d.width, d.height = self.width, self.height
         d.group_dim = self.group_dim
         d.lf_sample_type = self.lf_sample_type
-        for c in range(3):
-            d.coeff[c] = self.coeff[c].ctypes.data_as(abi.i32p)
+        keep_c = []
+        v16 = coeff_transport.endswith("i16")
+        d.coeff_sample_type = abi.SAMPLE_I16 if v16 else abi.SAMPLE_I32
         d.coeff_stride = self.wr
+        if coeff_transport.startswith("dense"):
+            d.coeff_format = abi.COEFF_DENSE
+            for c in range(3):
+                plane = self.coeff[c]
+                if v16:
+                    assert np.abs(plane).max() < 32768
+                    plane = np.ascontiguousarray(plane.astype(np.int16))
+                    keep_c.append(plane)
+                d.coeff[c] = plane.ctypes.data
+        else:
+            d.coeff_format = abi.COEFF_SPARSE
+            for c in range(3):
+                flat = self.coeff[c].reshape(-1)
+                pos = np.flatnonzero(flat).astype(np.uint32)
+                val = flat[pos]
+                if sparse_split:  # second "pass" refines the same positions; order shuffled
+                    first = val // 2
+                    pos = np.concatenate([pos, pos])
+                    val = np.concatenate([first, val - first])
+                    perm = np.random.default_rng(c).permutation(pos.size)
+                    pos, val = pos[perm], val[perm]
+                val = np.ascontiguousarray(val.astype(np.int16 if v16 else np.int32))
+                pos = np.ascontiguousarray(pos)
+                keep_c += [pos, val]
+                d.coeff[c] = val.ctypes.data if val.size else None
+                d.sparse_pos[c] = pos.ctypes.data_as(C.POINTER(C.c_uint32)) if pos.size else None
+                d.sparse_count[c] = pos.size
         lf_dim = self.group_dim * 8
         gx_n, gy_n = -(-self.width // lf_dim), -(-self.height // lf_dim)
         groups = (abi.LfGroup * (gx_n * gy_n))()
@@ -334,12 +378,13 @@ class VardctWorkload:
             d.sec_half_large[i] = self.sec[i].ctypes.data_as(abi.f32p)
         d.filter = self.filter
         d.color = self.color
+        d.noise = self.noise
         d.upsampling.factor = self.up_factor
         if self.up_w is not None:
             d.upsampling.up2_weight = self.up_w[0].ctypes.data_as(abi.f32p)
             d.upsampling.up4_weight = self.up_w[1].ctypes.data_as(abi.f32p)
             d.upsampling.up8_weight = self.up_w[2].ctypes.data_as(abi.f32p)
-        self._keep = [groups, keep]
+        self._keep = [groups, keep, keep_c]
         return d
 
     def out_size(self, stages):

@@ -298,5 +298,6 @@ class ModularWorkload:
         d.filter = self.filter
         d.upsampling.factor = 1
         d.color = self.color
+        d.noise = getattr(self, "noise", abi.NoiseParams())
         self._keep = [chans, metas, trs]
         return d

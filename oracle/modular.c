@@ -495,7 +495,9 @@ int jxl_oracle_modular_render(const JxlGpuModularDesc* d, uint32_t stages, float
         for (size_t i = 0; i < w8 * h8; ++i) sigma[i] = d->filter.epf_sigma_for_modular;
         JxlGpuColorParams cp = d->color;
         if (!d->xyb_encoded) cp.enabled = 0;  /* already in the display colour space */
-        rc = orc_post_stages(pix, W, W, H, sigma, w8, &d->filter, &d->upsampling, &cp, stages, out, out_stride);
+        /* render.rs:175-180: no VarDCT LfGlobal -> base_correlations_xb = None -> (0.0, 1.0) (noise.rs:35) */
+        rc = orc_post_stages(pix, W, W, H, sigma, w8, &d->filter, &d->upsampling, &d->noise, d->group_dim, 0.0f,
+                             1.0f, &cp, stages, out, out_stride);
         free(sigma);
     }
     for (int c = 0; c < 3; ++c) free(pix[c]);

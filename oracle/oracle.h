@@ -63,8 +63,14 @@ void orc_color_transform(float* const ch[3], size_t n, const JxlGpuColorParams* 
 /* ---- post.c: gabor -> epf -> upsample -> colour on planes `pix` (stride `stride`) ---- */
 int orc_post_stages(float* const pix[3], size_t stride, size_t width, size_t height,
                     const float* sigma, size_t sigma_stride, const JxlGpuFilterParams* fp,
-                    const JxlGpuUpsampling* up, const JxlGpuColorParams* cp, uint32_t stages,
-                    float* const out[3], uint32_t out_stride);
+                    const JxlGpuUpsampling* up, const JxlGpuNoiseParams* np, size_t group_dim, float corr_x,
+                    float corr_b, const JxlGpuColorParams* cp, uint32_t stages, float* const out[3],
+                    uint32_t out_stride);
+/* noise.c: features/noise.rs on full planes (the frame after upsampling); JXLGPU_ERR_UNSUPPORTED
+ * for the geometry on which the reference itself panics (see noise.c fill_once). */
+int orc_render_noise(float* const ch[3], size_t stride, size_t width, size_t height, size_t group_dim,
+                     const JxlGpuNoiseParams* np, float corr_x, float corr_b);
+void orc_noise_group(uint32_t width, uint32_t height, uint64_t seed0, uint64_t seed1, float* out, uint32_t* stride_out);
 
 /* OpenMP thread count of the oracle's parallel loops (returns the value in effect). */
 int jxl_oracle_set_threads(int n);

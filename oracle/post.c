@@ -4,6 +4,7 @@
  *   apply_gabor_like (render.rs:76-101, filter/gabor.rs:8-41)
  *   apply_epf        (render.rs:103-131, filter/epf.rs:10-104: step order and buffer swaps)
  *   upsample_nonseparable (render.rs:149, image.rs:487-557, features/upsampling.rs:6-43)
+ *   render_noise     (render.rs:207-222, features/noise.rs)
  *   ColorTransform::run_with_threads (lib.rs:925-998)
  */
 #include <stdlib.h>
@@ -13,8 +14,9 @@
 
 int orc_post_stages(float* const pix[3], size_t stride, size_t width, size_t height,
                     const float* sigma, size_t sigma_stride, const JxlGpuFilterParams* fp,
-                    const JxlGpuUpsampling* up, const JxlGpuColorParams* cp, uint32_t stages,
-                    float* const out[3], uint32_t out_stride) {
+                    const JxlGpuUpsampling* up, const JxlGpuNoiseParams* np, size_t group_dim, float corr_x,
+                    float corr_b, const JxlGpuColorParams* cp, uint32_t stages, float* const out[3],
+                    uint32_t out_stride) {
     size_t n = width * height;
     float* a[3];
     float* b[3];
@@ -66,6 +68,9 @@ int orc_post_stages(float* const pix[3], size_t stride, size_t width, size_t hei
             ow *= k; oh *= k;
         }
     }
+    int rc = 0;
+    if ((stages & JXLGPU_STAGE_NOISE) && np && np->enabled)
+        rc = orc_render_noise(a, ow, ow, oh, group_dim, np, corr_x, corr_b);
     if (stages & JXLGPU_STAGE_COLOR) orc_color_transform(a, ow * oh, cp);
     for (int c = 0; c < 3; ++c) {
 #pragma omp parallel for schedule(static)
@@ -74,5 +79,5 @@ int orc_post_stages(float* const pix[3], size_t stride, size_t width, size_t hei
         free(a[c]);
         free(b[c]);
     }
-    return 0;
+    return rc;
 }

@@ -127,3 +127,28 @@ def format_output(planes, sample_format, orientation):
     if rc != 0:
         raise RuntimeError(f"oracle format_output failed: {rc}")
     return out
+
+
+def noise_group(width, height, seed0, seed1):
+    """Raw noise of one group (NoiseGroup::new): (3, height, stride) floats in [1, 2)."""
+    stride = -(-width // 16) * 16
+    out = np.zeros((3, height, stride), dtype=np.float32)
+    st = C.c_uint32(0)
+    f = lib().orc_noise_group
+    f.argtypes, f.restype = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, f32p, C.POINTER(C.c_uint32)], None
+    f(width, height, seed0, seed1, _p(out), C.byref(st))
+    assert st.value == stride
+    return out
+
+
+def render_noise(planes, group_dim, noise_params, corr_x, corr_b):
+    """features/noise.rs on (3, h, w) float planes, in place on a copy; returns the copy."""
+    a = np.ascontiguousarray(planes, dtype=np.float32).copy()
+    _, h, w = a.shape
+    f = lib().orc_render_noise
+    f.restype = C.c_int
+    f.argtypes = [f32p * 3, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_float, C.c_float]
+    rc = f((f32p * 3)(*[_p(a[c]) for c in range(3)]), w, w, h, group_dim, C.byref(noise_params), corr_x, corr_b)
+    if rc != 0:
+        raise RuntimeError(f"orc_render_noise -> {rc}")
+    return a

@@ -490,6 +490,9 @@ int jxl_oracle_vardct_render(const JxlGpuVardctDesc* d, uint32_t stages, float* 
                              uint32_t out_stride, float* const lf_out[3]) {
     if (d->abi != JXLGPU_ABI_VERSION) return JXLGPU_ERR_ABI;
     if (d->jpeg_upsampling[0] | d->jpeg_upsampling[1] | d->jpeg_upsampling[2]) return JXLGPU_ERR_UNSUPPORTED;
+    /* the reference's framebuffer holds dense i32 coefficients (vardct/mod.rs:262-265); the compact
+     * transports of the device ABI are rebuilt to exactly that before anything is computed */
+    if (d->coeff_format != JXLGPU_COEFF_DENSE || d->coeff_sample_type != JXLGPU_SAMPLE_I32) return JXLGPU_ERR_INVALID_ARG;
     size_t w8 = (d->width + 7) / 8, h8 = (d->height + 7) / 8;
     size_t wr = w8 * 8, hr = h8 * 8;
     for (int n = 64, i = 0; n <= 256; n *= 2, ++i)
@@ -513,7 +516,7 @@ int jxl_oracle_vardct_render(const JxlGpuVardctDesc* d, uint32_t stages, float* 
         pix[c] = (float*)malloc(sizeof(float) * wr * hr);
 #pragma omp parallel for schedule(static)
         for (long y = 0; y < (long)hr; ++y)
-            memcpy(pix[c] + (size_t)y * wr, d->coeff[c] + (size_t)y * d->coeff_stride, sizeof(float) * wr);
+            memcpy(pix[c] + (size_t)y * wr, (const int32_t*)d->coeff[c] + (size_t)y * d->coeff_stride, sizeof(float) * wr);
     }
     size_t gpr = (d->width + d->group_dim - 1) / d->group_dim;
     size_t gpc = (d->height + d->group_dim - 1) / d->group_dim;
@@ -523,8 +526,10 @@ int jxl_oracle_vardct_render(const JxlGpuVardctDesc* d, uint32_t stages, float* 
     for (long g = 0; g < (long)(gpr * gpc); ++g)
         transform_group(d, &m, pix, wr, lfc, (size_t)g % gpr, (size_t)g / gpr);
 
-    int rc = orc_post_stages(pix, wr, d->width, d->height, m.sigma, w8, &d->filter, &d->upsampling,
-                             &d->color, stages, out, out_stride);
+    /* render.rs:175-180: noise correlates X and B with the frame's base correlations */
+    int rc = orc_post_stages(pix, wr, d->width, d->height, m.sigma, w8, &d->filter, &d->upsampling, &d->noise,
+                             d->group_dim, d->base_correlation_x, d->base_correlation_b, &d->color, stages, out,
+                             out_stride);
     for (int c = 0; c < 3; ++c) { free(pix[c]); free(lf[c]); }
     free_frame_meta(&m);
     return rc;

@@ -92,6 +92,25 @@ def test_render_xyb_tail(gpu_ctx, oracle, cfg):
     assert_ulp(got, exp, 1, f"modular render {cfg}")
 
 
+@pytest.mark.parametrize("kind", ["squeeze", "lossless_rgb8"])
+def test_render_with_noise(gpu_ctx, oracle, kind):
+    """Noise on Modular frames: base correlations (0, 1) (noise.rs:35), on XYB and on plain RGB."""
+    from jxl_oxide_amd.synth import make_noise_params
+    wl = ModularWorkload(300, 264, kind=kind, lossy=True, epf_iters=1 if kind == "squeeze" else 0)
+    wl.noise = make_noise_params(3)
+    d = wl.desc()
+    stages = abi.STAGE_ALL | abi.STAGE_MODULAR_TO_FLOAT
+    exp = oracle.modular_render(d, stages, 300, 264)
+    off = oracle.modular_render(d, stages & ~abi.STAGE_NOISE, 300, 264)
+    assert np.abs(exp - off).max() > 1e-3
+    f = gpu_ctx.modular_upload(d)
+    try:
+        got = gpu_ctx.modular_render(f, stages)
+    finally:
+        f.free()
+    assert_ulp(got, exp, 1, f"modular noise {kind}")
+
+
 def test_render_rgb8_no_colour_transform(gpu_ctx, oracle):
     wl = ModularWorkload(256, 256, kind="lossless_rgb8")
     d = wl.desc()

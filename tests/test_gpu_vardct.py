@@ -121,6 +121,32 @@ def test_colour_op_lists(gpu_ctx, oracle, mode, it):
     assert_ulp(got2, exp2, MAX_ULP, f"colour {mode} (colour-only stage)")
 
 
+@pytest.mark.parametrize("w,h,up,epf", [(520, 300, 1, 2), (264, 200, 1, 0), (72, 56, 2, 1), (40, 24, 8, 1), (257, 3, 1, 1)])
+def test_noise_synthesis(gpu_ctx, oracle, w, h, up, epf):
+    """xorshift128+ noise with GF(2) jump-ahead, ring-ordered 5x5 kernel, LUT
+    modulation; between upsampling and the colour transform."""
+    wl = VardctWorkload(w, h, seed=50 + w, epf_iters=epf, gabor=epf > 0, upsampling=up, noise=True)
+    got, exp = _both(gpu_ctx, oracle, wl, S_ALL)
+    assert_ulp(got, exp, MAX_ULP, f"noise {w}x{h} up{up}")
+    # and it is not a no-op
+    off, _ = oracle.vardct_render(wl.desc(), S_ALL & ~abi.STAGE_NOISE, *wl.out_size(S_ALL))
+    assert np.abs(off - exp).max() > 1e-3
+    # stopping before the colour transform exposes the noisy XYB planes
+    got2, exp2 = _both(gpu_ctx, oracle, wl, S_ALL & ~abi.STAGE_COLOR)
+    assert_ulp(got2, exp2, MAX_ULP, f"noise {w}x{h} up{up} (XYB)")
+
+
+def test_noise_where_the_reference_panics_is_refused(gpu_ctx):
+    wl = VardctWorkload(40, 257, seed=5, noise=True)
+    frame = gpu_ctx.vardct_upload(wl.desc())
+    try:
+        with pytest.raises(Exception) as e:
+            gpu_ctx.vardct_render(frame, S_ALL)
+        assert e.value.code == abi.ERR_UNSUPPORTED
+    finally:
+        frame.free()
+
+
 def test_hlg_is_refused(gpu_ctx):
     wl = VardctWorkload(64, 64, seed=5)
     wl.color.transfer_function = abi.TF_HLG
@@ -135,6 +161,35 @@ def test_upsampling(gpu_ctx, oracle, factor):
     got, exp = _both(gpu_ctx, oracle, wl, S_ALL)
     assert got.shape == (3, 56 * factor, 72 * factor)
     assert_ulp(got, exp, MAX_ULP, f"upsampling x{factor}")
+
+
+@pytest.mark.parametrize("transport,split", [("dense_i16", False), ("sparse_i32", False), ("sparse_i16", False),
+                                             ("sparse_i32", True)])
+def test_compact_coefficient_transport(gpu_ctx, oracle, transport, split):
+    """16-bit planes / (position, value) lists rebuild the reference's dense i32
+    framebuffer on the device; the oracle always sees the dense form."""
+    wl = VardctWorkload(520, 264, seed=41)
+    exp, _ = oracle.vardct_render(wl.desc(), S_ALL, wl.width, wl.height)
+    frame = gpu_ctx.vardct_upload(wl.desc(coeff_transport=transport, sparse_split=split))
+    try:
+        got = gpu_ctx.vardct_render(frame, S_ALL)
+    finally:
+        frame.free()
+    assert_ulp(got, exp, MAX_ULP, f"{transport} split={split}")
+
+
+def test_sparse_position_outside_frame_is_rejected(gpu_ctx):
+    import ctypes as C
+    wl = VardctWorkload(64, 64, seed=5)
+    d = wl.desc(coeff_transport="sparse_i32")
+    pos = np.array([64 * 64 + 3], dtype=np.uint32)
+    val = np.array([7], dtype=np.int32)
+    d.coeff[1] = val.ctypes.data
+    d.sparse_pos[1] = pos.ctypes.data_as(C.POINTER(C.c_uint32))
+    d.sparse_count[1] = 1
+    with pytest.raises(Exception) as e:
+        gpu_ctx.vardct_upload(d)
+    assert e.value.code == abi.ERR_INVALID_ARG
 
 
 def test_render_host_one_shot(gpu_ctx, oracle):
