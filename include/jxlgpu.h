@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 7u
+#define JXLGPU_ABI_VERSION 8u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -316,11 +316,18 @@ typedef struct {
     const JxlGpuModularChannel* meta_channels;
     uint32_t num_transforms;     /* in bitstream order; the inverse runs them in reverse             */
     const JxlGpuTransform* transforms;
-    /* M4, predictor application where it is separable from the entropy decode: 0xFFFFFFFF = the
-     * channel buffers already hold reconstructed samples; 5 = they hold Gradient-predictor
-     * residuals of a single-leaf tree (`decode_simple_grad`, jxl-modular/src/image.rs:821-872),
-     * applied per group_dim x group_dim tile.  Anything else: JXLGPU_ERR_UNSUPPORTED.               */
+    /* M4, predictor application where it is separable from the entropy decode: a single-leaf MA
+     * tree (`decode_single_node`, jxl-modular/src/image.rs:716-777), so that
+     *     sample = residual * multiplier + offset + predict(neighbours)      (decode_one, :878-890)
+     * 0xFFFFFFFF = the channel buffers already hold reconstructed samples; 0..13 = they hold the
+     * residuals (`unpack_signed` tokens) of that Predictor (jxl-modular/src/predictor.rs:26-41),
+     * applied per group_dim x group_dim tile with a fresh PredictorState per tile.  6 =
+     * SelfCorrecting with `wp_params`.  MA trees with more than one leaf choose the entropy-coding
+     * context from the neighbours, so they stay with the entropy decoder on the host.             */
     uint32_t residual_predictor;
+    int32_t residual_multiplier; /* MaTreeLeafClustered.multiplier (1 for a default leaf)            */
+    int32_t residual_offset;     /* MaTreeLeafClustered.offset                                       */
+    int32_t wp_params[11];       /* WpHeader: p1, p2, p3a..p3e, w0..w3 (predictor.rs:8-21)           */
     uint32_t group_dim;
     /* what happens after the inverse transforms (jxl-render/src/image.rs:93-189) */
     uint32_t xyb_encoded;        /* 1: convert_modular_xyb (M5); 0: int -> float by bit depth (C5)    */

@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -212,6 +212,9 @@ class ModularDesc(C.Structure):
         ("num_transforms", C.c_uint32),
         ("transforms", C.POINTER(Transform)),
         ("residual_predictor", C.c_uint32),
+        ("residual_multiplier", C.c_int32),
+        ("residual_offset", C.c_int32),
+        ("wp_params", C.c_int32 * 11),
         ("group_dim", C.c_uint32),
         ("xyb_encoded", C.c_uint32),
         ("m_lf_unscaled", C.c_float * 3),

@@ -8,9 +8,47 @@
 
 #include <algorithm>
 #include <new>
+#include <thread>
 
 #include "common.h"
 #include "pixel_device.h"  // linear_to_pq_dev (host+device) for the tone-map constants
+
+hipError_t ctx_dev_malloc(jxlgpu_ctx* ctx, void** out, size_t bytes) {
+    bytes = std::max<size_t>(bytes, 16);
+    auto it = ctx->pool.find(bytes);
+    if (it != ctx->pool.end()) {
+        *out = it->second;
+        ctx->pool.erase(it);
+        ctx->pool_bytes -= bytes;
+        ctx->live[*out] = bytes;
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory && !ctx->pool.empty()) {  // give the pooled memory back and retry
+        (void)hipGetLastError();
+        for (auto& kv : ctx->pool) (void)hipFree(kv.second);
+        ctx->pool.clear();
+        ctx->pool_bytes = 0;
+        e = hipMalloc(out, bytes);
+    }
+    if (e == hipSuccess) ctx->live[*out] = bytes;
+    return e;
+}
+
+// The caller guarantees that no queued work still touches `p` (frame_free synchronises first).
+void ctx_dev_release(jxlgpu_ctx* ctx, void* p) {
+    if (!p) return;
+    auto it = ctx->live.find(p);
+    if (it == ctx->live.end()) { (void)hipFree(p); return; }
+    const size_t bytes = it->second;
+    ctx->live.erase(it);
+    if (ctx->pool_bytes + bytes <= ctx->pool_cap) {
+        ctx->pool.emplace(bytes, p);
+        ctx->pool_bytes += bytes;
+    } else {
+        (void)hipFree(p);
+    }
+}
 
 void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
                        float* const out[3], uint32_t out_stride, bool gabor, int epf_iters, bool color,
@@ -61,7 +99,7 @@ template <typename T>
 int dev_alloc(jxlgpu_ctx* ctx, jxlgpu_frame* f, T** out, size_t count) {
     void* p = nullptr;
     size_t bytes = std::max<size_t>(count * sizeof(T), 16);
-    HIP_TRY(ctx, hipMalloc(&p, bytes));
+    HIP_TRY(ctx, ctx_dev_malloc(ctx, &p, bytes));
     f->allocs.push_back(p);
     *out = static_cast<T*>(p);
     return JXLGPU_OK;
@@ -79,10 +117,16 @@ int dev_upload(jxlgpu_ctx* ctx, jxlgpu_frame* f, T** out, const std::vector<T>& 
 
 // temporaries of the upload (freed when it returns, after a stream sync)
 struct Scratch {
+    jxlgpu_ctx* ctx = nullptr;
     std::vector<void*> ptrs;
-    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
-    int alloc(jxlgpu_ctx* ctx, void** out, size_t bytes) {
-        HIP_TRY(ctx, hipMalloc(out, std::max<size_t>(bytes, 16)));
+    ~Scratch() {
+        if (ptrs.empty()) return;
+        (void)hipStreamSynchronize(ctx->stream);  // error paths may leave kernels reading these
+        for (void* p : ptrs) ctx_dev_release(ctx, p);
+    }
+    int alloc(jxlgpu_ctx* c, void** out, size_t bytes) {
+        ctx = c;
+        HIP_TRY(c, ctx_dev_malloc(c, out, bytes));
         ptrs.push_back(*out);
         return JXLGPU_OK;
     }
@@ -224,6 +268,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     jxlgpu_ctx* ctx = new (std::nothrow) jxlgpu_ctx();
     if (!ctx) return JXLGPU_ERR_OOM;
     ctx->device = device;
+    if (const char* mb = getenv("JXLGPU_POOL_MB")) ctx->pool_cap = (size_t)strtoull(mb, nullptr, 10) << 20;
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
@@ -244,7 +289,9 @@ void jxlgpu_destroy(jxlgpu_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (hipEvent_t e : ctx->ev_d2h) if (e) (void)hipEventDestroy(e);
     if (ctx->noise_jump) (void)hipFree(ctx->noise_jump);
+    for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete ctx;
 }
@@ -289,7 +336,10 @@ void jxlgpu_frame_free(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    for (void* p : f->allocs) (void)hipFree(p);
+    for (void* p : f->allocs) {
+        if (ctx) ctx_dev_release(ctx, p);
+        else (void)hipFree(p);
+    }
     if (f->modular && f->modular_free) f->modular_free(f->modular);
     delete f;
 }
@@ -680,6 +730,28 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
     return JXLGPU_OK;
 }
 
+// Host-side copy out of the pinned staging buffer, split over a few threads (one memcpy stream
+// moves ~10 GB/s; the PCIe link delivers ~50).
+void parallel_copy_rows(char* dst, size_t dst_stride, const char* src, size_t src_stride, size_t row_bytes,
+                        uint32_t rows) {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned nt = std::min<unsigned>(8, hw ? hw : 1);
+    if ((size_t)rows * row_bytes < ((size_t)4 << 20) || rows < nt) nt = 1;
+    auto work = [=](uint32_t y0, uint32_t y1) {
+        if (dst_stride == row_bytes && src_stride == row_bytes) {
+            memcpy(dst + (size_t)y0 * row_bytes, src + (size_t)y0 * row_bytes, (size_t)(y1 - y0) * row_bytes);
+        } else {
+            for (uint32_t y = y0; y < y1; ++y) memcpy(dst + (size_t)y * dst_stride, src + (size_t)y * src_stride, row_bytes);
+        }
+    };
+    if (nt == 1) { work(0, rows); return; }
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < nt; ++i)
+        th.emplace_back(work, (uint32_t)((uint64_t)rows * i / nt), (uint32_t)((uint64_t)rows * (i + 1) / nt));
+    work(0, (uint32_t)((uint64_t)rows / nt));
+    for (auto& t : th) t.join();
+}
+
 int finish_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stride, uint32_t ow, uint32_t oh,
                   const JxlGpuOut* out) {
     for (int c = 0; c < 3; ++c) f->result[c] = cur[c];
@@ -702,14 +774,21 @@ int finish_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stri
                 HIP_TRY(ctx, hipHostMalloc(&ctx->pinned, plane * 3, hipHostMallocDefault));
                 ctx->pinned_size = plane * 3;
             }
-            for (int c = 0; c < 3; ++c)
+            // Plane c lands in its third of the staging buffer; while plane c+1 is still crossing
+            // PCIe, worker threads move plane c into the caller's grid.
+            for (int c = 0; c < 3; ++c) {
+                if (!ctx->ev_d2h[c]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_d2h[c], hipEventDisableTiming));
                 HIP_TRY(ctx, hipMemcpy2DAsync((char*)ctx->pinned + plane * c, (size_t)ow * 4, cur[c], (size_t)stride * 4,
                                               (size_t)ow * 4, oh, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            for (int c = 0; c < 3; ++c)
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_d2h[c], ctx->stream));
+            }
+            for (int c = 0; c < 3; ++c) {
+                HIP_TRY(ctx, hipEventSynchronize(ctx->ev_d2h[c]));
                 if (out->planes[c])
-                    for (uint32_t y = 0; y < oh; ++y)
-                        memcpy(out->planes[c] + (size_t)y * out->stride, (char*)ctx->pinned + plane * c + (size_t)y * ow * 4, (size_t)ow * 4);
+                    parallel_copy_rows((char*)out->planes[c], (size_t)out->stride * 4, (const char*)ctx->pinned + plane * c,
+                                       (size_t)ow * 4, (size_t)ow * 4, oh);
+            }
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
     }
     return JXLGPU_OK;

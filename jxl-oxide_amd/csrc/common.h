@@ -5,7 +5,9 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/jxlgpu.h"
@@ -113,7 +115,14 @@ struct jxlgpu_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: 64-pixel varblock kernels overlap the <=32 kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_d2h[3] = {};      // one per output plane: host copy-out overlaps the next plane's D2H
     std::string last_error;
+    // Device-buffer pool: frames of one stream of images have the same sizes, so the ~25 buffers of
+    // a freed frame are handed to the next upload instead of going through hipFree/hipMalloc
+    // (each an implicit device-wide synchronisation).  Exact-size reuse; capped (JXLGPU_POOL_MB).
+    std::unordered_map<void*, size_t> live;
+    std::multimap<size_t, void*> pool;
+    size_t pool_bytes = 0, pool_cap = (size_t)8 << 30;
     void* noise_jump = nullptr; // device copy of the xorshift128+ jump matrices (noise_kernels.hip)
     void* pinned = nullptr;     // pinned staging buffer (grown on demand)
     size_t pinned_size = 0;
@@ -224,6 +233,9 @@ void launch_nometa_groups(hipStream_t s, const TransformArgs& a, const uint32_t*
                           uint32_t count, uint32_t group_dim, uint32_t groups_per_row);
 void launch_gabor(hipStream_t s, const FilterArgs& a);
 void launch_epf(hipStream_t s, int step, const FilterArgs& a);
+// api.hip: pooled device memory (see jxlgpu_ctx::pool)
+hipError_t ctx_dev_malloc(jxlgpu_ctx* ctx, void** out, size_t bytes);
+void ctx_dev_release(jxlgpu_ctx* ctx, void* p);
 size_t noise_jump_table_bytes();
 const void* noise_jump_table_host();
 bool noise_geometry_unsupported(uint32_t height, uint32_t group_dim);

@@ -68,7 +68,7 @@ extern "C" int jxlgpu_frame_format_output(jxlgpu_ctx* ctx, jxlgpu_frame* f, cons
     if (out_mem != JXLGPU_MEM_DEVICE) {
         if (f->fmt_bytes < bytes) {
             void* p = nullptr;
-            HIP_TRY(ctx, hipMalloc(&p, bytes));
+            HIP_TRY(ctx, ctx_dev_malloc(ctx, &p, bytes));
             f->allocs.push_back(p);
             f->fmt_buf = p;
             f->fmt_bytes = bytes;

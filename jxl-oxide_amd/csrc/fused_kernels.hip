@@ -487,7 +487,7 @@ void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3],
                 for (int tx = 0; tx < ntx; ++tx)
                     if (tx < 1 || tx >= tx_hi || ty < 1 || ty >= ty_hi) ring.push_back((uint32_t)tx | ((uint32_t)ty << 16));
             void* p = nullptr;
-            if (hipMalloc(&p, ring.size() * 4) != hipSuccess) return;
+            if (ctx_dev_malloc(ctx, &p, ring.size() * 4) != hipSuccess) return;
             f->allocs.push_back(p);
             (void)hipMemcpy(p, ring.data(), ring.size() * 4, hipMemcpyHostToDevice);
             f->ring_tiles = static_cast<uint32_t*>(p);

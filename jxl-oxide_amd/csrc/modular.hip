@@ -77,11 +77,13 @@ template <>
 struct Wrap<int16_t> {
     static __device__ __forceinline__ int16_t add(int16_t a, int16_t b) { return (int16_t)(a + b); }
     static __device__ __forceinline__ int16_t sub(int16_t a, int16_t b) { return (int16_t)(a - b); }
+    static __device__ __forceinline__ int16_t mul(int16_t a, int16_t b) { return (int16_t)(a * b); }
 };
 template <>
 struct Wrap<int32_t> {
     static __device__ __forceinline__ int32_t add(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
     static __device__ __forceinline__ int32_t sub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+    static __device__ __forceinline__ int32_t mul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
 };
 
 struct SqzArgs {
@@ -514,6 +516,206 @@ __global__ __launch_bounds__(256) void gradient_kernel(void* buf, uint32_t strid
     }
 }
 
+// ---------------------------------------------------------------- device: M4, any single-leaf predictor
+// decode_single_node_slow / decode_one (jxl-modular/src/image.rs:878-949) for one tile per
+// workgroup: sample = residual * multiplier + offset + predict(neighbours), Wrapping<S>.
+// Lane r owns row r and trails row r-1 by three columns (NEE and the self-correcting predictor's
+// NE error reach two columns ahead in the previous row), one workgroup barrier per step.  The
+// neighbour registers (w, n, nw) and the self-correcting predictor's error registers follow
+// PredictorState / Properties::record (predictor.rs:540-577) and SelfCorrectingPredictor
+// (predictor.rs:312-441) statement by statement; its two error rows live in LDS and are
+// overwritten in place exactly like the reference's `true_err_row` / `subpred_err_row`.
+struct PredArgs {
+    void* buf;
+    uint32_t stride, width, height, group_dim, predictor;
+    int32_t mul, off;
+    int32_t wp[11];
+};
+
+__device__ __forceinline__ uint32_t div_lookup_dev(uint32_t i) { return i == 0 ? 0u : (1u << 24) / i; }  // predictor.rs:150-160
+
+template <typename S>
+__global__ __launch_bounds__(256) void predict_kernel(PredArgs a) {
+    __shared__ int32_t s_true_err[256];
+    __shared__ uint32_t s_sub_err[4][256];
+    S* base = (S*)a.buf;
+    const uint32_t x0 = blockIdx.x * a.group_dim, y0 = blockIdx.y * a.group_dim;
+    const uint32_t gw = min(a.group_dim, a.width - x0), gh = min(a.group_dim, a.height - y0);
+    const uint32_t r = threadIdx.x;
+    S* row = base + (size_t)(y0 + r) * a.stride + x0;
+    const S* prev = row - a.stride;
+    const S* prev2 = prev - a.stride;
+    const bool active = r < gh;
+    const bool sc_on = a.predictor == 6;
+    s_true_err[r] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_sub_err[i][r] = 0;
+    __syncthreads();
+
+    // PredictorState registers
+    int32_t w = 0, n = 0, nw = 0, ww1 = 0 /* sample at x-1 */, ww2 = 0 /* sample at x-2 */;
+    // SelfCorrectingPredictor registers
+    int32_t te_w = 0, te_nw = 0, te_n = 0, te_ne = 0;
+    uint32_t se_nw_ww[4] = {0, 0, 0, 0}, se_n_w[4] = {0, 0, 0, 0}, se_ne[4] = {0, 0, 0, 0};
+
+    const uint32_t steps = gw + 3 * (gh - 1);
+    for (uint32_t s = 0; s < steps; ++s) {
+        const int32_t x = (int32_t)s - 3 * (int32_t)r;
+        if (active && x >= 0 && x < (int32_t)gw) {
+            if (x == 0) {
+                // state at a row start: reset() for row 0, the row-end branch of record() otherwise
+                if (r == 0) {
+                    w = n = nw = 0;
+                } else {
+                    w = n = nw = (int32_t)prev[0];
+                    if (sc_on) {
+                        te_w = 0;
+                        te_n = s_true_err[0];
+                        te_nw = te_n;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { se_n_w[i] = s_sub_err[i][0]; se_nw_ww[i] = se_n_w[i]; }
+                        if (gw <= 1) {
+                            te_ne = te_n;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) se_ne[i] = se_n_w[i];
+                        } else {
+                            te_ne = s_true_err[1];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) se_ne[i] = s_sub_err[i][1];
+                        }
+                    }
+                }
+            }
+            // neighbours beyond w / n / nw (predictor.rs:226-273, EDGE = true everywhere)
+            const bool no_prev = r == 0;
+            const int32_t ne = (no_prev || x + 1 >= (int32_t)gw) ? n : (int32_t)prev[x + 1];
+            const int32_t nee = (no_prev || x + 2 >= (int32_t)gw) ? ne : (int32_t)prev[x + 2];
+            const int32_t nn = r >= 2 ? (int32_t)prev2[x] : n;
+            const int32_t ww = x >= 2 ? ww2 : w;
+
+            int64_t sc_prediction = 0, subpred[4] = {0, 0, 0, 0};
+            if (sc_on) {
+                const int64_t tw = te_w, tnw = te_nw, tn = te_n, tne = te_ne;
+                const int64_t n3 = (int64_t)n * 8, nw3 = (int64_t)nw * 8, ne3 = (int64_t)ne * 8, w3 = (int64_t)w * 8,
+                              nn3 = (int64_t)nn * 8;
+                subpred[0] = w3 + ne3 - n3;
+                subpred[1] = n3 - (((tw + tn + tne) * (int64_t)a.wp[0]) >> 5);
+                subpred[2] = w3 - (((tw + tn + tnw) * (int64_t)a.wp[1]) >> 5);
+                subpred[3] = n3 - ((tnw * (int64_t)a.wp[2] + tn * (int64_t)a.wp[3] + tne * (int64_t)a.wp[4] +
+                                    (nn3 - n3) * (int64_t)a.wp[5] + (nw3 - w3) * (int64_t)a.wp[6]) >> 5);
+                uint32_t weight[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t err_sum = se_nw_ww[i] + se_n_w[i] + se_ne[i];
+                    const uint64_t t = ((uint64_t)err_sum + 1) >> 5;
+                    const uint32_t shift = t ? 63u - (uint32_t)__builtin_clzll(t) : 0u;
+                    weight[i] = 4 + (((uint32_t)a.wp[7 + i] * div_lookup_dev((err_sum >> shift) + 1)) >> shift);
+                }
+                uint32_t sum_weights = weight[0] + weight[1] + weight[2] + weight[3];
+                const uint32_t log_weight = 31u - (uint32_t)__builtin_clz(sum_weights >> 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) weight[i] >>= log_weight;
+                sum_weights = weight[0] + weight[1] + weight[2] + weight[3];
+                int64_t acc = ((int64_t)sum_weights >> 1) - 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc += subpred[i] * (int64_t)weight[i];
+                int64_t prediction = (acc * (int64_t)div_lookup_dev(sum_weights)) >> 24;
+                if (((tn ^ tw) | (tn ^ tnw)) <= 0) {
+                    const int64_t mn = min(min(n3, w3), ne3), mx = max(max(n3, w3), ne3);
+                    prediction = prediction < mn ? mn : (prediction > mx ? mx : prediction);
+                }
+                sc_prediction = prediction;
+            }
+
+            // Predictor::predict, predictor.rs:79-125
+            int32_t pred;
+            {
+                const int64_t N = n, W = w, NW = nw;
+                switch (a.predictor) {
+                    case 0: pred = 0; break;
+                    case 1: pred = w; break;
+                    case 2: pred = n; break;
+                    case 3: pred = (int32_t)((W + N) / 2); break;
+                    case 4: {
+                        const int64_t dn = N > NW ? N - NW : NW - N, dw = W > NW ? W - NW : NW - W;
+                        pred = dn < dw ? w : n;
+                        break;
+                    }
+                    case 5: {
+                        const int64_t g = N + W - NW, lo = W < N ? W : N, hi = W > N ? W : N;
+                        pred = (int32_t)(g < lo ? lo : (g > hi ? hi : g));
+                        break;
+                    }
+                    case 6: pred = (int32_t)((sc_prediction + 3) >> 3); break;
+                    case 7: pred = ne; break;
+                    case 8: pred = nw; break;
+                    case 9: pred = ww; break;
+                    case 10: pred = (int32_t)((W + NW) / 2); break;
+                    case 11: pred = (int32_t)((N + NW) / 2); break;
+                    case 12: pred = (int32_t)((N + (int64_t)ne) / 2); break;
+                    default:
+                        pred = (int32_t)((6 * N - 2 * (int64_t)nn + 7 * W + (int64_t)ww + (int64_t)nee + 3 * (int64_t)ne + 8) / 16);
+                        break;
+                }
+            }
+            // decode_one: diff = residual.wrapping_muladd_i32(multiplier, offset); diff.add(prediction)
+            const S diff = Wrap<S>::add(Wrap<S>::mul(row[x], (S)a.mul), (S)a.off);
+            const S value = Wrap<S>::add(diff, (S)pred);
+            row[x] = value;
+            const int32_t sample = (int32_t)value;
+
+            if (sc_on) {
+                // SelfCorrectingPredictor::record, predictor.rs:394-441 (the row-end branch is the
+                // x == 0 block above, run by the next row's lane)
+                const int64_t s8 = (int64_t)sample * 8;
+                const int64_t true_err = sc_prediction - s8;
+                uint32_t sub_err[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t d = subpred[i] - s8;
+                    sub_err[i] = (uint32_t)(((uint64_t)(d < 0 ? -d : d) + 3) >> 3);
+                }
+                s_true_err[x] = (int32_t)true_err;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_sub_err[i][x] = sub_err[i];
+                if (x + 1 < (int32_t)gw) {
+                    te_w = (int32_t)true_err;
+                    te_nw = te_n;
+                    te_n = te_ne;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        se_nw_ww[i] = se_n_w[i];
+                        se_n_w[i] = se_ne[i] + sub_err[i];
+                    }
+                    if (x + 2 >= (int32_t)gw) {
+                        te_ne = te_n;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) se_ne[i] = se_n_w[i];
+                    } else if (r != 0) {
+                        te_ne = s_true_err[x + 2];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) se_ne[i] = s_sub_err[i][x + 2];
+                    }
+                }
+            }
+            // Properties::record, predictor.rs:552-576 (not at a row end)
+            if (x + 1 < (int32_t)gw) {
+                ww2 = ww1;
+                ww1 = sample;
+                w = sample;
+                if (r == 0) {
+                    nw = sample;
+                    n = sample;
+                } else {
+                    nw = n;
+                    n = (int32_t)prev[x + 1];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- device: int -> float
 struct ToFloatArgs {
     const void* in[3];
@@ -617,7 +819,7 @@ void default_squeeze(const std::vector<Grid>& l, int nb_meta, std::vector<JxlGpu
 template <typename T>
 int malloc_dev(jxlgpu_ctx* ctx, jxlgpu_frame* f, T** out, size_t bytes) {
     void* p = nullptr;
-    HIP_TRY(ctx, hipMalloc(&p, std::max<size_t>(bytes, 16)));
+    HIP_TRY(ctx, ctx_dev_malloc(ctx, &p, std::max<size_t>(bytes, 16)));
     f->allocs.push_back(p);
     *out = static_cast<T*>(p);
     return JXLGPU_OK;
@@ -671,12 +873,24 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     for (uint32_t c = 0; c < nch; ++c)
         HIP_TRY(ctx, hipMemcpyAsync(m->work[0][c], m->orig[c], (size_t)m->cw[c] * m->ch[c] * esz, hipMemcpyDeviceToDevice, s));
 
-    if (m->desc.residual_predictor == 5) {
+    if (m->desc.residual_predictor <= 13) {
         const uint32_t gd = m->desc.group_dim ? m->desc.group_dim : 256;
+        // decode_single_node's dispatch (image.rs:733-777)
+        const bool simple_grad = m->desc.residual_predictor == 5 && m->desc.residual_offset == 0 && m->desc.residual_multiplier == 1;
         for (uint32_t c = 0; c < nch; ++c) {
             dim3 grid(ceil_div(m->cw[c], gd), ceil_div(m->ch[c], gd));
-            if (i16) gradient_kernel<int16_t><<<grid, 256, 0, s>>>(m->work[0][c], m->cw[c], m->cw[c], m->ch[c], gd);
-            else gradient_kernel<int32_t><<<grid, 256, 0, s>>>(m->work[0][c], m->cw[c], m->cw[c], m->ch[c], gd);
+            if (simple_grad) {
+                if (i16) gradient_kernel<int16_t><<<grid, 256, 0, s>>>(m->work[0][c], m->cw[c], m->cw[c], m->ch[c], gd);
+                else gradient_kernel<int32_t><<<grid, 256, 0, s>>>(m->work[0][c], m->cw[c], m->cw[c], m->ch[c], gd);
+            } else {
+                PredArgs pa;
+                pa.buf = m->work[0][c]; pa.stride = m->cw[c]; pa.width = m->cw[c]; pa.height = m->ch[c];
+                pa.group_dim = gd; pa.predictor = m->desc.residual_predictor;
+                pa.mul = m->desc.residual_multiplier; pa.off = m->desc.residual_offset;
+                for (int i = 0; i < 11; ++i) pa.wp[i] = m->desc.wp_params[i];
+                if (i16) predict_kernel<int16_t><<<grid, 256, 0, s>>>(pa);
+                else predict_kernel<int32_t><<<grid, 256, 0, s>>>(pa);
+            }
         }
     }
 
@@ -838,11 +1052,11 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
     *out_frame = nullptr;
     if (d->abi != JXLGPU_ABI_VERSION) return fail(ctx, JXLGPU_ERR_ABI, "descriptor ABI version mismatch");
     if (d->num_channels == 0 || !d->channels) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "no channels");
-    if (d->residual_predictor != 0xFFFFFFFFu && d->residual_predictor != 5)
-        return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "only Gradient (5) residuals are separable on the device; others stay with the entropy decoder");
+    if (d->residual_predictor != 0xFFFFFFFFu && d->residual_predictor > 13)
+        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "residual_predictor is neither 0xFFFFFFFF nor a Predictor (0..13)");
     if (d->xyb_encoded)
         if (const char* why = color_params_unsupported(d->color)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, why);
-    if (d->residual_predictor == 5 && d->group_dim > 256) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "gradient tiles larger than 256");
+    if (d->residual_predictor <= 13 && d->group_dim > 256) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tiles larger than 256");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     jxlgpu_frame* f = new (std::nothrow) jxlgpu_frame();
     ModularState* m = new (std::nothrow) ModularState();

@@ -105,8 +105,11 @@ class Context:
         self._check(self.lib.jxlgpu_vardct_render(self.handle, frame.handle, stages, C.byref(o)))
         return out
 
-    def vardct_render_host(self, desc, stages, out_w, out_h):
-        out = np.zeros((3, out_h, out_w), dtype=np.float32)
+    def vardct_render_host(self, desc, stages, out_w, out_h, out=None):
+        """One-shot host-to-host call.  `out`: optional preallocated (3, out_h, out_w) float32 array
+        (a decoder reuses its frame buffers; a fresh np.zeros pays a page fault per 4 KB)."""
+        if out is None:
+            out = np.zeros((3, out_h, out_w), dtype=np.float32)
         o = abi.Out()
         for c in range(3):
             o.planes[c] = out[c].ctypes.data_as(abi.f32p)

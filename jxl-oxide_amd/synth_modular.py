@@ -161,13 +161,133 @@ def gradient_residuals(img, group_dim):
     return out
 
 
+def _tdiv(a, b):
+    """Integer division truncating toward zero (Rust `/` on i64)."""
+    q = np.abs(a) // b
+    return np.where(a < 0, -q, q)
+
+
+def predictor_residuals(img, group_dim, predictor, offset=0):
+    """Residuals of a single-leaf tree with one of the stateless predictors (all but 6) so that
+    `residual + offset + predict(neighbours)` rebuilds `img`, independently per tile.  The
+    neighbour rules are written from the format's definition (JPEG XL 18181-1 H.3: W = left, or
+    N at x = 0, or 0 at the origin; N = top or W; NW = top-left or W; NE = top-right or N;
+    NN = two up or N; NEE = two right of N or NE; WW = two left or W), vectorised over the
+    finished image — not from the decoder's running state."""
+    H, W = img.shape
+    out = np.zeros_like(img)
+    for y0 in range(0, H, group_dim):
+        for x0 in range(0, W, group_dim):
+            t = img[y0:y0 + group_dim, x0:x0 + group_dim].astype(np.int64)
+            h, w = t.shape
+            wv = np.zeros_like(t)
+            wv[:, 1:] = t[:, :-1]
+            wv[1:, 0] = t[:-1, 0]
+            n = wv.copy()
+            n[1:, :] = t[:-1, :]
+            nw = wv.copy()
+            nw[1:, 1:] = t[:-1, :-1]
+            ne = n.copy()
+            ne[1:, :-1] = t[:-1, 1:]
+            nn = n.copy()
+            nn[2:, :] = t[:-2, :]
+            nee = ne.copy()
+            nee[1:, :-2] = t[:-1, 2:]
+            ww = wv.copy()
+            ww[:, 2:] = t[:, :-2]
+            if predictor == 0: pred = np.zeros_like(t)
+            elif predictor == 1: pred = wv
+            elif predictor == 2: pred = n
+            elif predictor == 3: pred = _tdiv(wv + n, 2)
+            elif predictor == 4: pred = np.where(np.abs(n - nw) < np.abs(wv - nw), wv, n)
+            elif predictor == 5: pred = np.clip(n + wv - nw, np.minimum(n, wv), np.maximum(n, wv))
+            elif predictor == 7: pred = ne
+            elif predictor == 8: pred = nw
+            elif predictor == 9: pred = ww
+            elif predictor == 10: pred = _tdiv(wv + nw, 2)
+            elif predictor == 11: pred = _tdiv(n + nw, 2)
+            elif predictor == 12: pred = _tdiv(n + ne, 2)
+            elif predictor == 13: pred = _tdiv(6 * n - 2 * nn + 7 * wv + ww + nee + 3 * ne + 8, 16)
+            else: raise ValueError(predictor)
+            out[y0:y0 + h, x0:x0 + w] = t - pred - offset
+    return out
+
+
+DEFAULT_WP = [16, 10, 7, 7, 7, 0, 0, 13, 12, 12, 12]  # WpHeader defaults (predictor.rs:8-21)
+
+
+def weighted_residuals(img, group_dim, wp=DEFAULT_WP):
+    """Residuals for the self-correcting (weighted) predictor: a straight sequential Python
+    transcription of JPEG XL 18181-1 H.5 (error-weighted blend of four sub-predictors), run on the
+    true samples.  Slow; for small tiles only."""
+    H, W = img.shape
+    out = np.zeros_like(img)
+    p1, p2, p3a, p3b, p3c, p3d, p3e = wp[:7]
+    wmax = wp[7:11]
+    div = [0] + [(1 << 24) // i for i in range(1, 65)]
+    for y0 in range(0, H, group_dim):
+        for x0 in range(0, W, group_dim):
+            t = [[int(v) for v in row] for row in img[y0:y0 + group_dim, x0:x0 + group_dim]]
+            h, w = len(t), len(t[0])
+            terr = [[0] * w for _ in range(h)]                 # true_err(x, y)
+            serr = [[[0] * 4 for _ in range(w)] for _ in range(h)]  # sub-predictor errors
+            for y in range(h):
+                for x in range(w):
+                    def S(xx, yy):
+                        return t[yy][xx]
+                    Wv = S(x - 1, y) if x > 0 else (S(x, y - 1) if y > 0 else 0)
+                    N = S(x, y - 1) if y > 0 else Wv
+                    NW = S(x - 1, y - 1) if (x > 0 and y > 0) else Wv
+                    NE = S(x + 1, y - 1) if (x + 1 < w and y > 0) else N
+                    NN = S(x, y - 2) if y > 1 else N
+                    # error neighbours: zero outside the tile, except that N/NE fall back like samples
+                    def TE(xx, yy):
+                        return terr[yy][xx] if (0 <= xx < w and 0 <= yy < h) else 0
+                    te_w = TE(x - 1, y) if x > 0 else 0
+                    te_n = TE(x, y - 1) if y > 0 else 0
+                    te_nw = TE(x - 1, y - 1) if (x > 0 and y > 0) else te_n
+                    te_ne = TE(x + 1, y - 1) if (x + 1 < w and y > 0) else te_n
+                    def SE(xx, yy, i):
+                        return serr[yy][xx][i] if (0 <= xx < w and 0 <= yy < h) else 0
+                    n3, nw3, ne3, w3, nn3 = N << 3, NW << 3, NE << 3, Wv << 3, NN << 3
+                    sub = [w3 + ne3 - n3,
+                           n3 - (((te_w + te_n + te_ne) * p1) >> 5),
+                           w3 - (((te_w + te_n + te_nw) * p2) >> 5),
+                           n3 - ((te_nw * p3a + te_n * p3b + te_ne * p3c + (nn3 - n3) * p3d + (nw3 - w3) * p3e) >> 5)]
+                    weight = []
+                    for i in range(4):
+                        # err_sum = N + W + NW + WW + NE sub-errors (W and WW counted via the running sums)
+                        e_n = SE(x, y - 1, i) if y > 0 else 0
+                        e_w = SE(x - 1, y, i) if x > 0 else 0
+                        e_ww = SE(x - 2, y, i) if x > 1 else 0
+                        e_nw = SE(x - 1, y - 1, i) if (x > 0 and y > 0) else e_n   # NW falls back onto N
+                        e_ne = SE(x + 1, y - 1, i) if (x + 1 < w and y > 0) else e_n
+                        es = (e_n + e_w + e_ww + e_nw + e_ne) & 0xFFFFFFFF
+                        if x + 1 == w and x > 0:   # last column: NE folds onto N, which already carries W
+                            es = (es + e_w) & 0xFFFFFFFF
+                        shift = max(((es + 1) >> 5).bit_length() - 1, 0)
+                        weight.append(4 + ((wmax[i] * div[(es >> shift) + 1]) >> shift))
+                    lw = (sum(weight) >> 4).bit_length() - 1
+                    weight = [v >> lw for v in weight]
+                    sw = sum(weight)
+                    s_ = (sw >> 1) - 1 + sum(a * b for a, b in zip(sub, weight))
+                    pred = (s_ * div[sw]) >> 24
+                    if ((te_n ^ te_w) | (te_n ^ te_nw)) <= 0:
+                        pred = min(max(pred, min(n3, w3, ne3)), max(n3, w3, ne3))
+                    v = t[y][x]
+                    out[y0 + y, x0 + x] = v - ((pred + 3) >> 3)
+                    terr[y][x] = pred - (v << 3)
+                    serr[y][x] = [(abs(sp - (v << 3)) + 3) >> 3 for sp in sub]
+    return out
+
+
 class ModularWorkload:
     """kind: 'lossless_rgb8' (cfg 1: Gradient residuals + RCT), 'squeeze' (cfg 3: RCT/XYB ints +
     default Squeeze, optional lossy quantisation), 'palette', 'raw' (random data through explicit
     transforms, exercises wrapping)."""
 
     def __init__(self, width, height, kind="squeeze", seed=0, i16=True, lossy=True, rct_type=None,
-                 xyb=True, epf_iters=0, gabor=False, bit_depth=8):
+                 xyb=True, epf_iters=0, gabor=False, bit_depth=8, predictor=5, pred_offset=0):
         rng = np.random.default_rng(SEED_BASE + 0x100 + seed)
         self.width, self.height, self.kind = width, height, kind
         self.dtype = np.int16 if i16 else np.int32
@@ -181,9 +301,22 @@ class ModularWorkload:
         self.transforms = []
         self.meta = []
         self.residual_predictor = 0xFFFFFFFF
+        self.residual_multiplier, self.residual_offset = 1, 0
         self.expected = None  # exact integer result when the chain is lossless
 
-        if kind == "lossless_rgb8":
+        if kind == "predictor":
+            # single-leaf tree with an arbitrary predictor on plain RGB8 (no transforms)
+            rgb = [np.clip(p, 0, 255) for p in base]
+            self.expected = [p.astype(self.dtype) for p in rgb]
+            if predictor == 6:
+                chans = [weighted_residuals(p, 256) for p in rgb]
+            else:
+                chans = [predictor_residuals(p, 256, predictor, pred_offset) for p in rgb]
+            self.residual_predictor = predictor
+            self.residual_offset = pred_offset
+            self.buffers = [p.astype(self.dtype) for p in chans]
+
+        elif kind == "lossless_rgb8":
             rgb = [np.clip(p, 0, 255) for p in base]
             self.expected = [p.astype(self.dtype) for p in rgb]
             t = 6 if rct_type is None else rct_type
@@ -292,6 +425,9 @@ class ModularWorkload:
         d.num_transforms = len(self.transforms)
         d.transforms = C.cast(trs, C.POINTER(abi.Transform))
         d.residual_predictor = self.residual_predictor
+        d.residual_multiplier = self.residual_multiplier
+        d.residual_offset = self.residual_offset
+        d.wp_params[:] = DEFAULT_WP
         d.group_dim = 256
         d.xyb_encoded = 1 if self.xyb else 0
         d.m_lf_unscaled[:] = [(1.0 / 32.0) / 128.0, (1.0 / 4.0) / 128.0, (1.0 / 2.0) / 128.0]

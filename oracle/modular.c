@@ -290,9 +290,12 @@ int jxl_oracle_modular_inverse(const JxlGpuModularDesc* d, void* const* out) {
         w.meta[c] = malloc(n);
         memcpy(w.meta[c], d->meta_channels[c].data, n);
     }
-    /* M4: separable predictor application, per group_dim x group_dim tile (decode_simple_grad) */
-    if (d->residual_predictor == 5) {
+    /* M4: separable predictor application (single-leaf tree), per group_dim x group_dim tile.
+     * decode_single_node's dispatch (image.rs:733-777): Gradient with offset 0 / multiplier 1 takes
+     * decode_simple_grad, everything else decode_one with a fresh PredictorState (predict.c). */
+    if (d->residual_predictor <= 13) {
         uint32_t gd = d->group_dim ? d->group_dim : 256;
+        const int simple_grad = d->residual_predictor == 5 && d->residual_offset == 0 && d->residual_multiplier == 1;
         for (uint32_t c = 0; c < d->num_channels; ++c) {
             uint32_t W = d->channels[c].width, H = d->channels[c].height;
             long ngx = (W + gd - 1) / gd, ngy = (H + gd - 1) / gd;
@@ -300,12 +303,15 @@ int jxl_oracle_modular_inverse(const JxlGpuModularDesc* d, void* const* out) {
             for (long g = 0; g < ngx * ngy; ++g) {
                 uint32_t x0 = (uint32_t)(g % ngx) * gd, y0 = (uint32_t)(g / ngx) * gd;
                 uint32_t gw = W - x0 < gd ? W - x0 : gd, gh = H - y0 < gd ? H - y0 : gd;
-                if (esz == 2) gradient_apply_i16((int16_t*)w.bufs[c] + (size_t)y0 * W + x0, W, gw, gh);
+                if (!simple_grad)
+                    orc_predict_apply((char*)w.bufs[c] + ((size_t)y0 * W + x0) * esz, W, gw, gh, (int)esz,
+                                      d->residual_predictor, d->residual_multiplier, d->residual_offset, d->wp_params);
+                else if (esz == 2) gradient_apply_i16((int16_t*)w.bufs[c] + (size_t)y0 * W + x0, W, gw, gh);
                 else gradient_apply_i32((int32_t*)w.bufs[c] + (size_t)y0 * W + x0, W, gw, gh);
             }
         }
     } else if (d->residual_predictor != 0xFFFFFFFFu) {
-        return JXLGPU_ERR_UNSUPPORTED;
+        return JXLGPU_ERR_INVALID_ARG;
     }
 
     /* forward bookkeeping: which sub-rectangle is which transformed channel */

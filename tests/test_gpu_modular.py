@@ -71,6 +71,40 @@ def test_config1_lossless_rgb8(gpu_ctx, oracle, i16):
     _inverse_both(gpu_ctx, oracle, wl)
 
 
+@pytest.mark.parametrize("predictor", [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13])
+def test_single_leaf_predictors(gpu_ctx, oracle, predictor):
+    """M4: every stateless predictor, wavefront kernel vs oracle vs the original image."""
+    for (w, h, i16) in [(300, 270, True), (257, 3, False), (2, 40, True)]:
+        wl = ModularWorkload(w, h, kind="predictor", predictor=predictor, i16=i16, seed=predictor,
+                             pred_offset=(0 if predictor % 2 else 3))
+        got = _inverse_both(gpu_ctx, oracle, wl)
+        for c in range(3):
+            assert np.array_equal(got[c], wl.expected[c])
+
+
+@pytest.mark.parametrize("size,i16", [((40, 24), False), ((1, 9), True), ((9, 1), False), ((2, 2), True), ((70, 33), True)])
+def test_self_correcting_predictor(gpu_ctx, oracle, size, i16):
+    w, h = size
+    wl = ModularWorkload(w, h, kind="predictor", predictor=6, i16=i16, seed=w)
+    got = _inverse_both(gpu_ctx, oracle, wl)
+    for c in range(3):
+        assert np.array_equal(got[c], wl.expected[c])
+
+
+def test_self_correcting_predictor_full_tiles(gpu_ctx, oracle):
+    """300x270 = full 256-row tiles plus edge tiles; random residuals (the Python forward pass is
+    too slow at this size), device against oracle only, with a multiplier and an offset."""
+    wl = ModularWorkload(300, 270, kind="predictor", predictor=1, i16=False, seed=2)
+    rng = np.random.default_rng(9)
+    wl.buffers = [rng.integers(-40, 40, size=(270, 300)).astype(np.int32) for _ in range(3)]
+    wl.residual_predictor, wl.residual_multiplier, wl.residual_offset = 6, 3, -2
+    wl.expected = None
+    _inverse_both(gpu_ctx, oracle, wl)
+    wl.sample_type, wl.dtype = abi.SAMPLE_I16, np.int16
+    wl.buffers = [b.astype(np.int16) for b in wl.buffers]
+    _inverse_both(gpu_ctx, oracle, wl)
+
+
 def test_palette(gpu_ctx, oracle):
     wl = ModularWorkload(64, 48, kind="palette")
     got = _inverse_both(gpu_ctx, oracle, wl)
