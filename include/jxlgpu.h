@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 8u
+#define JXLGPU_ABI_VERSION 9u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -289,9 +289,10 @@ typedef struct {
     uint32_t kind;               /* JXLGPU_TR_*                                                    */
     /* Rct */
     uint32_t begin_c, rct_type;
-    /* Palette */
+    /* Palette (simple gather, implicit colours above nb_colours, delta entries below nb_deltas
+     * with the whole-channel d_pred predictor pass: transform/palette.rs:27-173) */
     uint32_t num_c, nb_colours, nb_deltas, d_pred;
-    int32_t wp_params[9];        /* WpHeader p1..p3[5], w[4] when d_pred == 6 (unsupported: slow path) */
+    int32_t wp_params[11];       /* WpHeader p1, p2, p3a..p3e, w0..w3 when d_pred == 6                  */
     /* Squeeze: explicit steps (after set_default_params, transform.rs:285-341) */
     uint32_t num_sq;
     const JxlGpuSqueezeStep* sq;

@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -190,7 +190,7 @@ class Transform(C.Structure):
         ("nb_colours", C.c_uint32),
         ("nb_deltas", C.c_uint32),
         ("d_pred", C.c_uint32),
-        ("wp_params", C.c_int32 * 9),
+        ("wp_params", C.c_int32 * 11),
         ("num_sq", C.c_uint32),
         ("sq", C.POINTER(SqueezeStep)),
     ]

@@ -459,21 +459,65 @@ struct PalArgs {
     void* dst[8];          // dst[0] = leader itself
     uint32_t pal_stride, idx_stride, dst_stride[8];
     uint32_t width, height, num_c, nb_colours;
-    int* not_simple;       // set to 1 when an index is outside [0, nb_colours)
+    int32_t nb_deltas;
+    uint32_t bit_depth;
+    uint8_t* need_delta;   // width x height: index < nb_deltas (palette.rs:63-65)
+    int* n_delta;          // how many such samples
 };
 
-// inverse_simple, palette.rs:146-173 (+ the is_simple scan, :37-45)
+// transform/palette.rs:11-24 (data table)
+__device__ constexpr int16_t kDeltaPalette[72][3] = {
+    {0, 0, 0}, {4, 4, 4}, {11, 0, 0}, {0, 0, -13}, {0, -12, 0}, {-10, -10, -10},
+    {-18, -18, -18}, {-27, -27, -27}, {-18, -18, 0}, {0, 0, -32}, {-32, 0, 0}, {-37, -37, -37},
+    {0, -32, -32}, {24, 24, 45}, {50, 50, 50}, {-45, -24, -24}, {-24, -45, -45}, {0, -24, -24},
+    {-34, -34, 0}, {-24, 0, -24}, {-45, -45, -24}, {64, 64, 64}, {-32, 0, -32}, {0, -32, 0},
+    {-32, 0, 32}, {-24, -45, -24}, {45, 24, 45}, {24, -24, -45}, {-45, -24, 24}, {80, 80, 80},
+    {64, 0, 0}, {0, 0, -64}, {0, -64, -64}, {-24, -24, 45}, {96, 96, 96}, {64, 64, 0},
+    {45, -24, -24}, {34, -34, 0}, {112, 112, 112}, {24, -45, -45}, {45, 45, -24}, {0, -32, 32},
+    {24, -24, 45}, {0, 96, 96}, {45, -24, 24}, {24, -45, -24}, {-24, -45, 24}, {0, -64, 0},
+    {96, 0, 0}, {128, 128, 128}, {64, 0, 64}, {144, 144, 144}, {96, 96, 0}, {-36, -36, 36},
+    {45, -24, -45}, {45, -45, -24}, {0, 0, -96}, {0, 128, 128}, {0, 96, 0}, {45, 24, -45},
+    {-128, 0, 0}, {24, -45, 24}, {-45, 24, -45}, {64, 0, -64}, {64, -64, -64}, {96, 0, 96},
+    {45, -45, 24}, {24, 45, -45}, {64, 64, -64}, {128, 128, 0}, {0, 0, -128}, {-24, 45, -45},
+};
+
+// Palette::inverse_inner's per-sample part (palette.rs:58-108): palette rows, the implicit 4x4x4 and
+// 5x5x5 colour cubes above nb_colours, the fixed delta palette below zero.  With only in-range
+// indices this is exactly inverse_simple (:146-173).
 template <typename S>
 __global__ __launch_bounds__(256) void palette_kernel(PalArgs g) {
     uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= g.width) return;
-    int32_t index = ((const S*)g.idx)[(size_t)y * g.idx_stride + x];
-    if (index < 0 || index >= (int32_t)g.nb_colours) {
-        atomicOr(g.not_simple, 1);
-        return;
+    const int32_t index = ((const S*)g.idx)[(size_t)y * g.idx_stride + x];
+    const int32_t nb_colors = (int32_t)g.nb_colours;
+    const bool delta = index < g.nb_deltas;
+    g.need_delta[(size_t)y * g.width + x] = delta ? 1 : 0;
+    if (delta) atomicAdd(g.n_delta, 1);
+    const int32_t maxv = (1 << g.bit_depth) - 1;
+    for (uint32_t c = g.num_c; c-- > 0;) {
+        int32_t v;
+        if (index >= 0 && index < nb_colors) {
+            v = ((const S*)g.palette)[(size_t)c * g.pal_stride + index];
+        } else if (index >= nb_colors) {
+            int32_t i2 = index - nb_colors;
+            if (i2 < 64) {
+                v = ((i2 >> (2 * c)) % 4) * maxv / 4 + (1 << (g.bit_depth > 3 ? g.bit_depth - 3 : 0));
+            } else {
+                int32_t i3 = i2 - 64;
+                for (uint32_t k = 0; k < c; ++k) i3 /= 5;
+                v = (i3 % 5) * maxv / 4;
+            }
+        } else if (c >= 3) {
+            v = 0;
+        } else {
+            int32_t i2 = (-(index + 1)) % 143;
+            int32_t t = kDeltaPalette[(i2 + 1) >> 1][c];
+            if ((i2 & 1) == 0) t = -t;
+            if (g.bit_depth > 8) t <<= (g.bit_depth < 24 ? g.bit_depth : 24) - 8;
+            v = t;
+        }
+        ((S*)g.dst[c])[(size_t)y * g.dst_stride[c] + x] = (S)v;
     }
-    for (uint32_t c = g.num_c; c-- > 0;)
-        ((S*)g.dst[c])[(size_t)y * g.dst_stride[c] + x] = ((const S*)g.palette)[(size_t)c * g.pal_stride + index];
 }
 
 // decode_simple_grad arithmetic (image.rs:821-872) on one group_dim x group_dim tile per
@@ -716,6 +760,225 @@ __global__ __launch_bounds__(256) void predict_kernel(PredArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- device: M3, delta-palette predictor pass
+// The predictor pass of Palette::inverse_inner (palette.rs:112-142): ONE PredictorState over the
+// whole channel, so the wavefront spans the image: workgroup b owns rows [256 b, 256 b + 256), lane r
+// trails lane r-1 by three columns, and lane 0 of workgroup b trails the last lane of workgroup
+// b-1 the same way through a progress counter in global memory (release/acquire at agent scope).
+// All workgroups of the launch are resident together (a few dozen), lower bands are dispatched
+// first, and the spin is bounded: if it ever expires the kernel raises `fail` and the host returns
+// JXLGPU_ERR_DEVICE instead of hanging.  `rec` holds the recorded i32 `sample_value`s
+// (palette.rs:130-139), which for i16 buffers may differ from the stored, truncated samples; the
+// self-correcting predictor's two error rows are global arrays overwritten in place, as in the
+// reference.
+struct DeltaArgs {
+    void* grid[3];
+    int32_t* rec[3];
+    uint32_t stride[3];
+    const uint8_t* need_delta;
+    uint32_t width, height, d_pred;
+    int32_t wp[11];
+    int32_t* true_err[3];     // width
+    uint32_t* sub_err[3];     // 4 x width
+    uint32_t* progress;       // [3][bands]: columns finished by the band's last row
+    uint32_t bands;
+    int* fail;
+};
+
+template <typename S>
+__global__ __launch_bounds__(256) void palette_delta_kernel(DeltaArgs a) {
+    const uint32_t band = blockIdx.x, ch = blockIdx.y;
+    const uint32_t r = threadIdx.x;
+    const uint32_t y = band * 256 + r;
+    const uint32_t gw = a.width;
+    const uint32_t rows = min(256u, a.height - band * 256);
+    const bool active = r < rows;
+    S* row = (S*)a.grid[ch] + (size_t)y * a.stride[ch];
+    int32_t* rec = a.rec[ch] + (size_t)y * gw;
+    const int32_t* prev = rec - gw;
+    const int32_t* prev2 = prev - gw;
+    const uint8_t* flags = a.need_delta + (size_t)y * gw;
+    int32_t* s_true_err = a.true_err[ch];
+    uint32_t* s_sub_err = a.sub_err[ch];  // [i * gw + x]
+    uint32_t* my_progress = a.progress + ch * a.bands + band;
+    const uint32_t* up_progress = a.progress + ch * a.bands + band - 1;
+    const bool sc_on = a.d_pred == 6;
+
+    int32_t w = 0, n = 0, nw = 0, ww1 = 0, ww2 = 0;
+    int32_t te_w = 0, te_nw = 0, te_n = 0, te_ne = 0;
+    uint32_t se_nw_ww[4] = {0, 0, 0, 0}, se_n_w[4] = {0, 0, 0, 0}, se_ne[4] = {0, 0, 0, 0};
+
+    const uint32_t steps = gw + 3 * (rows - 1);
+    bool gave_up = false;
+    for (uint32_t s = 0; s < steps; ++s) {
+        if (band > 0 && r == 0 && s < gw && !gave_up) {
+            // row y-1 must have finished columns <= s + 2
+            const uint32_t need = min(gw, s + 3);
+            uint32_t spins = 0;
+            while (__hip_atomic_load(up_progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 22)) {  // ~0.2 s: never in a healthy run; results are void, no hang
+                    atomicExch(a.fail, 1);
+                    gave_up = true;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        const int32_t x = (int32_t)s - 3 * (int32_t)r;
+        if (active && x >= 0 && x < (int32_t)gw) {
+            const bool no_prev = y == 0;
+            if (x == 0) {
+                if (no_prev) {
+                    w = n = nw = 0;
+                } else {
+                    w = n = nw = prev[0];
+                    if (sc_on) {
+                        te_w = 0;
+                        te_n = s_true_err[0];
+                        te_nw = te_n;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { se_n_w[i] = s_sub_err[i * gw]; se_nw_ww[i] = se_n_w[i]; }
+                        if (gw <= 1) {
+                            te_ne = te_n;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) se_ne[i] = se_n_w[i];
+                        } else {
+                            te_ne = s_true_err[1];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) se_ne[i] = s_sub_err[i * gw + 1];
+                        }
+                    }
+                }
+            }
+            const int32_t ne = (no_prev || x + 1 >= (int32_t)gw) ? n : prev[x + 1];
+            const int32_t nee = (no_prev || x + 2 >= (int32_t)gw) ? ne : prev[x + 2];
+            const int32_t nn = y >= 2 ? prev2[x] : n;
+            const int32_t ww = x >= 2 ? ww2 : w;
+
+            int64_t sc_prediction = 0, subpred[4] = {0, 0, 0, 0};
+            if (sc_on) {
+                const int64_t tw = te_w, tnw = te_nw, tn = te_n, tne = te_ne;
+                const int64_t n3 = (int64_t)n * 8, nw3 = (int64_t)nw * 8, ne3 = (int64_t)ne * 8, w3 = (int64_t)w * 8,
+                              nn3 = (int64_t)nn * 8;
+                subpred[0] = w3 + ne3 - n3;
+                subpred[1] = n3 - (((tw + tn + tne) * (int64_t)a.wp[0]) >> 5);
+                subpred[2] = w3 - (((tw + tn + tnw) * (int64_t)a.wp[1]) >> 5);
+                subpred[3] = n3 - ((tnw * (int64_t)a.wp[2] + tn * (int64_t)a.wp[3] + tne * (int64_t)a.wp[4] +
+                                    (nn3 - n3) * (int64_t)a.wp[5] + (nw3 - w3) * (int64_t)a.wp[6]) >> 5);
+                uint32_t weight[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t err_sum = se_nw_ww[i] + se_n_w[i] + se_ne[i];
+                    const uint64_t t = ((uint64_t)err_sum + 1) >> 5;
+                    const uint32_t shift = t ? 63u - (uint32_t)__builtin_clzll(t) : 0u;
+                    weight[i] = 4 + (((uint32_t)a.wp[7 + i] * div_lookup_dev((err_sum >> shift) + 1)) >> shift);
+                }
+                uint32_t sum_weights = weight[0] + weight[1] + weight[2] + weight[3];
+                const uint32_t log_weight = 31u - (uint32_t)__builtin_clz(sum_weights >> 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) weight[i] >>= log_weight;
+                sum_weights = weight[0] + weight[1] + weight[2] + weight[3];
+                int64_t acc = ((int64_t)sum_weights >> 1) - 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc += subpred[i] * (int64_t)weight[i];
+                int64_t prediction = (acc * (int64_t)div_lookup_dev(sum_weights)) >> 24;
+                if (((tn ^ tw) | (tn ^ tnw)) <= 0) {
+                    const int64_t mn = min(min(n3, w3), ne3), mx = max(max(n3, w3), ne3);
+                    prediction = prediction < mn ? mn : (prediction > mx ? mx : prediction);
+                }
+                sc_prediction = prediction;
+            }
+
+            int32_t sample_value = (int32_t)row[x];
+            if (flags[x]) {
+                int32_t pred;
+                const int64_t N = n, W = w, NW = nw;
+                switch (a.d_pred) {
+                    case 0: pred = 0; break;
+                    case 1: pred = w; break;
+                    case 2: pred = n; break;
+                    case 3: pred = (int32_t)((W + N) / 2); break;
+                    case 4: {
+                        const int64_t dn = N > NW ? N - NW : NW - N, dw = W > NW ? W - NW : NW - W;
+                        pred = dn < dw ? w : n;
+                        break;
+                    }
+                    case 5: {
+                        const int64_t g = N + W - NW, lo = W < N ? W : N, hi = W > N ? W : N;
+                        pred = (int32_t)(g < lo ? lo : (g > hi ? hi : g));
+                        break;
+                    }
+                    case 6: pred = (int32_t)((sc_prediction + 3) >> 3); break;
+                    case 7: pred = ne; break;
+                    case 8: pred = nw; break;
+                    case 9: pred = ww; break;
+                    case 10: pred = (int32_t)((W + NW) / 2); break;
+                    case 11: pred = (int32_t)((N + NW) / 2); break;
+                    case 12: pred = (int32_t)((N + (int64_t)ne) / 2); break;
+                    default:
+                        pred = (int32_t)((6 * N - 2 * (int64_t)nn + 7 * W + (int64_t)ww + (int64_t)nee + 3 * (int64_t)ne + 8) / 16);
+                        break;
+                }
+                sample_value = (int32_t)((uint32_t)sample_value + (uint32_t)pred);  // palette.rs:133
+                row[x] = (S)sample_value;                                            // S::from_i32
+            }
+            rec[x] = sample_value;
+
+            if (sc_on) {
+                const int64_t s8 = (int64_t)sample_value * 8;
+                const int64_t true_err = sc_prediction - s8;
+                uint32_t sub_err[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t d = subpred[i] - s8;
+                    sub_err[i] = (uint32_t)(((uint64_t)(d < 0 ? -d : d) + 3) >> 3);
+                }
+                s_true_err[x] = (int32_t)true_err;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_sub_err[i * gw + x] = sub_err[i];
+                if (x + 1 < (int32_t)gw) {
+                    te_w = (int32_t)true_err;
+                    te_nw = te_n;
+                    te_n = te_ne;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        se_nw_ww[i] = se_n_w[i];
+                        se_n_w[i] = se_ne[i] + sub_err[i];
+                    }
+                    if (x + 2 >= (int32_t)gw) {
+                        te_ne = te_n;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) se_ne[i] = se_n_w[i];
+                    } else if (!no_prev) {
+                        te_ne = s_true_err[x + 2];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) se_ne[i] = s_sub_err[i * gw + x + 2];
+                    }
+                }
+            }
+            if (x + 1 < (int32_t)gw) {
+                ww2 = ww1;
+                ww1 = sample_value;
+                w = sample_value;
+                if (no_prev) {
+                    nw = sample_value;
+                    n = sample_value;
+                } else {
+                    nw = n;
+                    n = prev[x + 1];
+                }
+            }
+            if (r == rows - 1) {
+                // publish: everything this row wrote up to column x is visible before the counter moves
+                __threadfence();
+                __hip_atomic_store(my_progress, (uint32_t)x + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- device: int -> float
 struct ToFloatArgs {
     const void* in[3];
@@ -794,6 +1057,10 @@ struct ModularState {
     std::vector<std::vector<JxlGpuSqueezeStep>> steps;
     std::vector<int> final_loc;               // after the last inverse run
     int* d_flag = nullptr;
+    uint8_t* need_delta = nullptr;   // palette slow path: index < nb_deltas
+    size_t need_delta_bytes = 0;
+    uint32_t* delta_aux = nullptr;   // fail flag, band progress, error rows, recorded i32 samples
+    size_t delta_aux_words = 0;
     void* chk = nullptr;                      // segment link values of the squeeze step in flight
     size_t chk_bytes = 0;
     int* d_redo = nullptr;                    // lines redone serially (diagnostics)
@@ -1010,16 +1277,60 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 a.dst[k + 1] = ptr(mg, 0, &a.dst_stride[k + 1]);
             }
             a.width = leader.w; a.height = leader.h; a.num_c = tr.num_c; a.nb_colours = tr.nb_colours;
-            a.not_simple = m->d_flag;
+            a.nb_deltas = (int32_t)tr.nb_deltas; a.bit_depth = m->desc.bit_depth;
+            if (tr.num_c > 8) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "palette over more than 8 channels");
+            const size_t npx = (size_t)a.width * a.height;
+            if (m->need_delta_bytes < npx) {
+                if (int rc = malloc_dev(ctx, f, &m->need_delta, npx)) return rc;
+                m->need_delta_bytes = npx;
+            }
+            a.need_delta = m->need_delta;
+            a.n_delta = m->d_flag;
             HIP_TRY(ctx, hipMemsetAsync(m->d_flag, 0, sizeof(int), s));
             dim3 grid(ceil_div(a.width, 256), a.height);
             if (i16) palette_kernel<int16_t><<<grid, 256, 0, s>>>(a);
             else palette_kernel<int32_t><<<grid, 256, 0, s>>>(a);
-            int flag = 0;
-            HIP_TRY(ctx, hipMemcpyAsync(&flag, m->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+            int n_delta = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&n_delta, m->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, hipStreamSynchronize(s));
-            if (flag) return fail(ctx, JXLGPU_ERR_UNSUPPORTED,
-                                  "palette with implicit / delta entries (serial predictor pass) stays on the CPU path");
+            if (n_delta > 0) {
+                // palette.rs:112-142: the predictor pass over every channel of the palette
+                if (tr.d_pred > 13) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "palette d_pred is not a Predictor");
+                const uint32_t bands = ceil_div(a.height, 256);
+                const size_t aux_words = (size_t)3 * (npx + 5 * (size_t)a.width + bands) + 4;
+                if (m->delta_aux_words < aux_words) {
+                    if (int rc = malloc_dev(ctx, f, &m->delta_aux, aux_words * 4)) return rc;
+                    m->delta_aux_words = aux_words;
+                }
+                for (uint32_t c0 = 0; c0 < tr.num_c; c0 += 3) {
+                    const uint32_t nc = std::min<uint32_t>(3, tr.num_c - c0);
+                    DeltaArgs da;
+                    memset(&da, 0, sizeof(da));
+                    uint32_t* aux = m->delta_aux;
+                    // layout: [fail + pad (4)] [progress 3*bands] [err rows 3*5*width] [rec 3*npx]
+                    da.fail = reinterpret_cast<int*>(aux);
+                    da.progress = aux + 4;
+                    uint32_t* err = aux + 4 + 3 * bands;
+                    int32_t* rec = reinterpret_cast<int32_t*>(err + (size_t)15 * a.width);
+                    HIP_TRY(ctx, hipMemsetAsync(aux, 0, (4 + (size_t)3 * bands + (size_t)15 * a.width) * 4, s));
+                    for (uint32_t k = 0; k < nc; ++k) {
+                        da.grid[k] = a.dst[c0 + k];
+                        da.stride[k] = a.dst_stride[c0 + k];
+                        da.rec[k] = rec + (size_t)k * npx;
+                        da.true_err[k] = reinterpret_cast<int32_t*>(err + (size_t)k * 5 * a.width);
+                        da.sub_err[k] = err + (size_t)k * 5 * a.width + a.width;
+                    }
+                    da.need_delta = m->need_delta;
+                    da.width = a.width; da.height = a.height; da.d_pred = tr.d_pred; da.bands = bands;
+                    for (int i = 0; i < 11; ++i) da.wp[i] = tr.wp_params[i];
+                    if (i16) palette_delta_kernel<int16_t><<<dim3(bands, nc), 256, 0, s>>>(da);
+                    else palette_delta_kernel<int32_t><<<dim3(bands, nc), 256, 0, s>>>(da);
+                    int failed = 0;
+                    HIP_TRY(ctx, hipMemcpyAsync(&failed, da.fail, sizeof(int), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(ctx, hipStreamSynchronize(s));
+                    if (failed) return fail(ctx, JXLGPU_ERR_DEVICE, "delta-palette wavefront: a workgroup waited too long for the band above");
+                }
+            }
             std::vector<int> members = leader.members;
             leader.members.clear();
             const Grid lead_copy = leader;

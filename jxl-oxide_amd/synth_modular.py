@@ -213,6 +213,69 @@ def predictor_residuals(img, group_dim, predictor, offset=0):
     return out
 
 
+DELTA_PALETTE = [
+    (0, 0, 0), (4, 4, 4), (11, 0, 0), (0, 0, -13), (0, -12, 0), (-10, -10, -10),
+    (-18, -18, -18), (-27, -27, -27), (-18, -18, 0), (0, 0, -32), (-32, 0, 0), (-37, -37, -37),
+    (0, -32, -32), (24, 24, 45), (50, 50, 50), (-45, -24, -24), (-24, -45, -45), (0, -24, -24),
+    (-34, -34, 0), (-24, 0, -24), (-45, -45, -24), (64, 64, 64), (-32, 0, -32), (0, -32, 0),
+    (-32, 0, 32), (-24, -45, -24), (45, 24, 45), (24, -24, -45), (-45, -24, 24), (80, 80, 80),
+    (64, 0, 0), (0, 0, -64), (0, -64, -64), (-24, -24, 45), (96, 96, 96), (64, 64, 0),
+    (45, -24, -24), (34, -34, 0), (112, 112, 112), (24, -45, -45), (45, 45, -24), (0, -32, 32),
+    (24, -24, 45), (0, 96, 96), (45, -24, 24), (24, -45, -24), (-24, -45, 24), (0, -64, 0),
+    (96, 0, 0), (128, 128, 128), (64, 0, 64), (144, 144, 144), (96, 96, 0), (-36, -36, 36),
+    (45, -24, -45), (45, -45, -24), (0, 0, -96), (0, 128, 128), (0, 96, 0), (45, 24, -45),
+    (-128, 0, 0), (24, -45, 24), (-45, 24, -45), (64, 0, -64), (64, -64, -64), (96, 0, 96),
+    (45, -45, 24), (24, 45, -45), (64, 64, -64), (128, 128, 0), (0, 0, -128), (-24, 45, -45),
+]  # the format's fixed delta palette (18181-1 table H.x), data
+
+
+def palette_delta_reference(idx, pal, ncol, ndelta, d_pred, bit_depth, wrap_bits):
+    """Slow, direct evaluation of the palette inverse with delta entries for the stateless
+    predictors W(1), N(2), Gradient(5) and Zero(0): colour lookup per the format, then a raster
+    scan per channel where delta pixels add the prediction from already finished neighbours."""
+    H, W = idx.shape
+    out = np.zeros((3, H, W), dtype=np.int64)
+    maxv = (1 << bit_depth) - 1
+    for y in range(H):
+        for x in range(W):
+            i = int(idx[y, x])
+            for c in range(3):
+                if 0 <= i < ncol:
+                    v = int(pal[c, i])
+                elif i >= ncol:
+                    j = i - ncol
+                    if j < 64:
+                        v = ((j >> (2 * c)) % 4) * maxv // 4 + (1 << max(bit_depth - 3, 0))
+                    else:
+                        j -= 64
+                        v = ((j // 5 ** c) % 5) * maxv // 4
+                else:
+                    j = (-(i + 1)) % 143
+                    v = DELTA_PALETTE[(j + 1) >> 1][c]
+                    if j & 1 == 0:
+                        v = -v
+                    if bit_depth > 8:
+                        v <<= min(bit_depth, 24) - 8
+                out[c, y, x] = v
+    half = 1 << (wrap_bits - 1)
+    for c in range(3):
+        rec = out[c].copy()  # recorded (untruncated) values
+        for y in range(H):
+            for x in range(W):
+                if idx[y, x] < ndelta:
+                    wv = rec[y, x - 1] if x > 0 else (rec[y - 1, x] if y > 0 else 0)
+                    n = rec[y - 1, x] if y > 0 else wv
+                    nw = rec[y - 1, x - 1] if (x > 0 and y > 0) else wv
+                    if d_pred == 0: p = 0
+                    elif d_pred == 1: p = wv
+                    elif d_pred == 2: p = n
+                    elif d_pred == 5: p = min(max(n + wv - nw, min(n, wv)), max(n, wv))
+                    else: raise ValueError(d_pred)
+                    rec[y, x] = ((rec[y, x] + p + (1 << 31)) % (1 << 32)) - (1 << 31)
+                    out[c, y, x] = ((rec[y, x] + half) % (2 * half)) - half
+    return out
+
+
 DEFAULT_WP = [16, 10, 7, 7, 7, 0, 0, 13, 12, 12, 12]  # WpHeader defaults (predictor.rs:8-21)
 
 
@@ -362,6 +425,23 @@ class ModularWorkload:
             self.transforms.append(("palette", 0, 3, ncol))
             self.meta.append(pal.astype(self.dtype))
             self.buffers = [idx.astype(self.dtype), np.zeros((H, W), self.dtype), np.zeros((H, W), self.dtype)]
+        elif kind == "palette_delta":
+            # lossy-palette style index plane: regular entries, implicit colours (index >= nb_colours),
+            # delta entries (negative indices and the first nb_deltas palette rows) that add a prediction
+            ncol, ndelta = 29, 4
+            pal = rng.integers(0, 256, size=(3, ncol)).astype(np.int64)
+            pal[:, :ndelta] = rng.integers(-9, 10, size=(3, ndelta))
+            idx = rng.integers(ndelta, ncol, size=(H, W)).astype(np.int64)
+            r = rng.random(size=(H, W))
+            idx = np.where(r < 0.15, rng.integers(ncol, ncol + 64 + 125, size=(H, W)), idx)       # implicit
+            idx = np.where((r >= 0.15) & (r < 0.30), -rng.integers(1, 300, size=(H, W)), idx)      # DELTA_PALETTE
+            idx = np.where((r >= 0.30) & (r < 0.38), rng.integers(0, ndelta, size=(H, W)), idx)    # palette deltas
+            self.palette_delta = (ncol, ndelta, predictor)
+            self.transforms.append(("palette", 0, 3, ncol, ndelta, predictor))
+            self.meta.append(pal.astype(self.dtype))
+            self.buffers = [idx.astype(self.dtype), np.zeros((H, W), self.dtype), np.zeros((H, W), self.dtype)]
+            self.expected = None
+            self.index_plane, self.palette = idx, pal
         elif kind == "raw":
             # arbitrary data straight into the inverse chain: wrapping arithmetic included
             info = np.iinfo(self.dtype)
@@ -422,6 +502,9 @@ class ModularWorkload:
             else:
                 trs[i].kind = abi.TR_PALETTE
                 trs[i].begin_c, trs[i].num_c, trs[i].nb_colours = t[1], t[2], t[3]
+                if len(t) > 4:
+                    trs[i].nb_deltas, trs[i].d_pred = t[4], t[5]
+                    trs[i].wp_params[:] = DEFAULT_WP
         d.num_transforms = len(self.transforms)
         d.transforms = C.cast(trs, C.POINTER(abi.Transform))
         d.residual_predictor = self.residual_predictor

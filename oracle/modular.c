@@ -13,6 +13,7 @@
  *   Squeeze::inverse, SqueezeParams   jxl-modular/src/transform.rs:439-493
  *   inverse_row_*_base, inverse_permute   jxl-modular/src/transform/rct.rs:154-256
  *   Palette::inverse / inverse_simple jxl-modular/src/transform.rs:260-281, transform/palette.rs:146-173
+ *   Palette::inverse_inner slow path  transform/palette.rs:27-142 (DELTA_PALETTE :11-24)
  *   decode_simple_grad (arithmetic)   jxl-modular/src/image.rs:821-872, sample.rs:129-136,179-186
  *   convert_to_float_modular(_xyb)    jxl-render/src/image.rs:93-189
  *   BitDepth::parse_integer_sample    jxl-image/src/lib.rs:458-494
@@ -150,6 +151,22 @@
             }                                                                                      \
         }                                                                                          \
     }
+
+/* transform/palette.rs:11-24 (data table) */
+static const int16_t DELTA_PALETTE[72][3] = {
+    {0, 0, 0}, {4, 4, 4}, {11, 0, 0}, {0, 0, -13}, {0, -12, 0}, {-10, -10, -10},
+    {-18, -18, -18}, {-27, -27, -27}, {-18, -18, 0}, {0, 0, -32}, {-32, 0, 0}, {-37, -37, -37},
+    {0, -32, -32}, {24, 24, 45}, {50, 50, 50}, {-45, -24, -24}, {-24, -45, -45}, {0, -24, -24},
+    {-34, -34, 0}, {-24, 0, -24}, {-45, -45, -24}, {64, 64, 64}, {-32, 0, -32}, {0, -32, 0},
+    {-32, 0, 32}, {-24, -45, -24}, {45, 24, 45}, {24, -24, -45}, {-45, -24, 24}, {80, 80, 80},
+    {64, 0, 0}, {0, 0, -64}, {0, -64, -64}, {-24, -24, 45}, {96, 96, 96}, {64, 64, 0},
+    {45, -24, -24}, {34, -34, 0}, {112, 112, 112}, {24, -45, -45}, {45, 45, -24}, {0, -32, 32},
+    {24, -24, 45}, {0, 96, 96}, {45, -24, 24}, {24, -45, -24}, {-24, -45, 24}, {0, -64, 0},
+    {96, 0, 0}, {128, 128, 128}, {64, 0, 64}, {144, 144, 144}, {96, 96, 0}, {-36, -36, 36},
+    {45, -24, -45}, {45, -45, -24}, {0, 0, -96}, {0, 128, 128}, {0, 96, 0}, {45, 24, -45},
+    {-128, 0, 0}, {24, -45, 24}, {-45, 24, -45}, {64, 0, -64}, {64, -64, -64}, {96, 0, 96},
+    {45, -45, 24}, {24, 45, -45}, {64, 64, -64}, {128, 128, 0}, {0, 0, -128}, {-24, 45, -45},
+};
 
 DEFINE_SQUEEZE(int32_t, i32)
 DEFINE_SQUEEZE(int16_t, i16)
@@ -389,24 +406,76 @@ int jxl_oracle_modular_inverse(const JxlGpuModularDesc* d, void* const* out) {
                     int32_t idx = esz == 2 ? ((int16_t*)lp)[y * ls + x] : ((int32_t*)lp)[y * ls + x];
                     if (idx < 0 || idx >= (int32_t)tr->nb_colours) { simple = 0; break; }
                 }
-            if (!simple) { rc = JXLGPU_ERR_UNSUPPORTED; break; }
-            for (int c = (int)tr->num_c - 1; c >= 0; --c) {
-                /* members first (they read the index grid), the leader itself last */
-                void* dst;
-                size_t ds;
-                Grid mg = *leader;
-                if (c > 0) { mg.buf = leader->members[c - 1]; mg.nmembers = 0; }
-                dst = grid_ptr(&w, &mg, &ds, esz);
-                for (uint32_t y = 0; y < leader->h; ++y)
-                    for (uint32_t x = 0; x < leader->w; ++x) {
-                        if (esz == 2) {
-                            int32_t idx = ((int16_t*)lp)[y * ls + x];
-                            ((int16_t*)dst)[y * ds + x] = ((const int16_t*)pp)[(size_t)c * ps + idx];
-                        } else {
-                            int32_t idx = ((int32_t*)lp)[y * ls + x];
-                            ((int32_t*)dst)[y * ds + x] = ((const int32_t*)pp)[(size_t)c * ps + idx];
+            if (!simple) {
+                /* palette.rs:47-142: implicit colours, delta entries, then the predictor pass */
+                const int32_t nb_colors = (int32_t)tr->nb_colours, nb_deltas = (int32_t)tr->nb_deltas;
+                const uint32_t bit_depth = d->bit_depth;
+                const size_t W = leader->w, H = leader->h;
+                uint8_t* need_delta = (uint8_t*)calloc(W * H, 1);
+                size_t n_delta = 0;
+                void* dsts[16]; size_t dstr[16];
+                int channels = (int)tr->num_c;
+                if (channels > 16) { free(need_delta); rc = JXLGPU_ERR_UNSUPPORTED; break; }
+                for (int c = 0; c < channels; ++c) {
+                    Grid mg = *leader;
+                    if (c > 0) { mg.buf = leader->members[c - 1]; mg.nmembers = 0; }
+                    dsts[c] = grid_ptr(&w, &mg, &dstr[c], esz);
+                }
+                for (size_t y = 0; y < H; ++y)
+                    for (size_t x = 0; x < W; ++x) {
+                        int32_t index = esz == 2 ? ((int16_t*)lp)[y * ls + x] : ((int32_t*)lp)[y * ls + x];
+                        if (index < nb_deltas) { need_delta[y * W + x] = 1; ++n_delta; }
+                        for (int c = 0; c < channels; ++c) {
+                            int32_t v;
+                            if (index >= 0 && index < nb_colors) {
+                                v = esz == 2 ? ((const int16_t*)pp)[(size_t)c * ps + index] : ((const int32_t*)pp)[(size_t)c * ps + index];
+                            } else if (index >= nb_colors) {
+                                int32_t i2 = index - nb_colors;
+                                if (i2 < 64) {
+                                    v = ((i2 >> (2 * c)) % 4) * ((1 << bit_depth) - 1) / 4 + (1 << (bit_depth > 3 ? bit_depth - 3 : 0));
+                                } else {
+                                    int32_t i3 = i2 - 64;
+                                    for (int k = 0; k < c; ++k) i3 /= 5;
+                                    v = (i3 % 5) * ((1 << bit_depth) - 1) / 4;
+                                }
+                            } else if (c >= 3) {
+                                v = 0;
+                            } else {
+                                int32_t i2 = -(index + 1);
+                                i2 = i2 % 143;
+                                int32_t t = DELTA_PALETTE[(i2 + 1) >> 1][c];
+                                if ((i2 & 1) == 0) t = -t;
+                                if (bit_depth > 8) t <<= (bit_depth < 24 ? bit_depth : 24) - 8;
+                                v = t;
+                            }
+                            if (esz == 2) ((int16_t*)dsts[c])[y * dstr[c] + x] = (int16_t)v;
+                            else ((int32_t*)dsts[c])[y * dstr[c] + x] = v;
                         }
                     }
+                if (n_delta)
+                    for (int c = 0; c < channels; ++c)
+                        orc_palette_delta_pass(dsts[c], dstr[c], W, H, (int)esz, need_delta, tr->d_pred, tr->wp_params);
+                free(need_delta);
+            } else {
+                /* inverse_simple, palette.rs:146-173 */
+                for (int c = (int)tr->num_c - 1; c >= 0; --c) {
+                    /* members first (they read the index grid), the leader itself last */
+                    void* dst;
+                    size_t ds;
+                    Grid mg = *leader;
+                    if (c > 0) { mg.buf = leader->members[c - 1]; mg.nmembers = 0; }
+                    dst = grid_ptr(&w, &mg, &ds, esz);
+                    for (uint32_t y = 0; y < leader->h; ++y)
+                        for (uint32_t x = 0; x < leader->w; ++x) {
+                            if (esz == 2) {
+                                int32_t idx = ((int16_t*)lp)[y * ls + x];
+                                ((int16_t*)dst)[y * ds + x] = ((const int16_t*)pp)[(size_t)c * ps + idx];
+                            } else {
+                                int32_t idx = ((int32_t*)lp)[y * ls + x];
+                                ((int32_t*)dst)[y * ds + x] = ((const int32_t*)pp)[(size_t)c * ps + idx];
+                            }
+                        }
+                }
             }
             /* un-merge: member grids come back right after the leader */
             int nm = leader->nmembers;

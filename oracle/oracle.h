@@ -76,6 +76,9 @@ void orc_noise_group(uint32_t width, uint32_t height, uint64_t seed0, uint64_t s
 void orc_predict_apply(void* tile, size_t stride, size_t width, size_t height, int esz, uint32_t predictor,
                        int32_t multiplier, int32_t offset, const int32_t wp[11]);
 
+void orc_palette_delta_pass(void* grid, size_t stride, size_t width, size_t height, int esz,
+                            const uint8_t* need_delta, uint32_t d_pred, const int32_t wp[11]);
+
 /* OpenMP thread count of the oracle's parallel loops (returns the value in effect). */
 int jxl_oracle_set_threads(int n);
 

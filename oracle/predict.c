@@ -240,3 +240,44 @@ void orc_predict_apply(void* tile, size_t stride, size_t width, size_t height, i
     free(ps.prev_row); free(ps.curr_row);
     free(sc.true_err_row); free(sc.subpred_err_row);
 }
+
+/* The predictor pass of Palette::inverse_inner's slow path (transform/palette.rs:112-142): one
+ * PredictorState over the whole channel; samples flagged in `need_delta` (index < nb_deltas) get
+ * the prediction added.  The state records the i32 `sample_value` (palette.rs:130-139), which for
+ * i16 buffers can differ from the stored, truncated sample. */
+void orc_palette_delta_pass(void* grid, size_t stride, size_t width, size_t height, int esz,
+                            const uint8_t* need_delta, uint32_t d_pred, const int32_t wp[11]) {
+    if (width == 0 || height == 0) return;
+    PState ps;
+    memset(&ps, 0, sizeof(ps));
+    ps.width = (uint32_t)width;
+    ps.prev_row = (int32_t*)calloc(width, 4);
+    ps.curr_row = (int32_t*)calloc(width, 4);
+    ScPred sc;
+    memset(&sc, 0, sizeof(sc));
+    if (d_pred == 6) {
+        sc.width = (uint32_t)width;
+        sc.true_err_row = (int32_t*)calloc(width, 4);
+        sc.subpred_err_row = (uint32_t(*)[4])calloc(width, 16);
+        sc.p1 = wp[0]; sc.p2 = wp[1];
+        for (int i = 0; i < 5; ++i) sc.p3[i] = wp[2 + i];
+        for (int i = 0; i < 4; ++i) sc.wn[i] = (uint32_t)wp[7 + i];
+    }
+    for (size_t y = 0; y < height; ++y) {
+        for (size_t x = 0; x < width; ++x) {
+            ScResult r;
+            if (d_pred == 6) r = sc_predict(&sc, ps.n, ps.nw, ps_ne(&ps), ps.w, ps_nn(&ps));
+            int32_t sample_value = esz == 2 ? (int32_t)((int16_t*)grid)[y * stride + x] : ((int32_t*)grid)[y * stride + x];
+            if (need_delta[y * width + x]) {
+                int32_t diff = predict(&ps, d_pred, &r);
+                sample_value = (int32_t)((uint32_t)sample_value + (uint32_t)diff);
+                if (esz == 2) ((int16_t*)grid)[y * stride + x] = (int16_t)sample_value;
+                else ((int32_t*)grid)[y * stride + x] = sample_value;
+            }
+            if (d_pred == 6) sc_record(&sc, &r, sample_value);
+            ps_record(&ps, sample_value);
+        }
+    }
+    free(ps.prev_row); free(ps.curr_row);
+    free(sc.true_err_row); free(sc.subpred_err_row);
+}

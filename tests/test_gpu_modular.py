@@ -105,6 +105,22 @@ def test_self_correcting_predictor_full_tiles(gpu_ctx, oracle):
     _inverse_both(gpu_ctx, oracle, wl)
 
 
+@pytest.mark.parametrize("d_pred", [0, 1, 5, 6, 13])
+@pytest.mark.parametrize("i16", [True, False])
+def test_palette_with_delta_entries(gpu_ctx, oracle, d_pred, i16):
+    """M3 slow path: implicit colours, delta palette, and the whole-channel predictor pass as a
+    wavefront across workgroups (600 rows = three 256-row bands)."""
+    from jxl_oxide_amd.synth_modular import palette_delta_reference
+    wl = ModularWorkload(37, 21, kind="palette_delta", predictor=d_pred, i16=i16, seed=d_pred)
+    got = _inverse_both(gpu_ctx, oracle, wl)
+    if d_pred in (0, 1, 5):
+        exp = palette_delta_reference(wl.index_plane, wl.palette, 29, 4, d_pred, 8, 16 if i16 else 32)
+        for c in range(3):
+            assert np.array_equal(got[c].astype(np.int64), exp[c])
+    wl = ModularWorkload(300, 600, kind="palette_delta", predictor=d_pred, i16=i16, seed=10 + d_pred)
+    _inverse_both(gpu_ctx, oracle, wl)
+
+
 def test_palette(gpu_ctx, oracle):
     wl = ModularWorkload(64, 48, kind="palette")
     got = _inverse_both(gpu_ctx, oracle, wl)

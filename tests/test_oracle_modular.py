@@ -95,3 +95,16 @@ def test_predictor_multiplier_and_wrapping(oracle):
             west = exp[y, x - 1] if x > 0 else (exp[y - 1, 0] if y > 0 else 0)
             exp[y, x] = wrap(wrap(wrap(int(res[y, x]) * 37) - 11) + west)
     assert np.array_equal(got[0].astype(np.int64), exp)
+
+
+@pytest.mark.parametrize("d_pred", [0, 1, 2, 5])
+@pytest.mark.parametrize("i16", [True, False])
+def test_palette_with_delta_entries(oracle, d_pred, i16):
+    """M3 slow path: implicit colours, DELTA_PALETTE entries, delta palette rows + predictor pass,
+    against a direct Python evaluation."""
+    from jxl_oxide_amd.synth_modular import palette_delta_reference
+    wl = ModularWorkload(37, 21, kind="palette_delta", predictor=d_pred, i16=i16, seed=d_pred)
+    got = oracle.modular_inverse(wl.desc(), wl.shapes(), wl.dtype)
+    exp = palette_delta_reference(wl.index_plane, wl.palette, 29, 4, d_pred, 8, 16 if i16 else 32)
+    for c in range(3):
+        assert np.array_equal(got[c].astype(np.int64), exp[c]), f"channel {c}"
