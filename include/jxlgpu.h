@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 9u
+#define JXLGPU_ABI_VERSION 10u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -109,6 +109,10 @@ typedef struct {
     float tm_target_display_luminance; /* 255.0 (SDR target) or 1000.0 (PQ -> HLG)                */
     uint32_t tm_gamut_map;     /* GamutMap{luminances = tm_luminances, saturation_factor}         */
     float tm_gamut_saturation_factor;
+    /* frame_header.do_ycbcr (JPEG-recompressed frames): the planes are Cb, Y, Cr and
+     * `jxl_color::ycbcr_to_rgb` (jxl-color/src/ycbcr.rs:40-56, jxl-render/src/lib.rs:950-954) runs
+     * instead of the XYB op list (`enabled` is ignored).                                          */
+    uint32_t ycbcr;
 } JxlGpuColorParams;
 
 /* ---- non-separable upsampling (jxl-render/src/features/upsampling.rs) ---- */
@@ -161,7 +165,13 @@ typedef struct {
     uint32_t width, height;       /* frame_header.color_sample_width()/height()                   */
     uint32_t group_dim;           /* frame_header.group_dim(); only 256 is supported              */
     uint32_t lf_sample_type;      /* JXLGPU_SAMPLE_* of lf_quant                                   */
-    uint32_t jpeg_upsampling[3];  /* must be 0 (else JXLGPU_ERR_UNSUPPORTED)                       */
+    /* frame_header.jpeg_upsampling, per framebuffer channel (Cb, Y, Cr): ChannelShift::
+     * from_jpeg_upsampling (jxl-modular/src/param.rs:105-122).  Non-zero (chroma-subsampled) frames
+     * are supported when every varblock is DCT8 and skip_adaptive_lf_smoothing is set (what JPEG
+     * transcodes are); then the block grids of the LF groups are rounded up to even cell counts
+     * (hf_metadata.rs:70-81), channel c's coefficient plane is shift_size(w8, h8) * 8 samples with
+     * row stride `coeff_stride >> hshift(c)`, and lf_quant[k] has the shifted size of its channel. */
+    uint32_t jpeg_upsampling[3];
     /* HF coefficients as `write_hf_coeff` leaves them (jxl-vardct/src/hf_coeff.rs:207-244):
      * planes in framebuffer order [0]=X,[1]=Y,[2]=B, width_rounded x height_rounded (ceil to 8),
      * row stride `coeff_stride` elements (jxl-render/src/vardct/mod.rs:206-222, 262-265).

@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -94,6 +94,7 @@ class ColorParams(C.Structure):
         ("tm_target_display_luminance", C.c_float),
         ("tm_gamut_map", C.c_uint32),
         ("tm_gamut_saturation_factor", C.c_float),
+        ("ycbcr", C.c_uint32),
     ]
 
 

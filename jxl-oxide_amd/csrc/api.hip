@@ -55,6 +55,15 @@ void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3],
                        jxlgpu_ctx* ctx);
 bool fused_post_supported(const jxlgpu_frame* f, bool gabor, int epf_iters);
 
+struct UploadOpts {
+    uint32_t lfg_cells_x = 0, lfg_cells_y = 0;  // LF group size in cells (0: group_dim)
+    bool no_cfl = false;                        // chroma-subsampled frames skip both CfL steps
+    bool no_post = false;                       // no filter buffers: the frame only runs V1-V8
+};
+extern "C" int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadOpts& o, jxlgpu_frame** out_frame);
+int upload_subsampled(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_frame** out_frame);
+int render_subsampled(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuOut* out);
+
 namespace {
 
 // TransformType -> (bw, bh), jxl-vardct/src/dct_select.rs:52-76
@@ -192,6 +201,7 @@ void fill_color_args(const JxlGpuColorParams& cp, ColorArgs* c) {
     c->gamut_sat = cp.gamut_saturation_factor;
     c->has_matrix2 = cp.has_matrix2;
     c->tf = cp.transfer_function;
+    c->ycbcr = cp.ycbcr;
     c->gamma = cp.gamma;
     c->tone_map = cp.tone_map;
     if (cp.tone_map) {
@@ -237,7 +247,7 @@ void fill_color_args_public(const JxlGpuColorParams& cp, ColorArgs* c) { fill_co
 
 // nullptr if the colour op list can run on the device, else why not
 const char* color_params_unsupported(const JxlGpuColorParams& cp) {
-    if (!cp.enabled) return nullptr;
+    if (!cp.enabled || cp.ycbcr) return nullptr;
     if (cp.transfer_function == JXLGPU_TF_HLG)
         return "HLG transfer function (libm powf/ln in the reference, not bit-reproducible) stays on the CPU path";
     if (cp.transfer_function > JXLGPU_TF_HLG) return "unknown transfer function";
@@ -336,6 +346,7 @@ void jxlgpu_frame_free(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
+    for (auto& sub : f->subs) jxlgpu_frame_free(ctx, sub.child);
     for (void* p : f->allocs) {
         if (ctx) ctx_dev_release(ctx, p);
         else (void)hipFree(p);
@@ -348,8 +359,16 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
     if (!ctx || !d || !out_frame) return JXLGPU_ERR_INVALID_ARG;
     *out_frame = nullptr;
     if (d->abi != JXLGPU_ABI_VERSION) return fail(ctx, JXLGPU_ERR_ABI, "descriptor ABI version mismatch");
+    if (d->jpeg_upsampling[0] | d->jpeg_upsampling[1] | d->jpeg_upsampling[2]) return upload_subsampled(ctx, d, out_frame);
+    return vardct_upload_impl(ctx, d, UploadOpts{}, out_frame);
+}
+
+// One frame geometry: every channel has the same size.  `o` lets upload_subsampled build the
+// per-geometry children of a chroma-subsampled frame from derived descriptors.
+int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadOpts& o, jxlgpu_frame** out_frame) {
+    *out_frame = nullptr;
     if (d->jpeg_upsampling[0] | d->jpeg_upsampling[1] | d->jpeg_upsampling[2])
-        return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "chroma-subsampled (jpeg_upsampling != 0) frames stay on the CPU path");
+        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "internal: subsampled descriptor in the single-geometry upload");
     if (d->group_dim != 256) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "only group_dim == 256 is supported");
     if (const char* why = color_params_unsupported(d->color)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, why);
     if (d->width == 0 || d->height == 0 || d->width > (1u << 18) || d->height > (1u << 18))
@@ -382,9 +401,12 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
     f->wr = f->w8 * 8; f->hr = f->h8 * 8;
     f->w64 = ceil_div(d->width, 64); f->h64 = ceil_div(d->height, 64);
     f->group_dim = d->group_dim;
-    const uint32_t lf_dim = d->group_dim * 8;
-    f->lf_groups_per_row = ceil_div(d->width, lf_dim);
-    const uint32_t lf_rows = ceil_div(d->height, lf_dim);
+    // LF group size in cells; children of a subsampled frame keep the parent's LF-group tiling
+    f->lfg_cells_x = o.lfg_cells_x ? o.lfg_cells_x : d->group_dim;
+    f->lfg_cells_y = o.lfg_cells_y ? o.lfg_cells_y : d->group_dim;
+    const uint32_t lf_px_x = f->lfg_cells_x * 8, lf_px_y = f->lfg_cells_y * 8;
+    f->lf_groups_per_row = ceil_div(d->width, lf_px_x);
+    const uint32_t lf_rows = ceil_div(d->height, lf_px_y);
     f->num_lf_groups = f->lf_groups_per_row * lf_rows;
     if (d->num_lf_groups != f->num_lf_groups || !d->lf_groups)
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "num_lf_groups does not match the frame size");
@@ -410,13 +432,13 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
     for (uint32_t g = 0; g < f->num_lf_groups; ++g) {
         const JxlGpuLfGroup& lg = d->lf_groups[g];
         const uint32_t gx = g % f->lf_groups_per_row, gy = g / f->lf_groups_per_row;
-        const uint32_t exp_w = std::min(lf_dim, d->width - gx * lf_dim), exp_h = std::min(lf_dim, d->height - gy * lf_dim);
+        const uint32_t exp_w = std::min(lf_px_x, d->width - gx * lf_px_x), exp_h = std::min(lf_px_y, d->height - gy * lf_px_y);
         if (lg.width_px != exp_w || lg.height_px != exp_h)
             return fail(ctx, JXLGPU_ERR_INVALID_ARG, "LF group size does not match the frame geometry");
         if (lg.extra_precision > 3) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "extra_precision > 3");
         const uint32_t bw = ceil_div(lg.width_px, 8), bh = ceil_div(lg.height_px, 8);
         const uint32_t cw = ceil_div(lg.width_px, 64), ch = ceil_div(lg.height_px, 64);
-        const size_t cell0 = (size_t)gy * d->group_dim * f->w8 + (size_t)gx * d->group_dim;
+        const size_t cell0 = (size_t)gy * f->lfg_cells_y * f->w8 + (size_t)gx * f->lfg_cells_x;
         // copy_lf_dequant scale (vardct/mod.rs:398-400), f64 on the host exactly as the reference
         const int32_t precision_scale = 1 << (9 - lg.extra_precision);
         for (int c = 0; c < 3; ++c)
@@ -440,7 +462,8 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
                 hf_mul[o] = lg.hf_mul[(size_t)y * bw + x];
                 if (lg.epf_sigma) sigma[o] = lg.epf_sigma[(size_t)y * bw + x];
             }
-        const size_t t0 = (size_t)gy * (lf_dim / 64) * f->w64 + (size_t)gx * (lf_dim / 64);
+        const size_t t0 = (size_t)gy * (lf_px_y / 64) * f->w64 + (size_t)gx * (lf_px_x / 64);
+        if (o.no_cfl) continue;  // vardct/mod.rs:355: no chroma-from-luma on subsampled frames
         for (uint32_t y = 0; y < ch; ++y)
             for (uint32_t x = 0; x < cw; ++x) {
                 // chroma_from_luma_hf_grouped, vardct/mod.rs:590-593
@@ -458,7 +481,7 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
     const uint32_t groups_x = ceil_div(d->width, d->group_dim), groups_y = ceil_div(d->height, d->group_dim);
     for (uint32_t gy = 0; gy < groups_y; ++gy)
         for (uint32_t gx = 0; gx < groups_x; ++gx) {
-            const uint32_t lfg = (gy / 8) * f->lf_groups_per_row + gx / 8;
+            const uint32_t lfg = (gy * gcells / f->lfg_cells_y) * f->lf_groups_per_row + gx * gcells / f->lfg_cells_x;
             if (!has_meta[lfg]) {
                 nometa.push_back(gy * groups_x + gx);
                 continue;
@@ -511,6 +534,7 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
         TRY(dev_alloc(ctx, f, &f->lf_a[c], ncell));
         TRY(dev_alloc(ctx, f, &f->lf[c], ncell));
         TRY(dev_alloc(ctx, f, &f->pix[c], npix));
+        if (o.no_post) continue;
         TRY(dev_alloc(ctx, f, &f->buf_a[c], npix));
         TRY(dev_alloc(ctx, f, &f->buf_b[c], npix));
     }
@@ -584,6 +608,7 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
         int32_t x_factor = (int32_t)d->x_factor_lf - 128, b_factor = (int32_t)d->b_factor_lf - 128;
         f->kx_lf = d->base_correlation_x + ((float)x_factor / (float)d->colour_factor);
         f->kb_lf = d->base_correlation_b + ((float)b_factor / (float)d->colour_factor);
+        if (o.no_cfl) f->kx_lf = f->kb_lf = 0.0f;  // vardct/mod.rs:184: skipped when subsampled; x + 0*y == x
     }
     for (int c = 0; c < 3; ++c) f->lf_div[c] = (float)(512.0 * (double)d->m_lf[c] / (double)scale_inv);
     fill_color_args(d->color, &f->color);
@@ -636,6 +661,7 @@ uint64_t jxlgpu_frame_algorithmic_bytes(const jxlgpu_frame* f, uint32_t stages) 
 int jxlgpu_frame_download_lf(jxlgpu_ctx* ctx, const jxlgpu_frame* f, float* const planes[3]) {
     if (!ctx || !f || !planes) return JXLGPU_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!f->subs.empty()) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "LF planes of a chroma-subsampled frame have per-channel sizes");
     const float* const* src = f->desc.skip_adaptive_lf_smoothing ? f->lf_a : f->lf;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int c = 0; c < 3; ++c)
@@ -655,7 +681,7 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
     const bool do_gab = (stages & JXLGPU_STAGE_GABOR) && fp.gab_enabled;
     const int epf_iters = (stages & JXLGPU_STAGE_EPF) ? (int)fp.epf_iters : 0;
     const bool do_up = (stages & JXLGPU_STAGE_UPSAMPLE) && up_factor > 1;
-    const bool do_color = (stages & JXLGPU_STAGE_COLOR) && f->desc.color.enabled;
+    const bool do_color = (stages & JXLGPU_STAGE_COLOR) && (f->desc.color.enabled || f->desc.color.ycbcr);
     const bool do_noise = (stages & JXLGPU_STAGE_NOISE) && f->desc.noise.enabled;
     const bool fuse_color = do_color && !do_up && !do_noise;  // noise sits between upsampling and colour
 
@@ -794,11 +820,203 @@ int finish_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stri
     return JXLGPU_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Chroma-subsampled frames (JPEG transcodes).  Channels of different sizes are
+// different *geometries*: the frame becomes one child frame per distinct (hshift, vshift), each a
+// plain single-geometry frame whose three channel slots keep their own parameters (quant bias,
+// qm scale, dequant matrices, LF scale); slots that do not belong to the geometry are pointed at a
+// member's data and their output is ignored.  Children keep the parent's LF-group tiling
+// (256 >> shift cells), so the per-group `lf_quant` arrays and `extra_precision` pass through
+// unchanged.  After the children's V1-V8, upsample_jpeg brings every channel to full resolution
+// (image.rs:448-485) and the common post stages run on the parent.
+namespace {
+
+uint32_t ssize1(uint32_t n, bool has, bool sub) {  // ChannelShift::shift_size, param.rs:142-165
+    if (!has) return n;
+    const uint32_t size = (n + 1) / 2;
+    return sub ? size : size * 2;
+}
+
+}  // namespace
+
+int upload_subsampled(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_frame** out_frame) {
+    if (!d->skip_adaptive_lf_smoothing)
+        return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "chroma-subsampled frame with adaptive LF smoothing stays on the CPU path");
+    if (d->group_dim != 256) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "only group_dim == 256 is supported");
+    if ((d->upsampling.factor ? d->upsampling.factor : 1) != 1)
+        return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "chroma-subsampled frame with non-separable upsampling");
+    if (d->coeff_format != JXLGPU_COEFF_DENSE)
+        return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "sparse coefficient transport on a chroma-subsampled frame");
+    if (d->width == 0 || d->height == 0 || d->width > (1u << 18) || d->height > (1u << 18))
+        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "bad frame size");
+    if (!d->lf_groups) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "no LF groups");
+    // ChannelShift::from_jpeg_upsampling, param.rs:105-122
+    bool has_h = false, has_v = false;
+    for (int i = 0; i < 3; ++i) {
+        if (d->jpeg_upsampling[i] > 3) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "jpeg_upsampling > 3");
+        has_h |= d->jpeg_upsampling[i] == 1 || d->jpeg_upsampling[i] == 2;
+        has_v |= d->jpeg_upsampling[i] == 1 || d->jpeg_upsampling[i] == 3;
+    }
+    int hs[3], vs[3];
+    for (int c = 0; c < 3; ++c) {
+        switch (d->jpeg_upsampling[c]) {
+            case 0: hs[c] = has_h; vs[c] = has_v; break;
+            case 1: hs[c] = 0; vs[c] = 0; break;
+            case 2: hs[c] = 0; vs[c] = has_v; break;
+            default: hs[c] = has_h; vs[c] = 0; break;
+        }
+    }
+    const uint32_t W = d->width, H = d->height, W8 = ceil_div(W, 8), H8 = ceil_div(H, 8);
+    const uint32_t lf_dim = d->group_dim * 8, per_row = ceil_div(W, lf_dim), lf_rows = ceil_div(H, lf_dim);
+    if (d->num_lf_groups != per_row * lf_rows) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "num_lf_groups does not match the frame size");
+    if (d->coeff_stride < ssize1(W8, has_h, false) * 8 || (d->coeff_stride & 1))
+        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "coeff_stride < width_rounded (or odd)");
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    jxlgpu_frame* f = new (std::nothrow) jxlgpu_frame();
+    if (!f) return JXLGPU_ERR_OOM;
+    struct Guard {
+        jxlgpu_ctx* c; jxlgpu_frame* f; bool armed = true;
+        ~Guard() { if (armed) jxlgpu_frame_free(c, f); }
+    } guard{ctx, f};
+    f->desc = *d;
+    f->width = W; f->height = H;
+    f->w8 = W8; f->h8 = H8; f->wr = W8 * 8; f->hr = H8 * 8;
+    f->w64 = ceil_div(W, 64); f->h64 = ceil_div(H, 64);
+    f->group_dim = d->group_dim;
+    f->lfg_cells_x = f->lfg_cells_y = d->group_dim;
+    f->lf_groups_per_row = per_row; f->num_lf_groups = d->num_lf_groups;
+
+    // frame-level sigma for the post stages; every varblock must be DCT8 (what JPEG transcodes are:
+    // for_each_varblocks, vardct/mod.rs:693-730, maps other shapes onto overlapping chroma blocks)
+    std::vector<float> sigma((size_t)W8 * H8, d->filter.epf_sigma_for_modular);
+    for (uint32_t g = 0; g < d->num_lf_groups; ++g) {
+        const JxlGpuLfGroup& lg = d->lf_groups[g];
+        const uint32_t gx = g % per_row, gy = g / per_row;
+        if (lg.width_px != std::min(lf_dim, W - gx * lf_dim) || lg.height_px != std::min(lf_dim, H - gy * lf_dim))
+            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "LF group size does not match the frame geometry");
+        if (!lg.has_hf_meta) continue;
+        if (!lg.block_kind || !lg.hf_mul) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "HfMetadata pointers missing");
+        const uint32_t gbw = ceil_div(lg.width_px, 8), gbh = ceil_div(lg.height_px, 8);
+        const uint32_t bw = ssize1(gbw, has_h, false), bh = ssize1(gbh, has_v, false);  // hf_metadata.rs:70-81
+        for (uint32_t y = 0; y < bh; ++y)
+            for (uint32_t x = 0; x < bw; ++x) {
+                if (lg.block_kind[(size_t)y * bw + x] != JXLGPU_DCT8)
+                    return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "chroma-subsampled frame with varblocks other than DCT8 stays on the CPU path");
+                if (lg.epf_sigma && x < gbw && y < gbh)
+                    sigma[(size_t)(gy * d->group_dim + y) * W8 + gx * d->group_dim + x] = lg.epf_sigma[(size_t)y * bw + x];
+            }
+    }
+
+    // ---- one child per distinct geometry
+    bool done[3] = {false, false, false};
+    for (int lead = 0; lead < 3; ++lead) {
+        if (done[lead]) continue;
+        jxlgpu_frame::Sub sub;
+        sub.hshift = hs[lead]; sub.vshift = vs[lead];
+        for (int c = 0; c < 3; ++c) {
+            sub.member[c] = hs[c] == hs[lead] && vs[c] == vs[lead];
+            done[c] |= sub.member[c];
+        }
+        const bool sh = sub.hshift != 0, sv = sub.vshift != 0;
+        JxlGpuVardctDesc cd = *d;
+        for (int i = 0; i < 3; ++i) cd.jpeg_upsampling[i] = 0;
+        cd.width = ssize1(W8, has_h, sh) * 8;
+        cd.height = ssize1(H8, has_v, sv) * 8;
+        cd.coeff_stride = d->coeff_stride >> sub.hshift;
+        for (int c = 0; c < 3; ++c) cd.coeff[c] = d->coeff[sub.member[c] ? c : lead];
+        cd.skip_adaptive_lf_smoothing = 1;
+        memset(&cd.filter, 0, sizeof(cd.filter));
+        memset(&cd.noise, 0, sizeof(cd.noise));
+        memset(&cd.color, 0, sizeof(cd.color));
+        cd.upsampling.factor = 1;
+        // lf_quant channel k holds framebuffer slot kSlot[k] (util.rs:275-298)
+        static const int kSlot[3] = {1, 0, 2};
+        int k_of_lead = 0;
+        for (int k = 0; k < 3; ++k) if (kSlot[k] == lead) k_of_lead = k;
+        std::vector<JxlGpuLfGroup> groups(d->num_lf_groups);
+        std::vector<std::vector<uint8_t>> kinds(d->num_lf_groups);
+        std::vector<std::vector<int32_t>> muls(d->num_lf_groups), zeros(d->num_lf_groups);
+        for (uint32_t g = 0; g < d->num_lf_groups; ++g) {
+            const JxlGpuLfGroup& lg = d->lf_groups[g];
+            JxlGpuLfGroup& cg = groups[g];
+            cg = lg;
+            const uint32_t gbw = ceil_div(lg.width_px, 8), gbh = ceil_div(lg.height_px, 8);
+            const uint32_t pbw = ssize1(gbw, has_h, false);  // parent grid stride (rounded)
+            const uint32_t lw = ssize1(gbw, has_h, sh), lh = ssize1(gbh, has_v, sv);
+            cg.width_px = lw * 8; cg.height_px = lh * 8;
+            for (int k = 0; k < 3; ++k) cg.lf_quant[k] = lg.lf_quant[sub.member[kSlot[k]] ? k : k_of_lead];
+            cg.epf_sigma = nullptr;
+            zeros[g].assign((size_t)ceil_div(cg.width_px, 64) * ceil_div(cg.height_px, 64), 0);
+            cg.x_from_y = zeros[g].data(); cg.b_from_y = zeros[g].data();
+            if (!lg.has_hf_meta) continue;
+            kinds[g].assign((size_t)lw * lh, (uint8_t)JXLGPU_DCT8);
+            muls[g].resize((size_t)lw * lh);
+            for (uint32_t y = 0; y < lh; ++y)
+                for (uint32_t x = 0; x < lw; ++x)
+                    muls[g][(size_t)y * lw + x] = lg.hf_mul[(size_t)(y << sub.vshift) * pbw + (x << sub.hshift)];
+            cg.block_kind = kinds[g].data();
+            cg.hf_mul = muls[g].data();
+        }
+        cd.lf_groups = groups.data();
+        UploadOpts o;
+        o.lfg_cells_x = d->group_dim >> sub.hshift;
+        o.lfg_cells_y = d->group_dim >> sub.vshift;
+        o.no_cfl = true;
+        o.no_post = true;
+        TRY(vardct_upload_impl(ctx, &cd, o, &sub.child));
+        f->subs.push_back(sub);
+    }
+
+    const size_t npix = (size_t)f->wr * f->hr;
+    for (int c = 0; c < 3; ++c) {
+        TRY(dev_alloc(ctx, f, &f->pix[c], npix));
+        TRY(dev_alloc(ctx, f, &f->buf_a[c], npix));
+        TRY(dev_alloc(ctx, f, &f->buf_b[c], npix));
+    }
+    TRY(dev_upload(ctx, f, &f->sigma, sigma));
+    fill_color_args(d->color, &f->color);
+    f->noise_group_dim = d->group_dim;
+    f->noise_corr_x = d->base_correlation_x;
+    f->noise_corr_b = d->base_correlation_b;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < 3; ++c) f->desc.coeff[c] = nullptr;
+    f->desc.lf_groups = nullptr;
+    memset(f->desc.dequant, 0, sizeof(f->desc.dequant));
+    guard.armed = false;
+    *out_frame = f;
+    return JXLGPU_OK;
+}
+
+extern "C" int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuOut* out);
+
+int render_subsampled(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuOut* out) {
+    bool has_h = false, has_v = false;
+    for (const auto& sub : f->subs) { has_h |= sub.hshift != 0; has_v |= sub.vshift != 0; }
+    for (auto& sub : f->subs) TRY(jxlgpu_vardct_render(ctx, sub.child, stages & (JXLGPU_STAGE_LF | JXLGPU_STAGE_TRANSFORM), nullptr));
+    if (!(stages & JXLGPU_STAGE_TRANSFORM)) return JXLGPU_OK;
+    // upsample_jpeg, image.rs:448-485 / filter/ycbcr.rs:6-89
+    ctx->prof_begin(PROF_POST);
+    for (auto& sub : f->subs)
+        for (int c = 0; c < 3; ++c) {
+            if (!sub.member[c]) continue;
+            const uint32_t in_w = ssize1(f->width, has_h, sub.hshift != 0), in_h = ssize1(f->height, has_v, sub.vshift != 0);
+            launch_upsample_jpeg(ctx->stream, sub.child->pix[c], sub.child->wr, in_w, in_h, sub.hshift, sub.vshift,
+                                 f->pix[c], f->wr, f->width, f->height);
+        }
+    float* cur[3] = {f->pix[0], f->pix[1], f->pix[2]};
+    uint32_t stride = f->wr, ow = f->width, oh = f->height;
+    TRY(run_post_stages(ctx, f, stages, f->desc.filter, 1, cur, &stride, &ow, &oh));
+    ctx->prof_end(PROF_POST);
+    return finish_render(ctx, f, cur, stride, ow, oh, out);
+}
+
 extern "C" {
 
 int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuOut* out) {
     if (!ctx || !f || f->kind_of_frame != 0) return JXLGPU_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!f->subs.empty()) return render_subsampled(ctx, f, stages, out);
     hipStream_t s = ctx->stream;
     const JxlGpuVardctDesc& d = f->desc;
 
@@ -806,7 +1024,8 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
     LfArgs la;
     for (int c = 0; c < 3; ++c) { la.lfq[c] = f->lfq[c]; la.out[c] = f->lf_a[c]; }
     la.is_i16 = f->lf_is_i16; la.scale = f->lf_scale;
-    la.w8 = f->w8; la.h8 = f->h8; la.lf_groups_per_row = f->lf_groups_per_row; la.group_cells = f->group_dim;
+    la.w8 = f->w8; la.h8 = f->h8; la.lf_groups_per_row = f->lf_groups_per_row;
+    la.group_cells_x = f->lfg_cells_x; la.group_cells_y = f->lfg_cells_y;
     la.kx = f->kx_lf; la.kb = f->kb_lf;
     ctx->prof_begin(PROF_LF);
     launch_lf_dequant_cfl(s, la);

@@ -60,7 +60,7 @@ struct LfArgs {
     uint32_t is_i16;
     const float* scale;        // per LF group x 3 channels
     float* out[3];
-    uint32_t w8, h8, lf_groups_per_row, group_cells;
+    uint32_t w8, h8, lf_groups_per_row, group_cells_x, group_cells_y;
     float kx, kb;              // CfL-LF factors
 };
 
@@ -98,6 +98,7 @@ struct ColorArgs {
     uint32_t has_matrix2;
     float matrix2[9];
     uint32_t tf;
+    uint32_t ycbcr;            // do_ycbcr frames: ycbcr_to_rgb instead of the XYB op list
     float gamma;
     // ToneMapRec2408 (detect_peak = false): constants of rec2408_eetf_generic steps 1-2
     uint32_t tone_map;
@@ -196,6 +197,14 @@ struct jxlgpu_frame {
     ColorArgs color = {};
     void* fmt_buf = nullptr;             // device staging for jxlgpu_frame_format_output
     size_t fmt_bytes = 0;
+    // chroma-subsampled parent: one single-geometry child per distinct (hshift, vshift)
+    struct Sub {
+        jxlgpu_frame* child = nullptr;
+        int hshift = 0, vshift = 0;
+        bool member[3] = {false, false, false};
+    };
+    std::vector<Sub> subs;
+    uint32_t lfg_cells_x = 256, lfg_cells_y = 256;  // LF group size in cells
     float* noise_raw[3] = {};            // raw noise planes (allocated on the first noise render)
     uint32_t noise_w = 0, noise_h = 0;
     uint32_t noise_group_dim = 256;
@@ -242,6 +251,8 @@ bool noise_geometry_unsupported(uint32_t height, uint32_t group_dim);
 void launch_noise(hipStream_t s, const JxlGpuNoiseParams& np, const void* jump_dev, float* const raw[3],
                   float* const ch[3], uint32_t stride, uint32_t width, uint32_t height, uint32_t group_dim,
                   float corr_x, float corr_b);
+void launch_upsample_jpeg(hipStream_t s, const float* in, uint32_t in_stride, uint32_t in_w, uint32_t in_h, int hshift,
+                          int vshift, float* out, uint32_t out_stride, uint32_t width, uint32_t height);
 void launch_widen_i16(hipStream_t s, const int16_t* src, int32_t* dst, size_t count);
 void launch_coeff_scatter(hipStream_t s, const uint32_t* pos, const void* val, bool val_i16, size_t count,
                           uint32_t src_stride, uint32_t wr, uint32_t hr, int32_t* dst, uint32_t* bad);

@@ -500,7 +500,8 @@ void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3],
         a.segs = (a.sy1 - a.sy0 + a.rows_per_seg - 1) / a.rows_per_seg;
         const int waves = a.strips * a.segs;
         // plain XYB -> sRGB (no gamut map / second matrix) gets a branch-free colour epilogue
-        const bool plain_srgb = a.color.tf == JXLGPU_TF_SRGB && !a.color.gamut_map && !a.color.has_matrix2;
+        const bool plain_srgb = a.color.tf == JXLGPU_TF_SRGB && !a.color.gamut_map && !a.color.has_matrix2 &&
+                                !a.color.tone_map && !a.color.ycbcr;
         if (ctx && ctx->stream2) (void)hipEventRecord(ctx->ev_fork, s);  // inputs are ready here
         if (plain_srgb) post_stream_kernel<JXLGPU_TF_SRGB><<<(waves + 3) / 4, 256, 0, s>>>(a);
         else post_stream_kernel<-1><<<(waves + 3) / 4, 256, 0, s>>>(a);

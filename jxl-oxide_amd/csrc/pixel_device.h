@@ -301,6 +301,14 @@ __device__ __forceinline__ void matmul3vec_dev(const float (&a)[9], float (&v)[3
 // XybToMixedLms -> Matrix -> [GamutMap -> Matrix] -> TransferFunction for one pixel
 // (op list built at jxl-color/src/convert.rs:208-549; xyb.rs:44-58 for the first op).
 __device__ __forceinline__ void color_pixel(const ColorArgs& cp, float (&v)[3]) {
+    if (cp.ycbcr) {
+        // ycbcr_to_rgb run_generic, jxl-color/src/ycbcr.rs:40-56 (planes are Cb, Y, Cr)
+        const float cb = v[0], yy = v[1] + 128.0f / 255.0f, cr = v[2];
+        v[0] = __builtin_fmaf(cr, 1.402f, yy);
+        v[1] = __builtin_fmaf(cb, -0.114f * 1.772f / 0.587f, __builtin_fmaf(cr, -0.299f * 1.402f / 0.587f, yy));
+        v[2] = __builtin_fmaf(cb, 1.772f, yy);
+        return;
+    }
     float x = v[0], y = v[1], b = v[2];
     float g_l = y + x, g_m = y - x, g_s = b;
     g_l = g_l - cp.cbrt_opsin_bias[0];

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void lf_dequant_cfl_kernel(LfArgs a) {
     uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t y = blockIdx.y;
     if (x >= a.w8) return;
-    uint32_t g = (y / a.group_cells) * a.lf_groups_per_row + x / a.group_cells;
+    uint32_t g = (y / a.group_cells_y) * a.lf_groups_per_row + x / a.group_cells_x;
     size_t i = (size_t)y * a.w8 + x;
     float v[3];
 #pragma unroll

@@ -390,3 +390,160 @@ class VardctWorkload:
     def out_size(self, stages):
         f = self.up_factor if (stages & abi.STAGE_UPSAMPLE) else 1
         return self.width * f, self.height * f
+
+
+JPEG_MODES = {
+    # frame_header.jpeg_upsampling per framebuffer channel (Cb, Y, Cr); ChannelShift::
+    # from_jpeg_upsampling (jxl-modular/src/param.rs:105-122): 0 = "as subsampled as the frame
+    # gets", 1 = full resolution, 2 = vertical subsampling only, 3 = horizontal only
+    "444": [0, 0, 0],
+    "420": [0, 1, 0],
+    "422": [0, 2, 0],   # chroma halved horizontally
+    "440": [0, 3, 0],   # chroma halved vertically
+    "mixed": [0, 1, 2], # Cb 2x2, Y full, Cr vertical only: three geometries
+}
+
+
+def jpeg_shifts(ju):
+    hscale = any(v in (1, 2) for v in ju)
+    vscale = any(v in (1, 3) for v in ju)
+    out = []
+    for v in ju:
+        h, w = {0: (hscale, vscale), 1: (False, False), 2: (False, vscale), 3: (hscale, False)}[v]
+        out.append((int(h), int(w)))
+    return out, hscale, vscale
+
+
+def _ssize(n, has, sub):
+    if not has:
+        return n
+    s = -(-n // 2)
+    return s if sub else s * 2
+
+
+class JpegWorkload:
+    """A JPEG-transcode style VarDCT frame at the device boundary: DCT8 everywhere, YCbCr planes
+    (Cb, Y, Cr) with optional chroma subsampling, no chroma-from-luma use, LF smoothing skipped
+    (SURVEY §8f rank 4).  Coefficient magnitudes follow the same scaling rule as VardctWorkload."""
+
+    def __init__(self, width, height, mode="420", seed=0, epf_iters=0, gabor=False, lf_i16=True):
+        rng = np.random.default_rng(SEED_BASE + 0x4A00 + seed)
+        self.width, self.height, self.mode = width, height, mode
+        self.ju = JPEG_MODES[mode]
+        self.shifts, self.has_h, self.has_v = jpeg_shifts(self.ju)
+        self.group_dim = 256
+        W8, H8 = -(-width // 8), -(-height // 8)
+        self.W8r = -(-W8 // 2) * 2 if self.has_h else W8
+        self.H8r = -(-H8 // 2) * 2 if self.has_v else H8
+        self.cw = [_ssize(W8, self.has_h, h) for (h, v) in self.shifts]
+        self.ch = [_ssize(H8, self.has_v, v) for (h, v) in self.shifts]
+        self.global_scale = int(rng.integers(3000, 6001))
+        self.quant_lf = 16
+        self.mats = default_dequant_matrices()
+        self.sec = sec_half_large()
+        self.lf_sample_type = abi.SAMPLE_I16 if lf_i16 else abi.SAMPLE_I32
+        lf_dt = np.int16 if lf_i16 else np.int32
+        self.hf_mul = rng.integers(2, 9, size=(self.H8r, self.W8r)).astype(np.int32)
+        self.sigma = rng.uniform(0.2, 2.5, size=(self.H8r, self.W8r)).astype(np.float32)
+        self.kind = np.zeros((self.H8r, self.W8r), dtype=np.uint8)  # JXLGPU_DCT8
+        m_lf = [1.0 / 32.0, 1.0 / 4.0, 1.0 / 2.0]
+        self.lfq, self.coeff = [], []
+        for c in range(3):
+            cw, ch = self.cw[c], self.ch[c]
+            yy, xx = np.mgrid[0:ch, 0:cw]
+            step = m_lf[c] * 512.0 / (self.global_scale * self.quant_lf)
+            target = (0.2 if c == 1 else 0.08) * np.sin(xx / 5.0 + c) * np.cos(yy / 7.0)  # centred YCbCr
+            self.lfq.append(np.rint(target / step + rng.normal(0, 0.6, size=(ch, cw))).astype(lf_dt))
+            # HF: Laplacian quantised coefficients, ~85 % zeros, DC position empty (hf_coeff.rs)
+            pos = np.add.outer(np.arange(8), np.arange(8))
+            amp = 6.0 / (1.0 + pos)
+            vals = rng.laplace(0.0, 1.0, size=(ch, cw, 8, 8)) * amp
+            keep = rng.random(size=(ch, cw, 8, 8)) >= 0.85
+            q = np.where(keep, np.rint(vals), 0).astype(np.int32)
+            q[:, :, 0, 0] = 0
+            self.coeff.append(np.ascontiguousarray(q.transpose(0, 2, 1, 3).reshape(ch * 8, cw * 8)))
+        self.filter = abi.FilterParams()
+        self.filter.gab_enabled = 1 if gabor else 0
+        for c in range(3):
+            self.filter.gab_weights[c][0] = 0.115169525
+            self.filter.gab_weights[c][1] = 0.061248592
+        self.filter.epf_iters = epf_iters
+        self.filter.epf_channel_scale[:] = [40.0, 5.0, 3.5]
+        self.filter.epf_pass0_sigma_scale = 0.9
+        self.filter.epf_pass2_sigma_scale = 6.5
+        self.filter.epf_border_sad_mul = 2.0 / 3.0
+        self.filter.epf_sigma_for_modular = 1.0
+        self.color = abi.ColorParams()
+        self.color.ycbcr = 1
+        self._keep = []
+
+    def desc(self):
+        d = abi.VardctDesc()
+        d.abi = abi.ABI_VERSION
+        d.width, d.height, d.group_dim = self.width, self.height, self.group_dim
+        d.lf_sample_type = self.lf_sample_type
+        d.jpeg_upsampling[:] = self.ju
+        d.coeff_format, d.coeff_sample_type = abi.COEFF_DENSE, abi.SAMPLE_I32
+        d.coeff_stride = self.W8r * 8
+        for c in range(3):
+            assert self.coeff[c].shape[1] == (d.coeff_stride >> self.shifts[c][0])
+            d.coeff[c] = self.coeff[c].ctypes.data
+        lf_dim = self.group_dim * 8
+        gx_n, gy_n = -(-self.width // lf_dim), -(-self.height // lf_dim)
+        groups = (abi.LfGroup * (gx_n * gy_n))()
+        keep = []
+        SRC = [1, 0, 2]  # lf_quant channel k holds framebuffer channel SRC^-1: [0]=Y, [1]=X/Cb, [2]=B/Cr
+        for gy in range(gy_n):
+            for gx in range(gx_n):
+                g = groups[gy * gx_n + gx]
+                wpx = min(lf_dim, self.width - gx * lf_dim)
+                hpx = min(lf_dim, self.height - gy * lf_dim)
+                g.width_px, g.height_px = wpx, hpx
+                gbw, gbh = -(-wpx // 8), -(-hpx // 8)
+                bw = -(-gbw // 2) * 2 if self.has_h else gbw
+                bh = -(-gbh // 2) * 2 if self.has_v else gbh
+                cwt, cht = -(-wpx // 64), -(-hpx // 64)
+                cells = self.group_dim
+                sl = (slice(gy * cells, gy * cells + bh), slice(gx * cells, gx * cells + bw))
+                arrs = dict(kind=np.ascontiguousarray(self.kind[sl]), mul=np.ascontiguousarray(self.hf_mul[sl]),
+                            sigma=np.ascontiguousarray(self.sigma[sl]),
+                            xfy=np.zeros((cht, cwt), np.int32), bfy=np.zeros((cht, cwt), np.int32), lfq=[None] * 3)
+                assert arrs["kind"].shape == (bh, bw)
+                for k in range(3):
+                    c = SRC[k]
+                    h, v = self.shifts[c]
+                    lw, lh = _ssize(gbw, self.has_h, h), _ssize(gbh, self.has_v, v)
+                    ox, oy = (gx * cells) >> h, (gy * cells) >> v
+                    a = np.ascontiguousarray(self.lfq[c][oy:oy + lh, ox:ox + lw])
+                    assert a.shape == (lh, lw)
+                    arrs["lfq"][k] = a
+                    g.lf_quant[k] = a.ctypes.data
+                keep.append(arrs)
+                g.extra_precision = (gx + gy) % 2
+                g.has_hf_meta = 1
+                g.block_kind = arrs["kind"].ctypes.data_as(abi.u8p)
+                g.hf_mul = arrs["mul"].ctypes.data_as(abi.i32p)
+                g.epf_sigma = arrs["sigma"].ctypes.data_as(abi.f32p)
+                g.x_from_y = arrs["xfy"].ctypes.data_as(abi.i32p)
+                g.b_from_y = arrs["bfy"].ctypes.data_as(abi.i32p)
+        d.num_lf_groups = gx_n * gy_n
+        d.lf_groups = C.cast(groups, C.POINTER(abi.LfGroup))
+        d.global_scale, d.quant_lf = self.global_scale, self.quant_lf
+        d.m_lf[:] = [1.0 / 32.0, 1.0 / 4.0, 1.0 / 2.0]
+        d.colour_factor = 84
+        d.base_correlation_x, d.base_correlation_b = 0.0, 1.0
+        d.x_factor_lf, d.b_factor_lf = 128, 128
+        d.x_qm_scale, d.b_qm_scale = 2, 2
+        d.quant_bias[:] = list(QUANT_BIAS)
+        d.quant_bias_numerator = QUANT_BIAS_NUMERATOR
+        d.skip_adaptive_lf_smoothing = 1
+        for t in range(abi.NUM_TRANSFORMS):
+            for c in range(3):
+                d.dequant[t][c] = self.mats[t][c].ctypes.data_as(abi.f32p)
+        for i in range(3):
+            d.sec_half_large[i] = self.sec[i].ctypes.data_as(abi.f32p)
+        d.filter = self.filter
+        d.color = self.color
+        d.upsampling.factor = 1
+        self._keep = [groups, keep]
+        return d

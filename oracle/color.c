@@ -247,6 +247,10 @@ static void matmul3vec(const float a[9], float v[3]) {
 /* convert.rs:619-659 runs the op list per 65 536-sample chunk; every op is per-sample, so the
  * per-sample composition below is arithmetically identical. */
 void orc_color_transform(float* const ch[3], size_t n, const JxlGpuColorParams* cp) {
+    if (cp->ycbcr) {  /* lib.rs:950-954: do_ycbcr frames are not XYB */
+        orc_ycbcr_to_rgb(ch[0], ch[1], ch[2], n);
+        return;
+    }
     if (!cp->enabled) return;
     float itscale = 255.0f / cp->intensity_target;
     float cbrt_ob[3];

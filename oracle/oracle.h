@@ -79,6 +79,13 @@ void orc_predict_apply(void* tile, size_t stride, size_t width, size_t height, i
 void orc_palette_delta_pass(void* grid, size_t stride, size_t width, size_t height, int esz,
                             const uint8_t* need_delta, uint32_t d_pred, const int32_t wp[11]);
 
+/* jpeg.c: chroma-subsampled VarDCT (JPEG transcodes), chroma upsampling, YCbCr -> RGB */
+void orc_jpeg_shift(const uint32_t jpeg_upsampling[3], int idx, int* hshift, int* vshift, int* has_h, int* has_v);
+void orc_upsample_jpeg(const float* in, size_t in_stride, size_t in_w, size_t in_h, int hshift, int vshift,
+                       float* out, size_t target_width, size_t target_height);
+void orc_ycbcr_to_rgb(float* cb_r, float* y_g, float* cr_b, size_t n);
+int orc_vardct_subsampled(const JxlGpuVardctDesc* d, float* const full[3]);
+
 /* OpenMP thread count of the oracle's parallel loops (returns the value in effect). */
 int jxl_oracle_set_threads(int n);
 

@@ -355,12 +355,19 @@ static void build_frame_meta(const JxlGpuVardctDesc* d, FrameMeta* m) {
         size_t bw = (lg->width_px + 7) / 8, bh = (lg->height_px + 7) / 8;
         size_t cw = (lg->width_px + 63) / 64, ch = (lg->height_px + 63) / 64;
         size_t cell0x = gx * d->group_dim, cell0y = gy * d->group_dim;
+        /* hf_metadata.rs:70-81: the group's grids are rounded to even cell counts when subsampled */
+        size_t gstride = bw;
+        {
+            int hs_, vs_, has_h = 0, has_v = 0;
+            orc_jpeg_shift(d->jpeg_upsampling, 0, &hs_, &vs_, &has_h, &has_v);
+            if (has_h) gstride = (bw + 1) / 2 * 2;
+        }
         for (size_t y = 0; y < bh; ++y)
             for (size_t x = 0; x < bw; ++x) {
                 size_t o = (cell0y + y) * w8 + cell0x + x;
-                m->kind[o] = lg->block_kind[y * bw + x];
-                m->hf_mul[o] = lg->hf_mul[y * bw + x];
-                if (lg->epf_sigma) m->sigma[o] = lg->epf_sigma[y * bw + x];
+                m->kind[o] = lg->block_kind[y * gstride + x];
+                m->hf_mul[o] = lg->hf_mul[y * gstride + x];
+                if (lg->epf_sigma) m->sigma[o] = lg->epf_sigma[y * gstride + x];
             }
         size_t t0x = gx * (lf_dim / 64), t0y = gy * (lf_dim / 64);
         for (size_t y = 0; y < ch; ++y)
@@ -489,7 +496,26 @@ static void transform_group(const JxlGpuVardctDesc* d, const FrameMeta* m, float
 int jxl_oracle_vardct_render(const JxlGpuVardctDesc* d, uint32_t stages, float* const out[3],
                              uint32_t out_stride, float* const lf_out[3]) {
     if (d->abi != JXLGPU_ABI_VERSION) return JXLGPU_ERR_ABI;
-    if (d->jpeg_upsampling[0] | d->jpeg_upsampling[1] | d->jpeg_upsampling[2]) return JXLGPU_ERR_UNSUPPORTED;
+    if (d->jpeg_upsampling[0] | d->jpeg_upsampling[1] | d->jpeg_upsampling[2]) {
+        /* chroma-subsampled frame (jpeg.c): per-channel geometry up to upsample_jpeg, then the
+         * common tail of render.rs:70-156 on full-resolution planes */
+        if (lf_out && lf_out[0]) return JXLGPU_ERR_INVALID_ARG;
+        size_t W = d->width, H = d->height, w8s = (W + 7) / 8;
+        for (int n = 64, i = 0; n <= 256; n *= 2, ++i)
+            if (d->sec_half_large[i]) orc_set_sec_half_large(n, d->sec_half_large[i]);
+        float* full[3];
+        for (int c = 0; c < 3; ++c) full[c] = (float*)calloc(W * H, sizeof(float));
+        int rc = orc_vardct_subsampled(d, full);
+        if (rc == 0) {
+            FrameMeta m;
+            build_frame_meta(d, &m);
+            rc = orc_post_stages(full, W, W, H, m.sigma, w8s, &d->filter, &d->upsampling, &d->noise, d->group_dim,
+                                 d->base_correlation_x, d->base_correlation_b, &d->color, stages, out, out_stride);
+            free_frame_meta(&m);
+        }
+        for (int c = 0; c < 3; ++c) free(full[c]);
+        return rc;
+    }
     /* the reference's framebuffer holds dense i32 coefficients (vardct/mod.rs:262-265); the compact
      * transports of the device ABI are rebuilt to exactly that before anything is computed */
     if (d->coeff_format != JXLGPU_COEFF_DENSE || d->coeff_sample_type != JXLGPU_SAMPLE_I32) return JXLGPU_ERR_INVALID_ARG;

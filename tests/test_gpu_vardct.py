@@ -119,6 +119,10 @@ def test_colour_op_lists(gpu_ctx, oracle, mode, it):
     finally:
         frame.free()
     assert_ulp(got2, exp2, MAX_ULP, f"colour {mode} (colour-only stage)")
+    # default filter configuration at a size where the streaming kernel covers the interior
+    wl = VardctWorkload(264, 200, seed=32, intensity_target=it, color_mode=mode)
+    got3, exp3 = _both(gpu_ctx, oracle, wl, S_ALL)
+    assert_ulp(got3, exp3, MAX_ULP, f"colour {mode} (streaming kernel)")
 
 
 @pytest.mark.parametrize("w,h,up,epf", [(520, 300, 1, 2), (264, 200, 1, 0), (72, 56, 2, 1), (40, 24, 8, 1), (257, 3, 1, 1)])
