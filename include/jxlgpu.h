@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 10u
+#define JXLGPU_ABI_VERSION 11u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -265,6 +265,34 @@ const float* jxlgpu_frame_result_plane(const jxlgpu_frame* frame, uint32_t c);
 /* Intermediate buffers for stage-level parity tests: the LF image after V1-V3 (3 planes,
  * ceil(width/8) x ceil(height/8)).  Copies to host.                                                */
 int jxlgpu_frame_download_lf(jxlgpu_ctx* ctx, const jxlgpu_frame* frame, float* const planes[3]);
+
+/* ---- frame compositing primitive: `blend_single`, jxl-render/src/blend.rs:550-728 ----
+ * The per-sample arithmetic of frame blending (`blend`, blend.rs:179-416) and of patches (`patch`,
+ * :418-548) on device planes; choosing channels, alpha planes, reference frames and regions stays
+ * with the caller, as in the reference.  Rectangles are applied in list order (patches overlap).   */
+#define JXLGPU_BLEND_REPLACE 0u
+#define JXLGPU_BLEND_ADD 1u
+#define JXLGPU_BLEND_MUL 2u       /* BlendMode::Mul(clamp)                                          */
+#define JXLGPU_BLEND_BLEND 3u     /* BlendMode::Blend(BlendAlpha); new_alpha == NULL -> Replace      */
+#define JXLGPU_BLEND_MULADD 4u    /* BlendMode::MulAdd(BlendAlpha); new_alpha == NULL -> Add         */
+#define JXLGPU_BLEND_MIXALPHA 5u  /* BlendMode::MixAlpha { clamp, swapped } (the alpha channel itself) */
+#define JXLGPU_BLEND_SKIP 6u
+typedef struct {
+    uint32_t mode;                 /* JXLGPU_BLEND_*                                                  */
+    uint32_t clamp, swapped, premultiplied;
+    const float* base_alpha;       /* device plane addressed like `base`, or NULL (alpha = 0)          */
+    uint32_t base_alpha_stride;
+    const float* new_alpha;        /* device plane addressed like `new_plane`, or NULL                 */
+    uint32_t new_alpha_stride;
+    uint32_t base_x, base_y;       /* BlendParams.base_topleft                                        */
+    uint32_t new_x, new_y;         /* BlendParams.new_topleft                                         */
+    uint32_t width, height;
+} JxlGpuBlendRect;
+/* `base` (base_w x base_h, stride base_stride) and `new_plane` are device pointers, e.g. from
+ * jxlgpu_frame_result_plane.  Asynchronous on the ctx stream.                                       */
+int jxlgpu_blend_rects(jxlgpu_ctx* ctx, float* base, uint32_t base_stride, uint32_t base_w, uint32_t base_h,
+                       const float* new_plane, uint32_t new_stride, uint32_t new_w, uint32_t new_h,
+                       const JxlGpuBlendRect* rects, uint32_t num_rects);
 
 /* ---- output formatting on the device (the step right after the path) ----
  * `ImageStream::write_to_buffer` (jxl-oxide/src/fb.rs:309-397, sample conversion :436-527):

@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -95,6 +95,28 @@ class ColorParams(C.Structure):
         ("tm_gamut_map", C.c_uint32),
         ("tm_gamut_saturation_factor", C.c_float),
         ("ycbcr", C.c_uint32),
+    ]
+
+
+(BLEND_REPLACE, BLEND_ADD, BLEND_MUL, BLEND_BLEND, BLEND_MULADD, BLEND_MIXALPHA, BLEND_SKIP) = range(7)
+
+
+class BlendRect(C.Structure):
+    _fields_ = [
+        ("mode", C.c_uint32),
+        ("clamp", C.c_uint32),
+        ("swapped", C.c_uint32),
+        ("premultiplied", C.c_uint32),
+        ("base_alpha", C.c_void_p),
+        ("base_alpha_stride", C.c_uint32),
+        ("new_alpha", C.c_void_p),
+        ("new_alpha_stride", C.c_uint32),
+        ("base_x", C.c_uint32),
+        ("base_y", C.c_uint32),
+        ("new_x", C.c_uint32),
+        ("new_y", C.c_uint32),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
     ]
 
 
@@ -251,6 +273,8 @@ _SYMBOLS = [
     ("jxlgpu_modular_upload", C.c_int, [C.c_void_p, C.POINTER(ModularDesc), C.POINTER(C.c_void_p)]),
     ("jxlgpu_modular_inverse", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     ("jxlgpu_modular_render", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Out)]),
+    ("jxlgpu_blend_rects", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                     C.c_uint32, C.c_uint32, C.POINTER(BlendRect), C.c_uint32]),
 ]
 
 SYMBOL_NAMES = [s[0] for s in _SYMBOLS]

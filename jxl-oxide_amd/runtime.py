@@ -118,6 +118,12 @@ class Context:
         self._check(self.lib.jxlgpu_vardct_render_host(self.handle, C.byref(desc), stages, C.byref(o)))
         return out
 
+    def blend_rects(self, base_ptr, base_stride, base_w, base_h, new_ptr, new_stride, new_w, new_h, rects):
+        """blend_single on device planes (raw device pointers); `rects`: list of abi.BlendRect."""
+        arr = (abi.BlendRect * len(rects))(*rects)
+        self._check(self.lib.jxlgpu_blend_rects(self.handle, base_ptr, base_stride, base_w, base_h, new_ptr,
+                                                new_stride, new_w, new_h, arr, len(rects)))
+
     def format_output(self, frame, sample_format, orientation=1):
         """Interleaved, oriented f32/u16/u8 image of the last render (formatted on the device)."""
         w, h = frame.out_size(abi.STAGE_ALL)

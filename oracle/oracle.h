@@ -86,6 +86,9 @@ void orc_upsample_jpeg(const float* in, size_t in_stride, size_t in_w, size_t in
 void orc_ycbcr_to_rgb(float* cb_r, float* y_g, float* cr_b, size_t n);
 int orc_vardct_subsampled(const JxlGpuVardctDesc* d, float* const full[3]);
 
+/* blend.c: blend_single on one channel rectangle (alpha planes are host pointers) */
+void orc_blend_rect(float* base, size_t base_stride, const float* new_grid, size_t new_stride, const JxlGpuBlendRect* r);
+
 /* OpenMP thread count of the oracle's parallel loops (returns the value in effect). */
 int jxl_oracle_set_threads(int n);
 

@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import re
 
+import pytest
+
 from jxl_oxide_amd import abi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,3 +63,34 @@ def test_no_gpu_means_a_loud_error():
     h = C.c_void_p()
     assert lib.jxlgpu_create(0, C.byref(h)) != abi.OK
     assert not h.value
+
+
+def _build_c_caller(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(root, "jxl-oxide_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "abi_smoke.c"), "-o", exe, "-L", libdir, "-ljxlgpu",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+    return exe
+
+
+def test_c_caller_compiles_links_and_fails_loudly_without_a_gpu(tmp_path):
+    """include/jxlgpu.h is plain C11; a C program links against libjxlgpu.so and, on a host without
+    a GPU, gets JXLGPU_ERR_DEVICE from jxlgpu_create (exit code 3) — no silent CPU path."""
+    import subprocess
+    import torch
+    exe = _build_c_caller(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked variant")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_c_caller_renders_on_the_gpu(tmp_path):
+    import subprocess
+    exe = _build_c_caller(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)
