@@ -547,6 +547,13 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     TRY(dev_upload(ctx, f, &f->dequant, deq));
     TRY(dev_upload(ctx, f, &f->deq_off, deq_off));
     {
+        // quant_bias_numerator / k with the host's IEEE f32 division == the device's correctly
+        // rounded one; entries 0 and 1 are never selected (|q| <= 1 takes the quant_bias branch)
+        std::vector<float> lut(256, 0.0f);
+        for (int k = 2; k < 256; ++k) lut[k] = d->quant_bias_numerator / (float)k;
+        TRY(dev_upload(ctx, f, &f->deq_lut, lut));
+    }
+    {
         // one entry array (classes concatenated) + one descriptor per workgroup of the <=32 kernel,
         // widest shapes first so the long workgroups start early
 #ifndef JXL_VB_TILE
@@ -1057,6 +1064,8 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
     ta.global_scale = (float)d.global_scale;
     ta.quant_bias_numerator = d.quant_bias_numerator;
     ta.big_tmp = f->big_tmp;
+    static const bool no_lut = getenv("JXLGPU_NO_DEQ_LUT") != nullptr;
+    ta.deq_lut = no_lut ? nullptr : f->deq_lut;
     ctx->prof_begin(PROF_TRANSFORM);
     const bool has64 = f->list_count[CLS_64x64] | f->list_count[CLS_32x64] | f->list_count[CLS_64x32] |
                        f->list_count[CLS_SPECIAL8];

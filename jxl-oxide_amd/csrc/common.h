@@ -53,6 +53,7 @@ struct TransformArgs {
     float quant_bias[3];
     float quant_bias_numerator;
     float* big_tmp;            // 3 planes of pstride x (h8*8) scratch for the >=128 path
+    const float* deq_lut;      // 256 x quant_bias_numerator / k (k >= 2), or nullptr: divide
 };
 
 struct LfArgs {
@@ -209,6 +210,7 @@ struct jxlgpu_frame {
     uint32_t noise_w = 0, noise_h = 0;
     uint32_t noise_group_dim = 256;
     float noise_corr_x = 0.0f, noise_corr_b = 1.0f;  // base_correlations_xb (render.rs:175-180)
+    float* deq_lut = nullptr;            // quant_bias_numerator / k, k < 256 (dequant_one_lut)
     uint32_t* ring_tiles = nullptr;      // outer ring of 32x32 tiles for the fused tile kernel
     uint32_t n_ring_tiles = 0;
     float* up_weights[3] = {};  // expanded 5x5 kernels per phase for 2x/4x/8x

@@ -89,6 +89,24 @@ __device__ __forceinline__ float dequant_one(int32_t qn, float quant_bias, float
     return q;
 }
 
+// The same value through a table of quant_bias_numerator / k (k = |q| < 256, built on the host with
+// the same correctly rounded f32 division): qbn / q == sign(q) * (qbn / |q|) exactly, so only the
+// rare |q| >= 256 still divides.  Saves the 12-instruction division sequence and the per-coefficient
+// exec-mask branches in the hot A1 loop.
+__device__ __forceinline__ float dequant_one_lut(int32_t qn, float quant_bias, float qbn, const float* qlut, float m,
+                                                 float mul) {
+    float q = (float)qn;
+    const uint32_t aq = qn < 0 ? 0u - (uint32_t)qn : (uint32_t)qn;
+    float t = qlut[min(aq, 255u)];
+    if (__builtin_expect(aq > 255u, 0)) t = qbn / fabsf(q);
+    const float big = q - (qn < 0 ? -t : t);
+    const float small = q * quant_bias;
+    q = aq <= 1u ? small : big;
+    q *= m;
+    q *= mul;
+    return q;
+}
+
 // ---------------------------------------------------------------- V8: special 8x8 transforms
 // jxl-render/src/vardct/generic/transform.rs:14-219, operating on one 8x8 block in LDS
 // (row stride S).  One lane per (block, channel); these types are ~10 % of blocks.
@@ -301,9 +319,9 @@ struct VbCfg {
     static constexpr int LDS_WORDS = 3 * CH + NB;  // tiles + per-block cell position
 };
 
-template <int W, int H, bool SPECIAL, int NT = 256, int NBX = VbCfg<W, H>::NB>
+template <int W, int H, bool SPECIAL, int NT = 256, int NBX = VbCfg<W, H>::NB, bool LUT = false>
 __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* __restrict__ entries,
-                                          int nvalid, float* lds) {
+                                          int nvalid, float* lds, const float* qlut = nullptr) {
     using Cfg = VbCfg<W, H>;
     constexpr int NB = NBX, S = Cfg::S, BLK = Cfg::BLK, CH = NB * BLK, BW = Cfg::BW, BH = Cfg::BH;
     float* tile = lds;
@@ -341,10 +359,17 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float mul = mul_base * a.qm_scale[c];
-            d[c][0] = dequant_one(q[c].x, a.quant_bias[c], a.quant_bias_numerator, m[c].x, mul);
-            d[c][1] = dequant_one(q[c].y, a.quant_bias[c], a.quant_bias_numerator, m[c].y, mul);
-            d[c][2] = dequant_one(q[c].z, a.quant_bias[c], a.quant_bias_numerator, m[c].z, mul);
-            d[c][3] = dequant_one(q[c].w, a.quant_bias[c], a.quant_bias_numerator, m[c].w, mul);
+            if constexpr (LUT) {
+                d[c][0] = dequant_one_lut(q[c].x, a.quant_bias[c], a.quant_bias_numerator, qlut, m[c].x, mul);
+                d[c][1] = dequant_one_lut(q[c].y, a.quant_bias[c], a.quant_bias_numerator, qlut, m[c].y, mul);
+                d[c][2] = dequant_one_lut(q[c].z, a.quant_bias[c], a.quant_bias_numerator, qlut, m[c].z, mul);
+                d[c][3] = dequant_one_lut(q[c].w, a.quant_bias[c], a.quant_bias_numerator, qlut, m[c].w, mul);
+            } else {
+                d[c][0] = dequant_one(q[c].x, a.quant_bias[c], a.quant_bias_numerator, m[c].x, mul);
+                d[c][1] = dequant_one(q[c].y, a.quant_bias[c], a.quant_bias_numerator, m[c].y, mul);
+                d[c][2] = dequant_one(q[c].z, a.quant_bias[c], a.quant_bias_numerator, m[c].z, mul);
+                d[c][3] = dequant_one(q[c].w, a.quant_bias[c], a.quant_bias_numerator, m[c].w, mul);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -461,30 +486,6 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
     }
 }
 
-// All varblock shapes up to 32x32 in ONE launch: every workgroup reads its descriptor
-// {class, first entry, count} and branches (workgroup-uniformly) into the code for that shape, so
-// the thin classes (a few hundred 32x8 blocks...) fill the machine together instead of each
-// paying a launch and a tail.
-__global__ __launch_bounds__(256) void transform_small_kernel(TransformArgs a, const uint4* __restrict__ wgs,
-                                                              const uint4* __restrict__ entries) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const uint4 wg = wgs[blockIdx.x];
-    const uint4* e = entries + wg.y;
-    const int n = (int)wg.z;
-    switch (wg.x) {
-        case CLS_DCT8: run_class<8, 8, false>(a, e, n, lds); break;
-        case CLS_16x16: run_class<16, 16, false>(a, e, n, lds); break;
-        case CLS_8x16: run_class<8, 16, false>(a, e, n, lds); break;
-        case CLS_16x8: run_class<16, 8, false>(a, e, n, lds); break;
-        case CLS_32x32: run_class<32, 32, false>(a, e, n, lds); break;
-        case CLS_8x32: run_class<8, 32, false>(a, e, n, lds); break;
-        case CLS_32x8: run_class<32, 8, false>(a, e, n, lds); break;
-        case CLS_16x32: run_class<16, 32, false>(a, e, n, lds); break;
-        case CLS_32x16: run_class<32, 16, false>(a, e, n, lds); break;
-        default: break;
-    }
-}
-
 constexpr int kSmallLdsWords = VbCfg<8, 8>::LDS_WORDS > VbCfg<32, 32>::LDS_WORDS ? VbCfg<8, 8>::LDS_WORDS : VbCfg<32, 32>::LDS_WORDS;  // max over the classes above
 static_assert(VbCfg<8, 8>::LDS_WORDS <= kSmallLdsWords && VbCfg<16, 16>::LDS_WORDS <= kSmallLdsWords &&
               VbCfg<8, 16>::LDS_WORDS <= kSmallLdsWords && VbCfg<16, 8>::LDS_WORDS <= kSmallLdsWords &&
@@ -492,10 +493,45 @@ static_assert(VbCfg<8, 8>::LDS_WORDS <= kSmallLdsWords && VbCfg<16, 16>::LDS_WOR
               VbCfg<32, 8>::LDS_WORDS <= kSmallLdsWords && VbCfg<16, 32>::LDS_WORDS <= kSmallLdsWords &&
               VbCfg<32, 16>::LDS_WORDS <= kSmallLdsWords, "LDS budget of transform_small_kernel");
 
+// All varblock shapes up to 32x32 in ONE launch: every workgroup reads its descriptor
+// {class, first entry, count} and branches (workgroup-uniformly) into the code for that shape, so
+// the thin classes (a few hundred 32x8 blocks...) fill the machine together instead of each
+// paying a launch and a tail.
+template <bool LUT>
+__global__ __launch_bounds__(256) void transform_small_kernel(TransformArgs a, const uint4* __restrict__ wgs,
+                                                              const uint4* __restrict__ entries) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const uint4 wg = wgs[blockIdx.x];
+    const uint4* e = entries + wg.y;
+    const int n = (int)wg.z;
+    // quant_bias_numerator / k table behind the tiles (dequant_one_lut); nullptr keeps the division
+    float* qlut = nullptr;
+    if constexpr (LUT) {
+        qlut = lds + kSmallLdsWords;
+        qlut[threadIdx.x] = a.deq_lut[threadIdx.x];
+        __syncthreads();
+    }
+    switch (wg.x) {
+        case CLS_DCT8: run_class<8, 8, false, 256, VbCfg<8, 8>::NB, LUT>(a, e, n, lds, qlut); break;
+        case CLS_16x16: run_class<16, 16, false, 256, VbCfg<16, 16>::NB, LUT>(a, e, n, lds, qlut); break;
+        case CLS_8x16: run_class<8, 16, false, 256, VbCfg<8, 16>::NB, LUT>(a, e, n, lds, qlut); break;
+        case CLS_16x8: run_class<16, 8, false, 256, VbCfg<16, 8>::NB, LUT>(a, e, n, lds, qlut); break;
+        case CLS_32x32: run_class<32, 32, false, 256, VbCfg<32, 32>::NB, LUT>(a, e, n, lds, qlut); break;
+        case CLS_8x32: run_class<8, 32, false, 256, VbCfg<8, 32>::NB, LUT>(a, e, n, lds, qlut); break;
+        case CLS_32x8: run_class<32, 8, false, 256, VbCfg<32, 8>::NB, LUT>(a, e, n, lds, qlut); break;
+        case CLS_16x32: run_class<16, 32, false, 256, VbCfg<16, 32>::NB, LUT>(a, e, n, lds, qlut); break;
+        case CLS_32x16: run_class<32, 16, false, 256, VbCfg<32, 16>::NB, LUT>(a, e, n, lds, qlut); break;
+        default: break;
+    }
+}
+
+
+
 void launch_transform_small(hipStream_t s, const TransformArgs& a, const uint4* wgs, uint32_t n_wgs,
                             const uint4* entries) {
     if (!n_wgs) return;
-    transform_small_kernel<<<n_wgs, 256, kSmallLdsWords * sizeof(float), s>>>(a, wgs, entries);
+    if (a.deq_lut) transform_small_kernel<true><<<n_wgs, 256, (kSmallLdsWords + 256) * sizeof(float), s>>>(a, wgs, entries);
+    else transform_small_kernel<false><<<n_wgs, 256, kSmallLdsWords * sizeof(float), s>>>(a, wgs, entries);
 }
 
 // The 8x8 non-DCT family (Hornuss, DCT2, DCT4, 4x8, 8x4, AFV): register-hungry serial code per
