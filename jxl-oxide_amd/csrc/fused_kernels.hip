@@ -29,6 +29,16 @@ struct PostCfg {
     static constexpr int PLANE = LW * LW;
 };
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Uniform constants of the packed streaming kernel as {c, c} pairs (see stream_pk.inc).
+struct PkConsts {
+    f2 zero, one, K;
+    f2 gw0[3], gw1[3], ggw[3], cs[3];
+    f2 cbrt_ob[3], ob[3], itscale, mat[9];
+    f2 srgb_p[6];   // tf/srgb.rs:36-46 polynomial, 12.92, -0.055
+};
+
 struct FusedArgs {
     const float* in[3];
     float* out[3];
@@ -42,6 +52,7 @@ struct FusedArgs {
     const uint32_t* tiles;   // optional list of tiles (tx | ty << 16); null = full 2-D grid
     // streaming kernel geometry: it covers [sx0, sx1) x [sy0, sy1), strictly inside the image
     int sx0, sx1, sy0, sy1, rows_per_seg, strips, segs;
+    PkConsts pk;
 };
 
 // Refill the out-of-image cells of the square region [lo, LW-lo) of `buf` (3 planes) from their
@@ -218,11 +229,13 @@ __global__ __launch_bounds__(256) void fused_post_kernel(FusedArgs a) {
 constexpr int SW = 56;  // outputs per strip
 constexpr int SH = 4;   // halo lanes / rows (1 Gabor + 2 EPF step 1 + 1 EPF step 2)
 
+// bound_ctrl = 1: the lane without a source (0 resp. 63, always a halo lane) reads 0, which is what
+// `old = 0` gave it before, but without the v_mov that materialised `old` in front of every shift.
 __device__ __forceinline__ float from_left(float v) {   // value held by lane - 1 (pixel x - 1)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float from_right(float v) {  // value held by lane + 1 (pixel x + 1)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
 struct StreamState {
@@ -439,6 +452,8 @@ __global__ __launch_bounds__(256) void post_stream_kernel(FusedArgs a) {
     }
 }
 
+#include "stream_pk.inc"
+
 template <bool GAB, int ITERS>
 void launch_cfg(hipStream_t s, const FusedArgs& a) {
     dim3 grid(ceil_div(a.width, T), ceil_div(a.height, T));
@@ -452,6 +467,28 @@ void launch_cfg(hipStream_t s, const FusedArgs& a) {
     fused_post_kernel<GAB, ITERS><<<grid, 256, lds_bytes, s>>>(a);
 }
 
+}  // namespace
+
+namespace {
+void fill_pk_consts(FusedArgs& a) {
+    auto sp = [](float v) { return f2{v, v}; };
+    PkConsts& k = a.pk;
+    k.zero = sp(0.0f); k.one = sp(1.0f);
+    const float FRAC_1_SQRT_2 = 0.70710678118654752440f;
+    k.K = sp(6.6f * (FRAC_1_SQRT_2 - 1.0f));
+    for (int c = 0; c < 3; ++c) {
+        const float w0 = a.fp.gab_weights[c][0], w1 = a.fp.gab_weights[c][1];
+        k.gw0[c] = sp(w0); k.gw1[c] = sp(w1);
+        k.ggw[c] = sp(1.0f / (1.0f + w0 * 4.0f + w1 * 4.0f));
+        k.cs[c] = sp(a.fp.epf_channel_scale[c]);
+        k.cbrt_ob[c] = sp(a.color.cbrt_opsin_bias[c]);
+        k.ob[c] = sp(a.color.opsin_bias[c]);
+    }
+    k.itscale = sp(a.color.itscale);
+    for (int i = 0; i < 9; ++i) k.mat[i] = sp(a.color.matrix[i]);
+    const float srgb[6] = {0.059914046f, -0.10889456f, 0.107963754f, 0.018092343f, 12.92f, -0.055f};
+    for (int i = 0; i < 6; ++i) k.srgb_p[i] = sp(srgb[i]);
+}
 }  // namespace
 
 bool fused_post_supported(const jxlgpu_frame* f, bool gabor, int epf_iters) {
@@ -503,8 +540,29 @@ void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3],
         const bool plain_srgb = a.color.tf == JXLGPU_TF_SRGB && !a.color.gamut_map && !a.color.has_matrix2 &&
                                 !a.color.tone_map && !a.color.ycbcr;
         if (ctx && ctx->stream2) (void)hipEventRecord(ctx->ev_fork, s);  // inputs are ready here
-        if (plain_srgb) post_stream_kernel<JXLGPU_TF_SRGB><<<(waves + 3) / 4, 256, 0, s>>>(a);
-        else post_stream_kernel<-1><<<(waves + 3) / 4, 256, 0, s>>>(a);
+        static const bool use_pk = getenv("JXLGPU_STREAM_PK") != nullptr;
+        if (use_pk) {
+            // two strips per wave (stream_pk.inc): pick the segment height that fills the 1024 SIMDs evenly
+            const int pairs = (a.strips + 1) / 2;
+            if (!getenv("JXLGPU_STREAM_ROWS")) {
+                long best_cost = -1;
+                for (int rows = 24; rows <= 96; rows += 4) {
+                    const long segs = (a.sy1 - a.sy0 + rows - 1) / rows;
+                    const long rounds = (pairs * segs + 1023) / 1024;
+                    const long cost = rounds * (rows + 2 * SH);
+                    if (best_cost < 0 || cost < best_cost) { best_cost = cost; a.rows_per_seg = rows; }
+                }
+                a.segs = (a.sy1 - a.sy0 + a.rows_per_seg - 1) / a.rows_per_seg;
+            }
+            fill_pk_consts(a);
+            const int pk_waves = pairs * a.segs;
+            if (plain_srgb) post_stream_pk_kernel<JXLGPU_TF_SRGB><<<(pk_waves + 3) / 4, 256, 0, s>>>(a);
+            else post_stream_pk_kernel<-1><<<(pk_waves + 3) / 4, 256, 0, s>>>(a);
+        } else if (plain_srgb) {
+            post_stream_kernel<JXLGPU_TF_SRGB><<<(waves + 3) / 4, 256, 0, s>>>(a);
+        } else {
+            post_stream_kernel<-1><<<(waves + 3) / 4, 256, 0, s>>>(a);
+        }
         a.tiles = f->ring_tiles;
         constexpr size_t lds_bytes = 2 * 3 * PostCfg<true, 2>::PLANE * sizeof(float);
         // the border ring (a few hundred long-latency tiles) runs beside the streaming kernel
