@@ -163,7 +163,7 @@ def main():
                 (f0.algorithmic_bytes(stages) * total_frames / elapsed / 1e9) / HBM_PEAK_GBS, 4),
         }
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (bounded CPU sample)
             cpu = cpu_baseline(wls[0], stages, args.cpu_seconds, mp_per_frame)
         out = {
             "metric": "Megapixels/sec decoded (4K VarDCT d1)",

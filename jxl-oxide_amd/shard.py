@@ -83,3 +83,27 @@ def gather_planes(local, dst=0, group=None):
 def render_frames_sharded(n_frames, render_fn, rank, world):
     """Each rank renders its block of frames with `render_fn(frame_index) -> array/tensor`."""
     return {i: render_fn(i) for i in frame_shard(n_frames, rank, world)}
+
+
+def gather_formatted(ctx, frame, sample_format, orientation=1, dst=0, group=None):
+    """The last render of `frame`, formatted on the device (interleaved, oriented, u8 / u16 / f32:
+    jxlgpu_frame_format_output) straight into a torch tensor on this rank's
+    GPU, then gathered to `dst` with ONE collective (RCCL over xGMI when the tensors are on GPUs).
+    u8 output moves 3 B/px instead of the 12 B/px of planar f32.  Import torch and touch the GPU
+    before creating `ctx` (README: one HIP runtime per process).  Returns the list of per-rank
+    (h, w, 3) tensors on `dst`, None elsewhere."""
+    import ctypes as C
+
+    import torch
+
+    from . import abi
+    w, h = frame.out_size(abi.STAGE_ALL)
+    ow, oh = (w, h) if orientation <= 4 else (h, w)
+    dt = {abi.FMT_F32: torch.float32, abi.FMT_U16: torch.uint16, abi.FMT_U8: torch.uint8}[sample_format]
+    local = torch.empty((oh, ow, 3), dtype=dt, device="cuda")
+    fmt = abi.FormatDesc(sample_format, orientation)
+    rw, rh = C.c_uint32(), C.c_uint32()
+    ctx._check(ctx.lib.jxlgpu_frame_format_output(ctx.handle, frame.handle, C.byref(fmt), local.data_ptr(),
+                                                  abi.MEM_DEVICE, C.byref(rw), C.byref(rh)))
+    ctx.synchronize()
+    return gather_planes(local, dst=dst, group=group)

@@ -96,6 +96,17 @@ def _worker(rank, world, port, q):
             for rr, (a, b, _, _) in enumerate(plan):
                 stitched[:, a:b] = gathered[rr][:, :b - a].numpy()
             ok &= bool(np.array_equal(stitched.view(np.uint32), full.view(np.uint32)))
+        # (3) the gather moves formatted (interleaved u8) frames just as well: 3 B/px instead of 12
+        #     (on the GPU the formatting is jxlgpu_frame_format_output, shard.gather_formatted)
+        mine_u8 = {i: pyoracle.format_output(v, abi.FMT_U8, 1) for i, v in mine.items()}
+        local = torch.zeros((slots, 40, 72, 3), dtype=torch.uint8)
+        for k, i in enumerate(sorted(mine_u8)):
+            local[k] = torch.from_numpy(mine_u8[i])
+        gathered = shard.gather_planes(local, dst=0)
+        if rank == 0:
+            for r in range(world):
+                for k, i in enumerate(shard.frame_shard(n_frames, r, world)):
+                    ok &= bool(np.array_equal(gathered[r][k].numpy(), pyoracle.format_output(render(i), abi.FMT_U8, 1)))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
