@@ -54,6 +54,33 @@ int main(void) {
     assert sizes == [C.sizeof(m) for m in mirror]
 
 
+def test_field_offsets_match_the_compiler():
+    """offsetof() of every field of every POD struct == the ctypes mirror (same names, same order)."""
+    import subprocess
+    import tempfile
+    pairs = [("JxlGpuFormatDesc", abi.FormatDesc), ("JxlGpuFilterParams", abi.FilterParams),
+             ("JxlGpuColorParams", abi.ColorParams), ("JxlGpuUpsampling", abi.Upsampling),
+             ("JxlGpuNoiseParams", abi.NoiseParams), ("JxlGpuLfGroup", abi.LfGroup), ("JxlGpuVardctDesc", abi.VardctDesc),
+             ("JxlGpuOut", abi.Out), ("JxlGpuBlendRect", abi.BlendRect), ("JxlGpuSqueezeStep", abi.SqueezeStep),
+             ("JxlGpuTransform", abi.Transform), ("JxlGpuModularChannel", abi.ModularChannel),
+             ("JxlGpuModularDesc", abi.ModularDesc)]
+    lines, want = [], []
+    for cname, mirror in pairs:
+        lines.append(f'printf("%zu\\n", sizeof({cname}));')
+        want.append(C.sizeof(mirror))
+        for fname, _ in mirror._fields_:
+            lines.append(f'printf("%zu\\n", offsetof({cname}, {fname}));')
+            want.append(getattr(mirror, fname).offset)
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "jxlgpu.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n"
+    with tempfile.TemporaryDirectory() as td:
+        cfile = os.path.join(td, "o.c")
+        open(cfile, "w").write(prog)
+        exe = os.path.join(td, "o")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), cfile, "-o", exe])
+        got = [int(v) for v in subprocess.check_output([exe]).split()]
+    assert got == want
+
+
 def test_no_gpu_means_a_loud_error():
     """Without a visible GPU jxlgpu_create must fail with an error code (never fall back)."""
     import torch
