@@ -540,7 +540,8 @@ void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3],
         const bool plain_srgb = a.color.tf == JXLGPU_TF_SRGB && !a.color.gamut_map && !a.color.has_matrix2 &&
                                 !a.color.tone_map && !a.color.ycbcr;
         if (ctx && ctx->stream2) (void)hipEventRecord(ctx->ev_fork, s);  // inputs are ready here
-        static const bool use_pk = getenv("JXLGPU_STREAM_PK") != nullptr;
+        static const int pk_mode = getenv("JXLGPU_STREAM_PK") ? atoi(getenv("JXLGPU_STREAM_PK")) : 0;
+        const bool use_pk = pk_mode != 0;
         if (use_pk) {
             // two strips per wave (stream_pk.inc): pick the segment height that fills the 1024 SIMDs evenly
             const int pairs = (a.strips + 1) / 2;
@@ -556,8 +557,14 @@ void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3],
             }
             fill_pk_consts(a);
             const int pk_waves = pairs * a.segs;
-            if (plain_srgb) post_stream_pk_kernel<JXLGPU_TF_SRGB><<<(pk_waves + 3) / 4, 256, 0, s>>>(a);
-            else post_stream_pk_kernel<-1><<<(pk_waves + 3) / 4, 256, 0, s>>>(a);
+            if (pk_mode == 3) {
+                if (plain_srgb) post_stream_pk3_kernel<JXLGPU_TF_SRGB><<<(pk_waves + 3) / 4, 256, 0, s>>>(a);
+                else post_stream_pk3_kernel<-1><<<(pk_waves + 3) / 4, 256, 0, s>>>(a);
+            } else if (plain_srgb) {
+                post_stream_pk_kernel<JXLGPU_TF_SRGB><<<(pk_waves + 3) / 4, 256, 0, s>>>(a);
+            } else {
+                post_stream_pk_kernel<-1><<<(pk_waves + 3) / 4, 256, 0, s>>>(a);
+            }
         } else if (plain_srgb) {
             post_stream_kernel<JXLGPU_TF_SRGB><<<(waves + 3) / 4, 256, 0, s>>>(a);
         } else {
