@@ -53,6 +53,10 @@ struct FusedArgs {
     // streaming kernel geometry: it covers [sx0, sx1) x [sy0, sy1), strictly inside the image
     int sx0, sx1, sy0, sy1, rows_per_seg, strips, segs;
     PkConsts pk;
+    // two-pass streaming (stream_split.inc): pass A's region and geometry, E planes in between
+    float* mid[3];
+    uint32_t mid_stride;
+    int ax0, ax1, ay0, ay1, a_rows, a_strips, a_segs;
 };
 
 // Refill the out-of-image cells of the square region [lo, LW-lo) of `buf` (3 planes) from their
@@ -453,6 +457,8 @@ __global__ __launch_bounds__(256) void post_stream_kernel(FusedArgs a) {
 }
 
 #include "stream_pk.inc"
+#include "stream_split.inc"
+#include "stream_split_pk.inc"
 
 template <bool GAB, int ITERS>
 void launch_cfg(hipStream_t s, const FusedArgs& a) {
@@ -541,8 +547,37 @@ void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3],
                                 !a.color.tone_map && !a.color.ycbcr;
         if (ctx && ctx->stream2) (void)hipEventRecord(ctx->ev_fork, s);  // inputs are ready here
         static const int pk_mode = getenv("JXLGPU_STREAM_PK") ? atoi(getenv("JXLGPU_STREAM_PK")) : 0;
+        static const int split_mode = getenv("JXLGPU_STREAM_SPLIT") ? atoi(getenv("JXLGPU_STREAM_SPLIT")) : 0;
         const bool use_pk = pk_mode != 0;
-        if (use_pk) {
+        float* const* scratch = (out[0] == f->buf_a[0]) ? f->buf_b : f->buf_a;
+        if (split_mode && scratch[0] && scratch[0] != in[0] && scratch[0] != out[0]) {
+            // pass A (Gabor + EPF step 1) over the region grown by one sample, E into the spare
+            // plane set; pass B (EPF step 2 + colour) over the region itself
+            static const int rows_a = getenv("JXLGPU_SPLIT_ROWS_A") ? atoi(getenv("JXLGPU_SPLIT_ROWS_A")) : 50;
+            static const int rows_b = getenv("JXLGPU_SPLIT_ROWS_B") ? atoi(getenv("JXLGPU_SPLIT_ROWS_B")) : 46;
+            for (int c = 0; c < 3; ++c) a.mid[c] = scratch[c];
+            a.mid_stride = f->wr;
+            a.ax0 = a.sx0 - 1; a.ax1 = a.sx1 + 1; a.ay0 = a.sy0 - 1; a.ay1 = a.sy1 + 1;
+            a.a_rows = rows_a;
+            a.a_strips = (a.ax1 - a.ax0 + SWA - 1) / SWA;
+            a.a_segs = (a.ay1 - a.ay0 + a.a_rows - 1) / a.a_rows;
+            a.rows_per_seg = rows_b;
+            a.strips = (a.sx1 - a.sx0 + SWB - 1) / SWB;
+            a.segs = (a.sy1 - a.sy0 + a.rows_per_seg - 1) / a.rows_per_seg;
+            if (split_mode == 2) {
+                // two strips per wave, packed f32 (stream_split_pk.inc)
+                fill_pk_consts(a);
+                const int waves_a = ((a.a_strips + 1) / 2) * a.a_segs, waves_b = ((a.strips + 1) / 2) * a.segs;
+                post_stream_a_pk_kernel<<<(waves_a + 3) / 4, 256, 0, s>>>(a);
+                if (plain_srgb) post_stream_b_pk_kernel<JXLGPU_TF_SRGB><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
+                else post_stream_b_pk_kernel<-1><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
+            } else {
+                const int waves_a = a.a_strips * a.a_segs, waves_b = a.strips * a.segs;
+                post_stream_a_kernel<<<(waves_a + 3) / 4, 256, 0, s>>>(a);
+                if (plain_srgb) post_stream_b_kernel<JXLGPU_TF_SRGB><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
+                else post_stream_b_kernel<-1><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
+            }
+        } else if (use_pk) {
             // two strips per wave (stream_pk.inc): pick the segment height that fills the 1024 SIMDs evenly
             const int pairs = (a.strips + 1) / 2;
             if (!getenv("JXLGPU_STREAM_ROWS")) {
