@@ -564,13 +564,19 @@ void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3],
             a.rows_per_seg = rows_b;
             a.strips = (a.sx1 - a.sx0 + SWB - 1) / SWB;
             a.segs = (a.sy1 - a.sy0 + a.rows_per_seg - 1) / a.rows_per_seg;
-            if (split_mode == 2) {
-                // two strips per wave, packed f32 (stream_split_pk.inc)
+            if (split_mode == 2 || split_mode == 3) {
+                // two strips per wave, packed f32 (stream_split_pk.inc); 3: shared-reciprocal division
                 fill_pk_consts(a);
                 const int waves_a = ((a.a_strips + 1) / 2) * a.a_segs, waves_b = ((a.strips + 1) / 2) * a.segs;
-                post_stream_a_pk_kernel<<<(waves_a + 3) / 4, 256, 0, s>>>(a);
-                if (plain_srgb) post_stream_b_pk_kernel<JXLGPU_TF_SRGB><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
-                else post_stream_b_pk_kernel<-1><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
+                if (split_mode == 3) {
+                    post_stream_a_pk_kernel<true><<<(waves_a + 3) / 4, 256, 0, s>>>(a);
+                    if (plain_srgb) post_stream_b_pk_kernel<JXLGPU_TF_SRGB, true><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
+                    else post_stream_b_pk_kernel<-1, true><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
+                } else {
+                    post_stream_a_pk_kernel<false><<<(waves_a + 3) / 4, 256, 0, s>>>(a);
+                    if (plain_srgb) post_stream_b_pk_kernel<JXLGPU_TF_SRGB, false><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
+                    else post_stream_b_pk_kernel<-1, false><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
+                }
             } else {
                 const int waves_a = a.a_strips * a.a_segs, waves_b = a.strips * a.segs;
                 post_stream_a_kernel<<<(waves_a + 3) / 4, 256, 0, s>>>(a);

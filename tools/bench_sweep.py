@@ -14,7 +14,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT = ["", "JXLGPU_STREAM_SPLIT=1", "JXLGPU_STREAM_SPLIT=2", "JXLGPU_STREAM_PK=1", "JXLGPU_STREAM_PK=3", "JXLGPU_STREAM_PK=3 JXLGPU_STREAM_ROWS=36",
+DEFAULT = ["", "JXLGPU_STREAM_SPLIT=1", "JXLGPU_STREAM_SPLIT=2", "JXLGPU_STREAM_SPLIT=3", "JXLGPU_STREAM_PK=1", "JXLGPU_STREAM_PK=3", "JXLGPU_STREAM_PK=3 JXLGPU_STREAM_ROWS=36",
            "JXLGPU_STREAM_PK=1 JXLGPU_STREAM_ROWS=36", "JXLGPU_NO_DEQ_LUT=1", "JXLGPU_STREAM_ROWS=40", "JXLGPU_STREAM_ROWS=56"]
 
 

@@ -20,7 +20,7 @@ print(hashlib.sha256(out.tobytes()).hexdigest())
 ''' % ROOT
 
 if __name__ == "__main__":
-    variants = sys.argv[1:] or ["", "JXLGPU_STREAM_SPLIT=1", "JXLGPU_STREAM_SPLIT=2", "JXLGPU_STREAM_PK=3"]
+    variants = sys.argv[1:] or ["", "JXLGPU_STREAM_SPLIT=1", "JXLGPU_STREAM_SPLIT=2", "JXLGPU_STREAM_SPLIT=3", "JXLGPU_STREAM_PK=3"]
     ref = None
     for v in variants:
         env = dict(os.environ)

@@ -5,7 +5,7 @@
 #   tools/validate_variants.sh "JXLGPU_STREAM_SPLIT=2 JXLGPU_SPLIT_ROWS_A=34"
 VARIANTS=("$@")
 if [ ${#VARIANTS[@]} -eq 0 ]; then
-  VARIANTS=("JXLGPU_STREAM_SPLIT=1" "JXLGPU_STREAM_SPLIT=2" "JXLGPU_STREAM_PK=1" "JXLGPU_STREAM_PK=3" "JXLGPU_NO_DEQ_LUT=1" "JXLGPU_NO_STREAM=1" "JXLGPU_NO_FUSED=1")
+  VARIANTS=("JXLGPU_STREAM_SPLIT=1" "JXLGPU_STREAM_SPLIT=2" "JXLGPU_STREAM_SPLIT=3" "JXLGPU_STREAM_PK=1" "JXLGPU_STREAM_PK=3" "JXLGPU_NO_DEQ_LUT=1" "JXLGPU_NO_STREAM=1" "JXLGPU_NO_FUSED=1")
 fi
 rc=0
 for v in "${VARIANTS[@]}"; do
