@@ -50,10 +50,10 @@ void ctx_dev_release(jxlgpu_ctx* ctx, void* p) {
     }
 }
 
-void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
-                       float* const out[3], uint32_t out_stride, bool gabor, int epf_iters, bool color,
-                       jxlgpu_ctx* ctx);
-bool fused_post_supported(const jxlgpu_frame* f, bool gabor, int epf_iters);
+hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
+                             float* const out[3], uint32_t out_stride, bool gabor, int epf_iters, bool color,
+                             jxlgpu_ctx* ctx);
+bool fused_post_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, bool gabor, int epf_iters);
 
 struct UploadOpts {
     uint32_t lfg_cells_x = 0, lfg_cells_y = 0;  // LF group size in cells (0: group_dim)
@@ -152,27 +152,24 @@ int fail(jxlgpu_ctx* ctx, int code, const char* msg) {
     return code;
 }
 
-// HF coefficients of channel c into the dense i32 device plane f->coeff[c] (coeff_kernels.hip).
+// HF coefficients of channel c into the cell-tiled device layout f->coeff (coeff_kernels.hip).
+// Dense planes cross PCIe row-major as the caller holds them (a staging buffer, freed after the
+// upload) and are re-laid-out on the device; sparse lists scatter straight into the tiled layout
+// (the caller zero-fills f->coeff once before the first channel).
 int upload_coeff_plane(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuVardctDesc* d, int c, Scratch& tmp,
                        uint32_t* d_bad) {
     const size_t npix = (size_t)f->wr * f->hr;
     const bool v16 = d->coeff_sample_type == JXLGPU_SAMPLE_I16;
     const size_t vsz = v16 ? 2 : 4;
     if (d->coeff_format == JXLGPU_COEFF_DENSE) {
-        if (!v16) {
-            HIP_TRY(ctx, hipMemcpy2D(f->coeff[c], (size_t)f->wr * 4, d->coeff[c], (size_t)d->coeff_stride * 4,
-                                     (size_t)f->wr * 4, f->hr, hipMemcpyHostToDevice));
-            return JXLGPU_OK;
-        }
         void* t = nullptr;
-        TRY(tmp.alloc(ctx, &t, npix * 2));
-        HIP_TRY(ctx, hipMemcpy2D(t, (size_t)f->wr * 2, d->coeff[c], (size_t)d->coeff_stride * 2, (size_t)f->wr * 2,
+        TRY(tmp.alloc(ctx, &t, npix * vsz));
+        HIP_TRY(ctx, hipMemcpy2D(t, (size_t)f->wr * vsz, d->coeff[c], (size_t)d->coeff_stride * vsz, (size_t)f->wr * vsz,
                                  f->hr, hipMemcpyHostToDevice));
-        launch_widen_i16(ctx->stream, static_cast<const int16_t*>(t), f->coeff[c], npix);
+        launch_coeff_retile(ctx->stream, t, v16, f->wr, f->hr, (uint32_t)c, f->coeff);
         HIP_TRY(ctx, hipGetLastError());
         return JXLGPU_OK;
     }
-    HIP_TRY(ctx, hipMemsetAsync(f->coeff[c], 0, npix * 4, ctx->stream));
     const size_t n = (size_t)d->sparse_count[c];
     if (n == 0) return JXLGPU_OK;
     void *dp = nullptr, *dv = nullptr;
@@ -181,7 +178,7 @@ int upload_coeff_plane(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuVardctDesc*
     HIP_TRY(ctx, hipMemcpy(dp, d->sparse_pos[c], n * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dv, d->coeff[c], n * vsz, hipMemcpyHostToDevice));
     launch_coeff_scatter(ctx->stream, static_cast<const uint32_t*>(dp), dv, v16, n, d->coeff_stride, f->wr, f->hr,
-                         f->coeff[c], d_bad);
+                         (uint32_t)c, f->coeff, d_bad);
     HIP_TRY(ctx, hipGetLastError());
     return JXLGPU_OK;
 }
@@ -278,7 +275,20 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     jxlgpu_ctx* ctx = new (std::nothrow) jxlgpu_ctx();
     if (!ctx) return JXLGPU_ERR_OOM;
     ctx->device = device;
+    // environment -> per-context tuning, read once here (no process-global state afterwards)
     if (const char* mb = getenv("JXLGPU_POOL_MB")) ctx->pool_cap = (size_t)strtoull(mb, nullptr, 10) << 20;
+    if (const char* v = getenv("JXLGPU_STREAM_ROWS")) {
+        const int r = atoi(v);
+        if (r >= 8 && r <= 1024 && r % 4 == 0) ctx->tune.stream_rows = r;
+    }
+    ctx->tune.no_stream = getenv("JXLGPU_NO_STREAM") != nullptr;
+    ctx->tune.no_fused = getenv("JXLGPU_NO_FUSED") != nullptr;
+    ctx->tune.debug_sync = getenv("JXLGPU_DEBUG_SYNC") != nullptr;
+    if (const char* v = getenv("JXLGPU_SQZ_SEG")) {
+        const int r = atoi(v);
+        if (r >= 8 && r <= 4096) ctx->tune.sqz_seg = r;
+    }
+    if (const char* v = getenv("JXLGPU_SQZ_RUNIN")) ctx->tune.sqz_runin = (uint32_t)atoi(v);
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
@@ -525,8 +535,9 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     TRY(tmp.alloc(ctx, &d_bad_v, 4));
     uint32_t* d_bad = static_cast<uint32_t*>(d_bad_v);
     HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    TRY(dev_alloc(ctx, f, &f->coeff, npix * 3));
+    if (d->coeff_format == JXLGPU_COEFF_SPARSE) HIP_TRY(ctx, hipMemsetAsync(f->coeff, 0, npix * 12, ctx->stream));
     for (int c = 0; c < 3; ++c) {
-        TRY(dev_alloc(ctx, f, &f->coeff[c], npix));
         TRY(upload_coeff_plane(ctx, f, d, c, tmp, d_bad));
         uint8_t* p = nullptr;
         TRY(dev_upload(ctx, f, &p, lfq_host[c]));
@@ -554,29 +565,17 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
         TRY(dev_upload(ctx, f, &f->deq_lut, lut));
     }
     {
-        // one entry array (classes concatenated) + one descriptor per workgroup of the <=32 kernel,
-        // widest shapes first so the long workgroups start early
-#ifndef JXL_VB_TILE
-#define JXL_VB_TILE 2048
-#endif
-        auto nb = [](int w, int h) { return w * h >= JXL_VB_TILE ? 1 : JXL_VB_TILE / (w * h); };
-        const int kNB[CLS_COUNT] = {nb(8, 8), nb(8, 8), nb(16, 16), nb(8, 16), nb(16, 8), nb(32, 32), nb(8, 32),
-                                    nb(32, 8), nb(16, 32), nb(32, 16), 1, 1, 1, 1};
-        static const int kOrder[] = {CLS_32x32, CLS_16x32, CLS_32x16, CLS_8x32, CLS_32x8, CLS_16x16,
-                                     CLS_8x16, CLS_16x8, CLS_DCT8};
-        std::vector<uint4> entries, wgs;
+        // one entry array, classes concatenated; the special 8x8 family sorted by transform type so
+        // that the per-lane dispatch of transform_special_kernel is (nearly) wave-uniform
+        std::stable_sort(lists[CLS_SPECIAL8].begin(), lists[CLS_SPECIAL8].end(),
+                         [](const uint4& a, const uint4& b) { return a.y < b.y; });
+        std::vector<uint4> entries;
         for (int cls = 0; cls < CLS_COUNT; ++cls) {
             f->class_first[cls] = (uint32_t)entries.size();
             f->list_count[cls] = (uint32_t)lists[cls].size();
             entries.insert(entries.end(), lists[cls].begin(), lists[cls].end());
         }
-        for (int cls : kOrder)
-            for (uint32_t i = 0; i < f->list_count[cls]; i += kNB[cls])
-                wgs.push_back(make_uint4((uint32_t)cls, f->class_first[cls] + i,
-                                         std::min<uint32_t>(kNB[cls], f->list_count[cls] - i), 0));
         TRY(dev_upload(ctx, f, &f->entries, entries));
-        f->n_wg_descs = (uint32_t)wgs.size();
-        TRY(dev_upload(ctx, f, &f->wg_descs, wgs));
     }
     f->nometa_count = (uint32_t)nometa.size();
     if (!nometa.empty()) TRY(dev_upload(ctx, f, &f->nometa_groups, nometa));
@@ -693,10 +692,10 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
     const bool fuse_color = do_color && !do_up && !do_noise;  // noise sits between upsampling and colour
 
     // Fast path: everything after the transform in one tile kernel (fused_kernels.hip)
-    if ((do_gab || epf_iters) && fused_post_supported(f, do_gab, epf_iters)) {
+    if ((do_gab || epf_iters) && fused_post_supported(ctx, f, do_gab, epf_iters)) {
         const float* in[3] = {cur[0], cur[1], cur[2]};
         float** dst = (cur[0] == f->buf_a[0]) ? f->buf_b : f->buf_a;
-        launch_fused_post(s, f, in, *cur_stride, dst, f->wr, do_gab, epf_iters, fuse_color, ctx);
+        HIP_TRY(ctx, launch_fused_post(s, f, in, *cur_stride, dst, f->wr, do_gab, epf_iters, fuse_color, ctx));
         for (int c = 0; c < 3; ++c) cur[c] = dst[c];
         *cur_stride = f->wr;
         if (fuse_color) {
@@ -757,9 +756,9 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
         launch_noise(s, f->desc.noise, ctx->noise_jump, f->noise_raw, cur, *cur_stride, *ow, *oh, f->noise_group_dim,
                      f->noise_corr_x, f->noise_corr_b);
     }
-    if (getenv("JXLGPU_DEBUG_SYNC")) (void)hipStreamSynchronize(s);
+    if (ctx->tune.debug_sync) HIP_TRY(ctx, hipStreamSynchronize(s));
     if (do_color) launch_color(s, f->color, cur, *cur_stride, *ow, *oh);
-    if (getenv("JXLGPU_DEBUG_SYNC")) (void)hipStreamSynchronize(s);
+    if (ctx->tune.debug_sync) HIP_TRY(ctx, hipStreamSynchronize(s));
     return JXLGPU_OK;
 }
 
@@ -1053,32 +1052,38 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
 
     // ---- V4-V8
     TransformArgs ta;
+    ta.coeff = f->coeff;
     for (int c = 0; c < 3; ++c) {
-        ta.coeff[c] = f->coeff[c]; ta.pix[c] = f->pix[c]; ta.lf[c] = lf[c];
+        ta.pix[c] = f->pix[c]; ta.lf[c] = lf[c];
         ta.qm_scale[c] = f->qm_scale[c]; ta.quant_bias[c] = d.quant_bias[c];
     }
     ta.kind = f->kind; ta.hf_mul = f->hf_mul; ta.kx_map = f->kx_map; ta.kb_map = f->kb_map;
     ta.dequant = f->dequant; ta.deq_off = f->deq_off;
+    memcpy(ta.deq_off_v, f->deq_off_host, sizeof(ta.deq_off_v));
     ta.sec64 = f->sec[0]; ta.sec128 = f->sec[1]; ta.sec256 = f->sec[2];
-    ta.cstride = f->wr; ta.pstride = f->wr; ta.w8 = f->w8; ta.h8 = f->h8; ta.w64 = f->w64;
+    ta.pstride = f->wr; ta.w8 = f->w8; ta.h8 = f->h8; ta.w64 = f->w64;
     ta.global_scale = (float)d.global_scale;
     ta.quant_bias_numerator = d.quant_bias_numerator;
     ta.big_tmp = f->big_tmp;
-    static const bool no_lut = getenv("JXLGPU_NO_DEQ_LUT") != nullptr;
-    ta.deq_lut = no_lut ? nullptr : f->deq_lut;
+    ta.deq_lut = f->deq_lut;
     ctx->prof_begin(PROF_TRANSFORM);
-    const bool has64 = f->list_count[CLS_64x64] | f->list_count[CLS_32x64] | f->list_count[CLS_64x32] |
-                       f->list_count[CLS_SPECIAL8];
-    if (has64) {
-        // fork: the 64-pixel shapes (different LDS / register footprint) run beside the <=32 kernel
+    const bool has_side = f->list_count[CLS_64x64] | f->list_count[CLS_32x64] | f->list_count[CLS_64x32] |
+                          f->list_count[CLS_SPECIAL8] | f->list_count[CLS_32x32] | f->list_count[CLS_8x32] |
+                          f->list_count[CLS_32x8] | f->list_count[CLS_16x32] | f->list_count[CLS_32x16];
+    if (has_side) {
+        // fork: the few, long work items (64- and 32-px shapes, the special 8x8 family) start first on
+        // the side stream and run beside the bulk (8x8 and 16-px shapes) instead of forming its tail
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        for (int cls : {CLS_64x64, CLS_32x64, CLS_64x32, CLS_SPECIAL8})
+        for (int cls : {CLS_64x64, CLS_32x64, CLS_64x32})
             launch_transform_class(ctx->stream2, cls, ta, f->entries + f->class_first[cls], f->list_count[cls]);
+        HIP_TRY(ctx, launch_transform_rows(ctx->stream2, 1, ta, f->entries, f->class_first, f->list_count));
+        launch_transform_class(ctx->stream2, CLS_SPECIAL8, ta, f->entries + f->class_first[CLS_SPECIAL8],
+                               f->list_count[CLS_SPECIAL8]);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
     }
-    launch_transform_small(s, ta, f->wg_descs, f->n_wg_descs, f->entries);
-    if (has64) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+    HIP_TRY(ctx, launch_transform_rows(s, 0, ta, f->entries, f->class_first, f->list_count));
+    if (has_side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     launch_transform_class(s, CLS_BIG, ta, f->entries + f->class_first[CLS_BIG], f->list_count[CLS_BIG]);
     launch_nometa_groups(s, ta, f->nometa_groups, f->nometa_count, f->group_dim, ceil_div(f->width, f->group_dim));
     ctx->prof_end(PROF_TRANSFORM);

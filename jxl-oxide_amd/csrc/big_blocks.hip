@@ -120,10 +120,11 @@ __global__ __launch_bounds__(256) void big_block_kernel(TransformArgs a, const u
     // V4 + V5
     for (int i = t; i < W * H; i += 256) {
         int y = i / W, x = i % W;
-        size_t goff = (size_t)(py0 + y) * a.cstride + px0 + x;
-        float v = dequant_big(a.coeff[c][goff], a.quant_bias[c], a.quant_bias_numerator, mat_c[y * W + x], mul_c);
+        float v = dequant_big(a.coeff[coeff_tiled_index(px0 + x, py0 + y, c, a.w8)], a.quant_bias[c],
+                              a.quant_bias_numerator, mat_c[y * W + x], mul_c);
         if (c != 1) {
-            float yv = dequant_big(a.coeff[1][goff], a.quant_bias[1], a.quant_bias_numerator, mat_y[y * W + x], mul_y);
+            float yv = dequant_big(a.coeff[coeff_tiled_index(px0 + x, py0 + y, 1, a.w8)], a.quant_bias[1],
+                                   a.quant_bias_numerator, mat_y[y * W + x], mul_y);
             uint32_t ti = ((py0 + y) >> 6) * a.w64 + ((px0 + x) >> 6);
             float k = c == 0 ? a.kx_map[ti] : a.kb_map[ti];
             v += k * yv;

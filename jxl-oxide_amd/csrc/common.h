@@ -34,8 +34,14 @@ enum VbClass : int {
     CLS_COUNT
 };
 
+// HF coefficients in HBM: 8x8 cells, channel-interleaved.  Cell (cx, cy) holds 3 x 64 words
+// {X, Y, B}, each 8 rows of 8.  Word index of sample (px, py) of channel c:
+__host__ __device__ inline size_t coeff_tiled_index(uint32_t px, uint32_t py, uint32_t c, uint32_t w8) {
+    return ((((size_t)(py >> 3) * w8 + (px >> 3)) * 3 + c) << 6) + ((py & 7u) << 3) + (px & 7u);
+}
+
 struct TransformArgs {
-    const int32_t* coeff[3];   // X, Y, B coefficient planes (i32), stride = cstride
+    const int32_t* coeff;      // i32 coefficients, cell-tiled (coeff_tiled_index)
     float* pix[3];             // output planes, stride = pstride
     const float* lf[3];        // LF planes after V1-V3, stride = w8
     const uint8_t* kind;       // frame-level BlockInfo plane, stride w8
@@ -43,11 +49,12 @@ struct TransformArgs {
     const float* kx_map;       // base_correlation_x + x_from_y/colour_factor, per 64x64 tile
     const float* kb_map;
     const float* dequant;      // all matrices, flat
-    const uint32_t* deq_off;   // [27*3] offsets into `dequant`
+    const uint32_t* deq_off;   // [27*3] offsets into `dequant` (device copy, per-lane lookups)
+    uint32_t deq_off_v[27 * 3]; // the same table by value (kernarg: compile-time type -> scalar load)
     const float* sec64;        // sec_half(64/128/256)
     const float* sec128;
     const float* sec256;
-    uint32_t cstride, pstride, w8, h8, w64;
+    uint32_t pstride, w8, h8, w64;
     float global_scale;        // as f32
     float qm_scale[3];
     float quant_bias[3];
@@ -112,8 +119,20 @@ struct ColorArgs {
 // Kernel groups that can be bracketed with HIP events (jxlgpu_profile_*).
 enum ProfGroup : int { PROF_LF = 0, PROF_TRANSFORM = 1, PROF_POST = 2, PROF_MODULAR = 3, PROF_COUNT = 4 };
 
+// Tuning / debug switches.  Read from the environment ONCE, at jxlgpu_create, into the context:
+// the library keeps no process-global mutable state (include/jxlgpu.h "Threading").
+struct Tuning {
+    int stream_rows = 48;        // JXLGPU_STREAM_ROWS: rows per wave segment of post_stream_kernel
+    bool no_stream = false;      // JXLGPU_NO_STREAM: LDS tile kernel for the whole frame
+    bool no_fused = false;       // JXLGPU_NO_FUSED: one kernel per post stage
+    bool debug_sync = false;     // JXLGPU_DEBUG_SYNC: synchronise + report after every launch group
+    int sqz_seg = 128;           // JXLGPU_SQZ_SEG: pairs per inverse-Squeeze segment
+    uint32_t sqz_runin = 1;      // JXLGPU_SQZ_RUNIN: 0 forces the Squeeze fix-up path (tests)
+};
+
 struct jxlgpu_ctx {
     int device = 0;
+    Tuning tune;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: 64-pixel varblock kernels overlap the <=32 kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -161,7 +180,7 @@ struct jxlgpu_frame {
     uint32_t group_dim = 256, lf_groups_per_row = 1, num_lf_groups = 1;
     std::vector<void*> allocs;  // everything hipMalloc'ed for this frame
     // VarDCT device state
-    int32_t* coeff[3] = {};
+    int32_t* coeff = nullptr;   // 3 * wr * hr words, cell-tiled (coeff_tiled_index)
     void* lfq[3] = {};
     uint32_t lf_is_i16 = 0;
     float* lf_scale = nullptr;
@@ -185,8 +204,6 @@ struct jxlgpu_frame {
     uint4* entries = nullptr;            // all varblocks, classes concatenated
     uint32_t class_first[CLS_COUNT] = {};
     uint32_t list_count[CLS_COUNT] = {};
-    uint4* wg_descs = nullptr;           // {class, first entry, count, 0} per workgroup of the <=32 kernel
-    uint32_t n_wg_descs = 0;
     bool has_no_meta_groups = false;
     uint32_t* nometa_groups = nullptr;  // groups whose LF group has no HfMetadata
     uint32_t nometa_count = 0;
@@ -238,8 +255,8 @@ void launch_lf_dequant_cfl(hipStream_t s, const LfArgs& a);
 void launch_lf_smooth(hipStream_t s, const SmoothArgs& a);
 void launch_transform_class(hipStream_t s, int cls, const TransformArgs& a, const uint4* entries,
                             uint32_t count);
-void launch_transform_small(hipStream_t s, const TransformArgs& a, const uint4* wgs, uint32_t n_wgs,
-                            const uint4* entries);
+hipError_t launch_transform_rows(hipStream_t s, int family, const TransformArgs& a, const uint4* entries,
+                                 const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT]);
 void launch_nometa_groups(hipStream_t s, const TransformArgs& a, const uint32_t* groups,
                           uint32_t count, uint32_t group_dim, uint32_t groups_per_row);
 void launch_gabor(hipStream_t s, const FilterArgs& a);
@@ -255,9 +272,10 @@ void launch_noise(hipStream_t s, const JxlGpuNoiseParams& np, const void* jump_d
                   float corr_x, float corr_b);
 void launch_upsample_jpeg(hipStream_t s, const float* in, uint32_t in_stride, uint32_t in_w, uint32_t in_h, int hshift,
                           int vshift, float* out, uint32_t out_stride, uint32_t width, uint32_t height);
-void launch_widen_i16(hipStream_t s, const int16_t* src, int32_t* dst, size_t count);
+void launch_coeff_retile(hipStream_t s, const void* src, bool src_i16, uint32_t wr, uint32_t hr, uint32_t c,
+                         int32_t* dst);
 void launch_coeff_scatter(hipStream_t s, const uint32_t* pos, const void* val, bool val_i16, size_t count,
-                          uint32_t src_stride, uint32_t wr, uint32_t hr, int32_t* dst, uint32_t* bad);
+                          uint32_t src_stride, uint32_t wr, uint32_t hr, uint32_t c, int32_t* dst, uint32_t* bad);
 void launch_color(hipStream_t s, const ColorArgs& c, float* const planes[3], uint32_t stride,
                   uint32_t width, uint32_t height);
 void launch_upsample(hipStream_t s, const float* in, uint32_t in_stride, uint32_t w, uint32_t h,

@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "pixel_device.h"
 
@@ -29,16 +31,6 @@ struct PostCfg {
     static constexpr int PLANE = LW * LW;
 };
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-// Uniform constants of the packed streaming kernel as {c, c} pairs (see stream_pk.inc).
-struct PkConsts {
-    f2 zero, one, K;
-    f2 gw0[3], gw1[3], ggw[3], cs[3];
-    f2 cbrt_ob[3], ob[3], itscale, mat[9];
-    f2 srgb_p[6];   // tf/srgb.rs:36-46 polynomial, 12.92, -0.055
-};
-
 struct FusedArgs {
     const float* in[3];
     float* out[3];
@@ -52,11 +44,6 @@ struct FusedArgs {
     const uint32_t* tiles;   // optional list of tiles (tx | ty << 16); null = full 2-D grid
     // streaming kernel geometry: it covers [sx0, sx1) x [sy0, sy1), strictly inside the image
     int sx0, sx1, sy0, sy1, rows_per_seg, strips, segs;
-    PkConsts pk;
-    // two-pass streaming (stream_split.inc): pass A's region and geometry, E planes in between
-    float* mid[3];
-    uint32_t mid_stride;
-    int ax0, ax1, ay0, ay1, a_rows, a_strips, a_segs;
 };
 
 // Refill the out-of-image cells of the square region [lo, LW-lo) of `buf` (3 planes) from their
@@ -456,55 +443,44 @@ __global__ __launch_bounds__(256) void post_stream_kernel(FusedArgs a) {
     }
 }
 
-#include "stream_pk.inc"
-#include "stream_split.inc"
-#include "stream_split_pk.inc"
-
 template <bool GAB, int ITERS>
-void launch_cfg(hipStream_t s, const FusedArgs& a) {
-    dim3 grid(ceil_div(a.width, T), ceil_div(a.height, T));
+hipError_t launch_cfg(hipStream_t s, const FusedArgs& a, dim3 grid) {
     constexpr size_t lds_bytes = 2 * 3 * PostCfg<GAB, ITERS>::PLANE * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // > 64 KiB of dynamic LDS needs the attribute; setting it is idempotent and thread-safe
+    static std::once_flag once;
+    std::call_once(once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_post_kernel<GAB, ITERS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
-    }
+    });
     fused_post_kernel<GAB, ITERS><<<grid, 256, lds_bytes, s>>>(a);
+    return hipGetLastError();
 }
 
-}  // namespace
-
-namespace {
-void fill_pk_consts(FusedArgs& a) {
-    auto sp = [](float v) { return f2{v, v}; };
-    PkConsts& k = a.pk;
-    k.zero = sp(0.0f); k.one = sp(1.0f);
-    const float FRAC_1_SQRT_2 = 0.70710678118654752440f;
-    k.K = sp(6.6f * (FRAC_1_SQRT_2 - 1.0f));
-    for (int c = 0; c < 3; ++c) {
-        const float w0 = a.fp.gab_weights[c][0], w1 = a.fp.gab_weights[c][1];
-        k.gw0[c] = sp(w0); k.gw1[c] = sp(w1);
-        k.ggw[c] = sp(1.0f / (1.0f + w0 * 4.0f + w1 * 4.0f));
-        k.cs[c] = sp(a.fp.epf_channel_scale[c]);
-        k.cbrt_ob[c] = sp(a.color.cbrt_opsin_bias[c]);
-        k.ob[c] = sp(a.color.opsin_bias[c]);
+hipError_t launch_tile_kernel(hipStream_t s, const FusedArgs& a, bool gabor, int epf_iters, dim3 grid) {
+    switch ((gabor ? 4 : 0) + epf_iters) {
+        case 0: return launch_cfg<false, 0>(s, a, grid);
+        case 1: return launch_cfg<false, 1>(s, a, grid);
+        case 2: return launch_cfg<false, 2>(s, a, grid);
+        case 3: return launch_cfg<false, 3>(s, a, grid);
+        case 4: return launch_cfg<true, 0>(s, a, grid);
+        case 5: return launch_cfg<true, 1>(s, a, grid);
+        case 6: return launch_cfg<true, 2>(s, a, grid);
+        default: return launch_cfg<true, 3>(s, a, grid);
     }
-    k.itscale = sp(a.color.itscale);
-    for (int i = 0; i < 9; ++i) k.mat[i] = sp(a.color.matrix[i]);
-    const float srgb[6] = {0.059914046f, -0.10889456f, 0.107963754f, 0.018092343f, 12.92f, -0.055f};
-    for (int i = 0; i < 6; ++i) k.srgb_p[i] = sp(srgb[i]);
 }
+
 }  // namespace
 
-bool fused_post_supported(const jxlgpu_frame* f, bool gabor, int epf_iters) {
-    if (getenv("JXLGPU_NO_FUSED")) return false;
-    return true;
+bool fused_post_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, bool gabor, int epf_iters) {
+    return !(ctx && ctx->tune.no_fused);
 }
 
-void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
-                       float* const out[3], uint32_t out_stride, bool gabor, int epf_iters, bool color,
-                       jxlgpu_ctx* ctx) {
+// Returns a HIP error instead of silently skipping the launch (the caller switches `cur` to `out`
+// only on success).  If the ring-tile list cannot be allocated the whole frame runs through the
+// tile kernel, which needs no list.
+hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
+                             float* const out[3], uint32_t out_stride, bool gabor, int epf_iters, bool color,
+                             jxlgpu_ctx* ctx) {
     FusedArgs a;
     memset(&a, 0, sizeof(a));
     for (int c = 0; c < 3; ++c) { a.in[c] = in[c]; a.out[c] = out[c]; }
@@ -515,123 +491,56 @@ void launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3],
     a.color = f->color;
     a.do_color = color ? 1u : 0u;
     a.tiles = nullptr;
+    const dim3 full_grid(ceil_div(f->width, T), ceil_div(f->height, T));
 
     // Default configuration (Gabor + 2 EPF steps) on a frame with an interior: the streaming
     // kernel takes everything except the outer ring of tiles.
-    const int ntx = (int)ceil_div(f->width, T), nty = (int)ceil_div(f->height, T);
+    const int ntx = (int)full_grid.x, nty = (int)full_grid.y;
     int tx_hi = ntx - 1, ty_hi = nty - 1;
     while (tx_hi > 1 && T * tx_hi + SH > (int)f->width) --tx_hi;
     while (ty_hi > 1 && T * ty_hi + SH > (int)f->height) --ty_hi;
-    static const bool no_stream = getenv("JXLGPU_NO_STREAM") != nullptr;
-    if (gabor && epf_iters == 2 && tx_hi > 1 && ty_hi > 1 && !no_stream) {
-        if (!f->ring_tiles) {
-            std::vector<uint32_t> ring;
-            for (int ty = 0; ty < nty; ++ty)
-                for (int tx = 0; tx < ntx; ++tx)
-                    if (tx < 1 || tx >= tx_hi || ty < 1 || ty >= ty_hi) ring.push_back((uint32_t)tx | ((uint32_t)ty << 16));
-            void* p = nullptr;
-            if (ctx_dev_malloc(ctx, &p, ring.size() * 4) != hipSuccess) return;
+    const bool no_stream = ctx && ctx->tune.no_stream;
+    bool stream = gabor && epf_iters == 2 && tx_hi > 1 && ty_hi > 1 && !no_stream;
+    if (stream && !f->ring_tiles) {
+        std::vector<uint32_t> ring;
+        for (int ty = 0; ty < nty; ++ty)
+            for (int tx = 0; tx < ntx; ++tx)
+                if (tx < 1 || tx >= tx_hi || ty < 1 || ty >= ty_hi) ring.push_back((uint32_t)tx | ((uint32_t)ty << 16));
+        void* p = nullptr;
+        if (ctx_dev_malloc(ctx, &p, ring.size() * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            stream = false;  // tile kernel over the whole frame
+        } else {
             f->allocs.push_back(p);
-            (void)hipMemcpy(p, ring.data(), ring.size() * 4, hipMemcpyHostToDevice);
+            hipError_t e = hipMemcpy(p, ring.data(), ring.size() * 4, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return e;
             f->ring_tiles = static_cast<uint32_t*>(p);
             f->n_ring_tiles = (uint32_t)ring.size();
         }
-        static const int rows_env = getenv("JXLGPU_STREAM_ROWS") ? atoi(getenv("JXLGPU_STREAM_ROWS")) : 48;
-        a.sx0 = T; a.sx1 = T * tx_hi; a.sy0 = T; a.sy1 = T * ty_hi;
-        a.rows_per_seg = rows_env;
-        a.strips = (a.sx1 - a.sx0 + SW - 1) / SW;
-        a.segs = (a.sy1 - a.sy0 + a.rows_per_seg - 1) / a.rows_per_seg;
-        const int waves = a.strips * a.segs;
-        // plain XYB -> sRGB (no gamut map / second matrix) gets a branch-free colour epilogue
-        const bool plain_srgb = a.color.tf == JXLGPU_TF_SRGB && !a.color.gamut_map && !a.color.has_matrix2 &&
-                                !a.color.tone_map && !a.color.ycbcr;
-        if (ctx && ctx->stream2) (void)hipEventRecord(ctx->ev_fork, s);  // inputs are ready here
-        static const int pk_mode = getenv("JXLGPU_STREAM_PK") ? atoi(getenv("JXLGPU_STREAM_PK")) : 0;
-        static const int split_mode = getenv("JXLGPU_STREAM_SPLIT") ? atoi(getenv("JXLGPU_STREAM_SPLIT")) : 0;
-        const bool use_pk = pk_mode != 0;
-        float* const* scratch = (out[0] == f->buf_a[0]) ? f->buf_b : f->buf_a;
-        if (split_mode && scratch[0] && scratch[0] != in[0] && scratch[0] != out[0]) {
-            // pass A (Gabor + EPF step 1) over the region grown by one sample, E into the spare
-            // plane set; pass B (EPF step 2 + colour) over the region itself
-            static const int rows_a = getenv("JXLGPU_SPLIT_ROWS_A") ? atoi(getenv("JXLGPU_SPLIT_ROWS_A")) : 50;
-            static const int rows_b = getenv("JXLGPU_SPLIT_ROWS_B") ? atoi(getenv("JXLGPU_SPLIT_ROWS_B")) : 46;
-            for (int c = 0; c < 3; ++c) a.mid[c] = scratch[c];
-            a.mid_stride = f->wr;
-            a.ax0 = a.sx0 - 1; a.ax1 = a.sx1 + 1; a.ay0 = a.sy0 - 1; a.ay1 = a.sy1 + 1;
-            a.a_rows = rows_a;
-            a.a_strips = (a.ax1 - a.ax0 + SWA - 1) / SWA;
-            a.a_segs = (a.ay1 - a.ay0 + a.a_rows - 1) / a.a_rows;
-            a.rows_per_seg = rows_b;
-            a.strips = (a.sx1 - a.sx0 + SWB - 1) / SWB;
-            a.segs = (a.sy1 - a.sy0 + a.rows_per_seg - 1) / a.rows_per_seg;
-            if (split_mode == 2 || split_mode == 3) {
-                // two strips per wave, packed f32 (stream_split_pk.inc); 3: shared-reciprocal division
-                fill_pk_consts(a);
-                const int waves_a = ((a.a_strips + 1) / 2) * a.a_segs, waves_b = ((a.strips + 1) / 2) * a.segs;
-                if (split_mode == 3) {
-                    post_stream_a_pk_kernel<true><<<(waves_a + 3) / 4, 256, 0, s>>>(a);
-                    if (plain_srgb) post_stream_b_pk_kernel<JXLGPU_TF_SRGB, true><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
-                    else post_stream_b_pk_kernel<-1, true><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
-                } else {
-                    post_stream_a_pk_kernel<false><<<(waves_a + 3) / 4, 256, 0, s>>>(a);
-                    if (plain_srgb) post_stream_b_pk_kernel<JXLGPU_TF_SRGB, false><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
-                    else post_stream_b_pk_kernel<-1, false><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
-                }
-            } else {
-                const int waves_a = a.a_strips * a.a_segs, waves_b = a.strips * a.segs;
-                post_stream_a_kernel<<<(waves_a + 3) / 4, 256, 0, s>>>(a);
-                if (plain_srgb) post_stream_b_kernel<JXLGPU_TF_SRGB><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
-                else post_stream_b_kernel<-1><<<(waves_b + 3) / 4, 256, 0, s>>>(a);
-            }
-        } else if (use_pk) {
-            // two strips per wave (stream_pk.inc): pick the segment height that fills the 1024 SIMDs evenly
-            const int pairs = (a.strips + 1) / 2;
-            if (!getenv("JXLGPU_STREAM_ROWS")) {
-                long best_cost = -1;
-                for (int rows = 24; rows <= 96; rows += 4) {
-                    const long segs = (a.sy1 - a.sy0 + rows - 1) / rows;
-                    const long rounds = (pairs * segs + 1023) / 1024;
-                    const long cost = rounds * (rows + 2 * SH);
-                    if (best_cost < 0 || cost < best_cost) { best_cost = cost; a.rows_per_seg = rows; }
-                }
-                a.segs = (a.sy1 - a.sy0 + a.rows_per_seg - 1) / a.rows_per_seg;
-            }
-            fill_pk_consts(a);
-            const int pk_waves = pairs * a.segs;
-            if (pk_mode == 3) {
-                if (plain_srgb) post_stream_pk3_kernel<JXLGPU_TF_SRGB><<<(pk_waves + 3) / 4, 256, 0, s>>>(a);
-                else post_stream_pk3_kernel<-1><<<(pk_waves + 3) / 4, 256, 0, s>>>(a);
-            } else if (plain_srgb) {
-                post_stream_pk_kernel<JXLGPU_TF_SRGB><<<(pk_waves + 3) / 4, 256, 0, s>>>(a);
-            } else {
-                post_stream_pk_kernel<-1><<<(pk_waves + 3) / 4, 256, 0, s>>>(a);
-            }
-        } else if (plain_srgb) {
-            post_stream_kernel<JXLGPU_TF_SRGB><<<(waves + 3) / 4, 256, 0, s>>>(a);
-        } else {
-            post_stream_kernel<-1><<<(waves + 3) / 4, 256, 0, s>>>(a);
-        }
-        a.tiles = f->ring_tiles;
-        constexpr size_t lds_bytes = 2 * 3 * PostCfg<true, 2>::PLANE * sizeof(float);
-        // the border ring (a few hundred long-latency tiles) runs beside the streaming kernel
-        if (ctx && ctx->stream2) {
-            (void)hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
-            fused_post_kernel<true, 2><<<f->n_ring_tiles, 256, lds_bytes, ctx->stream2>>>(a);
-            (void)hipEventRecord(ctx->ev_join, ctx->stream2);
-            (void)hipStreamWaitEvent(s, ctx->ev_join, 0);
-        } else {
-            fused_post_kernel<true, 2><<<f->n_ring_tiles, 256, lds_bytes, s>>>(a);
-        }
-        return;
     }
-    switch ((gabor ? 4 : 0) + epf_iters) {
-        case 0: launch_cfg<false, 0>(s, a); break;
-        case 1: launch_cfg<false, 1>(s, a); break;
-        case 2: launch_cfg<false, 2>(s, a); break;
-        case 3: launch_cfg<false, 3>(s, a); break;
-        case 4: launch_cfg<true, 0>(s, a); break;
-        case 5: launch_cfg<true, 1>(s, a); break;
-        case 6: launch_cfg<true, 2>(s, a); break;
-        default: launch_cfg<true, 3>(s, a); break;
+    if (!stream) return launch_tile_kernel(s, a, gabor, epf_iters, full_grid);
+
+    a.sx0 = T; a.sx1 = T * tx_hi; a.sy0 = T; a.sy1 = T * ty_hi;
+    a.rows_per_seg = ctx ? ctx->tune.stream_rows : 48;
+    a.strips = (a.sx1 - a.sx0 + SW - 1) / SW;
+    a.segs = (a.sy1 - a.sy0 + a.rows_per_seg - 1) / a.rows_per_seg;
+    const int waves = a.strips * a.segs;
+    // plain XYB -> sRGB (no gamut map / second matrix) gets a branch-free colour epilogue
+    const bool plain_srgb = a.color.tf == JXLGPU_TF_SRGB && !a.color.gamut_map && !a.color.has_matrix2 &&
+                            !a.color.tone_map && !a.color.ycbcr;
+    const bool side = ctx && ctx->stream2;
+    hipError_t e;
+    if (side && (e = hipEventRecord(ctx->ev_fork, s)) != hipSuccess) return e;  // inputs are ready here
+    if (plain_srgb) post_stream_kernel<JXLGPU_TF_SRGB><<<(waves + 3) / 4, 256, 0, s>>>(a);
+    else post_stream_kernel<-1><<<(waves + 3) / 4, 256, 0, s>>>(a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    a.tiles = f->ring_tiles;
+    // the border ring (a few hundred long-latency tiles) runs beside the streaming kernel
+    if (side) {
+        if ((e = hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0)) != hipSuccess) return e;
+        if ((e = launch_tile_kernel(ctx->stream2, a, true, 2, dim3(f->n_ring_tiles))) != hipSuccess) return e;
+        if ((e = hipEventRecord(ctx->ev_join, ctx->stream2)) != hipSuccess) return e;
+        return hipStreamWaitEvent(s, ctx->ev_join, 0);
     }
+    return launch_tile_kernel(s, a, true, 2, dim3(f->n_ring_tiles));
 }

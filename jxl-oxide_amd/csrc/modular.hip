@@ -1098,8 +1098,9 @@ int fail(jxlgpu_ctx* ctx, int code, const char* msg) {
 }
 
 template <typename S>
-void launch_squeeze(hipStream_t s, bool horizontal, const SqzArgs& a, void* chk, size_t chk_bytes, int* redo_count) {
-    static const int seg_env = getenv("JXLGPU_SQZ_SEG") ? atoi(getenv("JXLGPU_SQZ_SEG")) : 128;  // pairs per segment
+void launch_squeeze(hipStream_t s, const Tuning& tune, bool horizontal, const SqzArgs& a, void* chk, size_t chk_bytes,
+                    int* redo_count) {
+    const int seg_env = tune.sqz_seg;  // pairs per segment
     auto al = [](const void* p, uint32_t stride) { return ((uintptr_t)p % 16 == 0) && ((stride * sizeof(S)) % 16 == 0); };
     const bool vec = al(a.avg, a.avg_stride) && al(a.res, a.res_stride) && al(a.out, a.out_stride);
     const uint32_t len = horizontal ? a.width : a.height, lines = horizontal ? a.height : a.width;
@@ -1110,7 +1111,7 @@ void launch_squeeze(hipStream_t s, bool horizontal, const SqzArgs& a, void* chk,
     const bool segmented = nseg >= 2 && (!horizontal || vec) && chk &&
                            (size_t)nseg * 2 * lines * sizeof(S) <= chk_bytes;
     if (segmented) {
-        static const uint32_t runin = getenv("JXLGPU_SQZ_RUNIN") ? (uint32_t)atoi(getenv("JXLGPU_SQZ_RUNIN")) : 1u;
+        const uint32_t runin = tune.sqz_runin;
         SegArgs g{a, L, nseg, chk, runin};
         dim3 grid(ceil_div(lines, 64), nseg);
         if (horizontal) {
@@ -1246,9 +1247,9 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     a.out = ptr(g, out_loc, &a.out_stride);
                     a.width = g.w; a.height = g.h;
                     g.loc = out_loc;
-                    if (i16) launch_squeeze<int16_t>(s, st.horizontal, a, m->chk, m->chk_bytes, m->d_redo);
-                    else launch_squeeze<int32_t>(s, st.horizontal, a, m->chk, m->chk_bytes, m->d_redo);
-                    if (getenv("JXLGPU_DEBUG_SYNC")) {
+                    if (i16) launch_squeeze<int16_t>(s, ctx->tune, st.horizontal, a, m->chk, m->chk_bytes, m->d_redo);
+                    else launch_squeeze<int32_t>(s, ctx->tune, st.horizontal, a, m->chk, m->chk_bytes, m->d_redo);
+                    if (ctx->tune.debug_sync) {
                         hipError_t e = hipStreamSynchronize(s);
                         fprintf(stderr, "squeeze %s ch%d %ux%u avg=%p(%u) res=%p(%u) out=%p(%u) -> %s\n", st.horizontal ? "H" : "V",
                                 begin + k, a.width, a.height, a.avg, a.avg_stride, a.res, a.res_stride, a.out, a.out_stride,
@@ -1340,7 +1341,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             }
         }
     }
-    if (getenv("JXLGPU_DEBUG_SYNC")) {
+    if (ctx->tune.debug_sync) {
         int redo = 0;
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(&redo, m->d_redo, sizeof(int), hipMemcpyDeviceToHost);

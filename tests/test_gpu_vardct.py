@@ -73,12 +73,31 @@ def test_filter_configs(gpu_ctx, oracle, iters, gab):
 
 
 def test_staged_post_path_matches(gpu_ctx, oracle, monkeypatch):
-    """The stage-at-a-time kernels (fallback path) must agree with the oracle too."""
+    """The stage-at-a-time kernels (fallback path) must agree with the oracle too.  The switches
+    are read once per context, at jxlgpu_create, so the test opens its own context."""
+    from jxl_oxide_amd import runtime
     monkeypatch.setenv("JXLGPU_NO_FUSED", "1")
-    for iters in (1, 2, 3):
-        wl = VardctWorkload(200, 136, seed=70 + iters, epf_iters=iters)
-        got, exp = _both(gpu_ctx, oracle, wl, S_ALL)
-        assert_ulp(got, exp, MAX_ULP, f"staged iters={iters}")
+    ctx = runtime.Context(0)
+    try:
+        for iters in (1, 2, 3):
+            wl = VardctWorkload(200, 136, seed=70 + iters, epf_iters=iters)
+            got, exp = _both(ctx, oracle, wl, S_ALL)
+            assert_ulp(got, exp, MAX_ULP, f"staged iters={iters}")
+    finally:
+        ctx.close()
+
+
+def test_tile_kernel_whole_frame_matches(gpu_ctx, oracle, monkeypatch):
+    """JXLGPU_NO_STREAM: the LDS tile kernel (normally only the border ring) over the whole frame."""
+    from jxl_oxide_amd import runtime
+    monkeypatch.setenv("JXLGPU_NO_STREAM", "1")
+    ctx = runtime.Context(0)
+    try:
+        wl = VardctWorkload(264, 200, seed=75)
+        got, exp = _both(ctx, oracle, wl, S_ALL)
+        assert_ulp(got, exp, MAX_ULP, "tile kernel, whole frame")
+    finally:
+        ctx.close()
 
 
 @pytest.mark.parametrize("size", [(1, 1), (2, 3), (5, 4), (3, 40), (33, 2)])
