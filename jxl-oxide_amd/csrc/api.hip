@@ -3,6 +3,7 @@
 // serial `for_each_varblocks` scan, jxl-render/src/vardct/mod.rs:693-730) and sequences the
 // kernels on the context's HIP stream.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -51,8 +52,8 @@ void ctx_dev_release(jxlgpu_ctx* ctx, void* p) {
 }
 
 hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
-                             float* const out[3], uint32_t out_stride, bool gabor, int epf_iters, bool color,
-                             jxlgpu_ctx* ctx);
+                             uint32_t in_tiled_w8, float* const out[3], uint32_t out_stride, bool gabor, int epf_iters,
+                             bool color, jxlgpu_ctx* ctx);
 bool fused_post_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, bool gabor, int epf_iters);
 
 struct UploadOpts {
@@ -275,6 +276,11 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     jxlgpu_ctx* ctx = new (std::nothrow) jxlgpu_ctx();
     if (!ctx) return JXLGPU_ERR_OOM;
     ctx->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->num_cus = (uint32_t)prop.multiProcessorCount;
+    }
     // environment -> per-context tuning, read once here (no process-global state afterwards)
     if (const char* mb = getenv("JXLGPU_POOL_MB")) ctx->pool_cap = (size_t)strtoull(mb, nullptr, 10) << 20;
     if (const char* v = getenv("JXLGPU_STREAM_ROWS")) {
@@ -284,6 +290,12 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     ctx->tune.no_stream = getenv("JXLGPU_NO_STREAM") != nullptr;
     ctx->tune.no_fused = getenv("JXLGPU_NO_FUSED") != nullptr;
     ctx->tune.debug_sync = getenv("JXLGPU_DEBUG_SYNC") != nullptr;
+    if (const char* v = getenv("JXLGPU_TR_WGS_PER_CU")) {
+        int t[4];
+        if (sscanf(v, "%d,%d,%d,%d", &t[0], &t[1], &t[2], &t[3]) == 4)
+            for (int i = 0; i < 4; ++i)
+                if (t[i] >= 0 && t[i] <= 16) ctx->tune.tr_wgs_per_cu[i] = t[i];
+    }
     if (const char* v = getenv("JXLGPU_SQZ_SEG")) {
         const int r = atoi(v);
         if (r >= 8 && r <= 4096) ctx->tune.sqz_seg = r;
@@ -304,6 +316,21 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
 void jxlgpu_destroy(jxlgpu_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+#ifdef JXL_TR_PROFILE
+    if (ctx->tr_prof) {
+        unsigned long long h[64];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, ctx->tr_prof, sizeof(h), hipMemcpyDeviceToHost);
+        static const char* kPh[9] = {"n", "entries", "coef+lut", "barrier0", "llf+dequant", "ydq+barrier1", "cfl+rows", "cols+stores", "drain"};
+        for (int fam = 0; fam < 4; ++fam) {
+            if (!h[fam * 16]) continue;
+            fprintf(stderr, "[tr_prof] family %d: %llu wave-items;", fam, h[fam * 16]);
+            for (int i = 1; i < 9; ++i) fprintf(stderr, " %s %.0f", kPh[i], (double)h[fam * 16 + i] / (double)h[fam * 16]);
+            fprintf(stderr, " (cycles / wave-item)\n");
+        }
+        (void)hipFree(ctx->tr_prof);
+    }
+#endif
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -536,6 +563,7 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     uint32_t* d_bad = static_cast<uint32_t*>(d_bad_v);
     HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
     TRY(dev_alloc(ctx, f, &f->coeff, npix * 3));
+    TRY(dev_alloc(ctx, f, &f->pix_t, npix * 3));
     if (d->coeff_format == JXLGPU_COEFF_SPARSE) HIP_TRY(ctx, hipMemsetAsync(f->coeff, 0, npix * 12, ctx->stream));
     for (int c = 0; c < 3; ++c) {
         TRY(upload_coeff_plane(ctx, f, d, c, tmp, d_bad));
@@ -544,7 +572,6 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
         f->lfq[c] = p;
         TRY(dev_alloc(ctx, f, &f->lf_a[c], ncell));
         TRY(dev_alloc(ctx, f, &f->lf[c], ncell));
-        TRY(dev_alloc(ctx, f, &f->pix[c], npix));
         if (o.no_post) continue;
         TRY(dev_alloc(ctx, f, &f->buf_a[c], npix));
         TRY(dev_alloc(ctx, f, &f->buf_b[c], npix));
@@ -579,7 +606,7 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     }
     f->nometa_count = (uint32_t)nometa.size();
     if (!nometa.empty()) TRY(dev_upload(ctx, f, &f->nometa_groups, nometa));
-    if (f->list_count[CLS_BIG]) TRY(dev_alloc(ctx, f, &f->big_tmp, npix * 3));
+    if (f->list_count[CLS_BIG]) TRY(dev_alloc(ctx, f, &f->big_tmp, npix * 6));
 
     // sec_half(64/128/256): dct_common.rs:56-66
     for (int i = 0, n = 64; i < 3; ++i, n *= 2) {
@@ -680,8 +707,11 @@ int jxlgpu_frame_download_lf(jxlgpu_ctx* ctx, const jxlgpu_frame* f, float* cons
 
 // Gabor -> EPF -> upsample -> colour on device planes; shared by the VarDCT and Modular paths.
 // `cur` holds W x H samples with stride `*cur_stride`; on return it points at the result.
+// `tiled_in` (VarDCT): the input is the cell-tiled transform output f->pix_t instead of `cur`; the
+// fused post kernels read it as it is, every other consumer gets row-major planes first.
 int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuFilterParams& fp,
-                    uint32_t up_factor, float* cur[3], uint32_t* cur_stride, uint32_t* ow, uint32_t* oh) {
+                    uint32_t up_factor, float* cur[3], uint32_t* cur_stride, uint32_t* ow, uint32_t* oh,
+                    bool tiled_in) {
     hipStream_t s = ctx->stream;
     const uint32_t W = f->width, H = f->height;
     const bool do_gab = (stages & JXLGPU_STAGE_GABOR) && fp.gab_enabled;
@@ -692,10 +722,19 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
     const bool fuse_color = do_color && !do_up && !do_noise;  // noise sits between upsampling and colour
 
     // Fast path: everything after the transform in one tile kernel (fused_kernels.hip)
-    if ((do_gab || epf_iters) && fused_post_supported(ctx, f, do_gab, epf_iters)) {
-        const float* in[3] = {cur[0], cur[1], cur[2]};
-        float** dst = (cur[0] == f->buf_a[0]) ? f->buf_b : f->buf_a;
-        HIP_TRY(ctx, launch_fused_post(s, f, in, *cur_stride, dst, f->wr, do_gab, epf_iters, fuse_color, ctx));
+    const bool fused = (do_gab || epf_iters) && fused_post_supported(ctx, f, do_gab, epf_iters);
+    if (tiled_in && !fused) {
+        // no fused kernel in front: planes for whoever reads next (staged filters, upsampling,
+        // colour, the download of a transform-only render)
+        launch_untile(s, f->pix_t, f->w8, f->buf_a, f->wr, f->wr, f->hr);
+        for (int c = 0; c < 3; ++c) cur[c] = f->buf_a[c];
+        *cur_stride = f->wr;
+    }
+    if (fused) {
+        const float* in[3] = {tiled_in ? f->pix_t : cur[0], cur[1], cur[2]};
+        float** dst = (!tiled_in && cur[0] == f->buf_a[0]) ? f->buf_b : f->buf_a;
+        HIP_TRY(ctx, launch_fused_post(s, f, in, *cur_stride, tiled_in ? f->w8 : 0u, dst, f->wr, do_gab, epf_iters,
+                                       fuse_color, ctx));
         for (int c = 0; c < 3; ++c) cur[c] = dst[c];
         *cur_stride = f->wr;
         if (fuse_color) {
@@ -1007,12 +1046,12 @@ int render_subsampled(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const J
         for (int c = 0; c < 3; ++c) {
             if (!sub.member[c]) continue;
             const uint32_t in_w = ssize1(f->width, has_h, sub.hshift != 0), in_h = ssize1(f->height, has_v, sub.vshift != 0);
-            launch_upsample_jpeg(ctx->stream, sub.child->pix[c], sub.child->wr, in_w, in_h, sub.hshift, sub.vshift,
-                                 f->pix[c], f->wr, f->width, f->height);
+            launch_upsample_jpeg(ctx->stream, sub.child->pix_t, sub.child->w8, (uint32_t)c, in_w, in_h, sub.hshift,
+                                 sub.vshift, f->pix[c], f->wr, f->width, f->height);
         }
     float* cur[3] = {f->pix[0], f->pix[1], f->pix[2]};
     uint32_t stride = f->wr, ow = f->width, oh = f->height;
-    TRY(run_post_stages(ctx, f, stages, f->desc.filter, 1, cur, &stride, &ow, &oh));
+    TRY(run_post_stages(ctx, f, stages, f->desc.filter, 1, cur, &stride, &ow, &oh, false));
     ctx->prof_end(PROF_POST);
     return finish_render(ctx, f, cur, stride, ow, oh, out);
 }
@@ -1053,8 +1092,9 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
     // ---- V4-V8
     TransformArgs ta;
     ta.coeff = f->coeff;
+    ta.pix = f->pix_t;
     for (int c = 0; c < 3; ++c) {
-        ta.pix[c] = f->pix[c]; ta.lf[c] = lf[c];
+        ta.lf[c] = lf[c];
         ta.qm_scale[c] = f->qm_scale[c]; ta.quant_bias[c] = d.quant_bias[c];
     }
     ta.kind = f->kind; ta.hf_mul = f->hf_mul; ta.kx_map = f->kx_map; ta.kb_map = f->kb_map;
@@ -1066,32 +1106,30 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
     ta.quant_bias_numerator = d.quant_bias_numerator;
     ta.big_tmp = f->big_tmp;
     ta.deq_lut = f->deq_lut;
-    ctx->prof_begin(PROF_TRANSFORM);
-    const bool has_side = f->list_count[CLS_64x64] | f->list_count[CLS_32x64] | f->list_count[CLS_64x32] |
-                          f->list_count[CLS_SPECIAL8] | f->list_count[CLS_32x32] | f->list_count[CLS_8x32] |
-                          f->list_count[CLS_32x8] | f->list_count[CLS_16x32] | f->list_count[CLS_32x16];
-    if (has_side) {
-        // fork: the few, long work items (64- and 32-px shapes, the special 8x8 family) start first on
-        // the side stream and run beside the bulk (8x8 and 16-px shapes) instead of forming its tail
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        for (int cls : {CLS_64x64, CLS_32x64, CLS_64x32})
-            launch_transform_class(ctx->stream2, cls, ta, f->entries + f->class_first[cls], f->list_count[cls]);
-        HIP_TRY(ctx, launch_transform_rows(ctx->stream2, 1, ta, f->entries, f->class_first, f->list_count));
-        launch_transform_class(ctx->stream2, CLS_SPECIAL8, ta, f->entries + f->class_first[CLS_SPECIAL8],
-                               f->list_count[CLS_SPECIAL8]);
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+#ifdef JXL_TR_PROFILE
+    if (!ctx->tr_prof) {
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->tr_prof, 64 * 8));
+        HIP_TRY(ctx, hipMemset(ctx->tr_prof, 0, 64 * 8));
     }
-    HIP_TRY(ctx, launch_transform_rows(s, 0, ta, f->entries, f->class_first, f->list_count));
-    if (has_side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+    ta.prof = ctx->tr_prof;
+#endif
+    ctx->prof_begin(PROF_TRANSFORM);
+    // few, long work items first (64-px, 32-px shapes, the special 8x8 family), the bulk last
+    for (int fam : {3, 2}) HIP_TRY(ctx, launch_transform_items(s, fam, ta, f->entries, f->class_first, f->list_count, ctx->num_cus, ctx->tune.tr_wgs_per_cu[fam]));
+    launch_transform_class(s, CLS_SPECIAL8, ta, f->entries + f->class_first[CLS_SPECIAL8], f->list_count[CLS_SPECIAL8]);
+    for (int fam : {1, 0}) HIP_TRY(ctx, launch_transform_items(s, fam, ta, f->entries, f->class_first, f->list_count, ctx->num_cus, ctx->tune.tr_wgs_per_cu[fam]));
     launch_transform_class(s, CLS_BIG, ta, f->entries + f->class_first[CLS_BIG], f->list_count[CLS_BIG]);
     launch_nometa_groups(s, ta, f->nometa_groups, f->nometa_count, f->group_dim, ceil_div(f->width, f->group_dim));
     ctx->prof_end(PROF_TRANSFORM);
 
-    float* cur[3] = {f->pix[0], f->pix[1], f->pix[2]};
+    if (!f->buf_a[0]) {  // single-geometry child of a chroma-subsampled frame: V1-V8 only, the parent reads pix_t
+        HIP_TRY(ctx, hipGetLastError());
+        return JXLGPU_OK;
+    }
+    float* cur[3] = {nullptr, nullptr, nullptr};  // the input of the post stages is the tiled f->pix_t
     uint32_t stride = f->wr, ow = f->width, oh = f->height;
     ctx->prof_begin(PROF_POST);
-    TRY(run_post_stages(ctx, f, stages, d.filter, d.upsampling.factor ? d.upsampling.factor : 1, cur, &stride, &ow, &oh));
+    TRY(run_post_stages(ctx, f, stages, d.filter, d.upsampling.factor ? d.upsampling.factor : 1, cur, &stride, &ow, &oh, true));
     ctx->prof_end(PROF_POST);
     return finish_render(ctx, f, cur, stride, ow, oh, out);
 }

@@ -114,8 +114,10 @@ __global__ __launch_bounds__(256) void big_block_kernel(TransformArgs a, const u
     float mul_y = 65536.0f / (a.global_scale * hm) * a.qm_scale[1];
     const float* mat_c = a.dequant + a.deq_off[type * 3 + c];
     const float* mat_y = a.dequant + a.deq_off[type * 3 + 1];
-    float* out = a.pix[c] + (size_t)py0 * a.pstride + px0;
-    float* scratch = tmp + (size_t)c * a.pstride * (a.h8 * 8) + (size_t)py0 * a.pstride + px0;
+    // both working copies are row-major scratch planes; the result moves to the tiled output last
+    const size_t plane = (size_t)a.pstride * (a.h8 * 8);
+    float* out = tmp + (size_t)(3 + c) * plane + (size_t)py0 * a.pstride + px0;
+    float* scratch = tmp + (size_t)c * plane + (size_t)py0 * a.pstride + px0;
 
     // V4 + V5
     for (int i = t; i < W * H; i += 256) {
@@ -155,6 +157,11 @@ __global__ __launch_bounds__(256) void big_block_kernel(TransformArgs a, const u
     __syncthreads();
     for (int x = t; x < W; x += 256)
         idct_iterative(Strided{out + x, a.pstride}, Strided{scratch + x, a.pstride}, H, sl);
+    __syncthreads();
+    for (int i = t; i < W * H; i += 256) {
+        const int y = i / W, x = i % W;
+        a.pix[coeff_tiled_index(px0 + x, py0 + y, c, a.w8)] = out[(size_t)y * a.pstride + x];
+    }
 }
 
 void launch_big_blocks(hipStream_t s, const TransformArgs& a, const uint4* list, uint32_t count) {

@@ -34,15 +34,19 @@ enum VbClass : int {
     CLS_COUNT
 };
 
-// HF coefficients in HBM: 8x8 cells, channel-interleaved.  Cell (cx, cy) holds 3 x 64 words
-// {X, Y, B}, each 8 rows of 8.  Word index of sample (px, py) of channel c:
+// HF coefficients AND the transform output live in HBM as 8x8 cells, channel-interleaved: cell
+// (cx, cy) holds 3 x 64 words {X, Y, B}, each 8 rows of 8.  Every varblock, whatever
+// its shape or alignment, then reads and writes whole 256-byte runs: a row-major plane would take
+// 32-byte pieces of 128-byte lines from varblocks of different shape classes at different times
+// (measured with tools/mem_probe.hip: 1.8 TB/s against 4.0 TB/s for scattered 8x8 varblocks).
+// Word index of sample (px, py) of channel c:
 __host__ __device__ inline size_t coeff_tiled_index(uint32_t px, uint32_t py, uint32_t c, uint32_t w8) {
     return ((((size_t)(py >> 3) * w8 + (px >> 3)) * 3 + c) << 6) + ((py & 7u) << 3) + (px & 7u);
 }
 
 struct TransformArgs {
     const int32_t* coeff;      // i32 coefficients, cell-tiled (coeff_tiled_index)
-    float* pix[3];             // output planes, stride = pstride
+    float* pix;                // transform output, cell-tiled like `coeff` (coeff_tiled_index)
     const float* lf[3];        // LF planes after V1-V3, stride = w8
     const uint8_t* kind;       // frame-level BlockInfo plane, stride w8
     const int32_t* hf_mul;
@@ -54,13 +58,16 @@ struct TransformArgs {
     const float* sec64;        // sec_half(64/128/256)
     const float* sec128;
     const float* sec256;
-    uint32_t pstride, w8, h8, w64;
+    uint32_t pstride, w8, h8, w64;  // pstride: row stride of the big_tmp scratch planes
     float global_scale;        // as f32
     float qm_scale[3];
     float quant_bias[3];
     float quant_bias_numerator;
-    float* big_tmp;            // 3 planes of pstride x (h8*8) scratch for the >=128 path
+    float* big_tmp;            // 6 row-major planes of pstride x (h8*8): working storage of the >=128 path
     const float* deq_lut;      // 256 x quant_bias_numerator / k (k >= 2), or nullptr: divide
+#ifdef JXL_TR_PROFILE
+    unsigned long long* prof;  // tools only (make PROF=1): per-phase s_memtime sums, 4 families x 16 slots
+#endif
 };
 
 struct LfArgs {
@@ -126,12 +133,15 @@ struct Tuning {
     bool no_stream = false;      // JXLGPU_NO_STREAM: LDS tile kernel for the whole frame
     bool no_fused = false;       // JXLGPU_NO_FUSED: one kernel per post stage
     bool debug_sync = false;     // JXLGPU_DEBUG_SYNC: synchronise + report after every launch group
+    int tr_wgs_per_cu[4] = {0, 0, 0, 0};  // JXLGPU_TR_WGS_PER_CU="a,b,c,d": persistent transform workgroups per CU
+                                 // for the 8-, 16-, 32- and 64-px launch (0: one workgroup per item, no run-ahead)
     int sqz_seg = 128;           // JXLGPU_SQZ_SEG: pairs per inverse-Squeeze segment
     uint32_t sqz_runin = 1;      // JXLGPU_SQZ_RUNIN: 0 forces the Squeeze fix-up path (tests)
 };
 
 struct jxlgpu_ctx {
     int device = 0;
+    uint32_t num_cus = 256;     // hipDeviceProp_t::multiProcessorCount (persistent grids are sized from it)
     Tuning tune;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: 64-pixel varblock kernels overlap the <=32 kernel
@@ -144,6 +154,9 @@ struct jxlgpu_ctx {
     std::unordered_map<void*, size_t> live;
     std::multimap<size_t, void*> pool;
     size_t pool_bytes = 0, pool_cap = (size_t)8 << 30;
+#ifdef JXL_TR_PROFILE
+    unsigned long long* tr_prof = nullptr;
+#endif
     void* noise_jump = nullptr; // device copy of the xorshift128+ jump matrices (noise_kernels.hip)
     void* pinned = nullptr;     // pinned staging buffer (grown on demand)
     size_t pinned_size = 0;
@@ -195,7 +208,8 @@ struct jxlgpu_frame {
     float* sec[3] = {};
     float* lf_a[3] = {};        // after V1+V2
     float* lf[3] = {};          // after V3 (== lf_a when smoothing is skipped)
-    float* pix[3] = {};         // transform output, wr x hr
+    float* pix_t = nullptr;     // transform output, 3 * wr * hr words, cell-tiled (coeff_tiled_index)
+    float* pix[3] = {};         // chroma-subsampled parent only: row-major planes after upsample_jpeg
     float* buf_a[3] = {};       // filter ping
     float* buf_b[3] = {};       // filter pong
     float* big_tmp = nullptr;  // scratch for the >=128 transform path (aliases buf_a[0])
@@ -255,8 +269,9 @@ void launch_lf_dequant_cfl(hipStream_t s, const LfArgs& a);
 void launch_lf_smooth(hipStream_t s, const SmoothArgs& a);
 void launch_transform_class(hipStream_t s, int cls, const TransformArgs& a, const uint4* entries,
                             uint32_t count);
-hipError_t launch_transform_rows(hipStream_t s, int family, const TransformArgs& a, const uint4* entries,
-                                 const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT]);
+hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs& a, const uint4* entries,
+                                  const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT],
+                                  uint32_t num_cus, int wgs_per_cu);
 void launch_nometa_groups(hipStream_t s, const TransformArgs& a, const uint32_t* groups,
                           uint32_t count, uint32_t group_dim, uint32_t groups_per_row);
 void launch_gabor(hipStream_t s, const FilterArgs& a);
@@ -270,8 +285,10 @@ bool noise_geometry_unsupported(uint32_t height, uint32_t group_dim);
 void launch_noise(hipStream_t s, const JxlGpuNoiseParams& np, const void* jump_dev, float* const raw[3],
                   float* const ch[3], uint32_t stride, uint32_t width, uint32_t height, uint32_t group_dim,
                   float corr_x, float corr_b);
-void launch_upsample_jpeg(hipStream_t s, const float* in, uint32_t in_stride, uint32_t in_w, uint32_t in_h, int hshift,
-                          int vshift, float* out, uint32_t out_stride, uint32_t width, uint32_t height);
+void launch_upsample_jpeg(hipStream_t s, const float* in_tiled, uint32_t in_w8, uint32_t c, uint32_t in_w, uint32_t in_h,
+                          int hshift, int vshift, float* out, uint32_t out_stride, uint32_t width, uint32_t height);
+void launch_untile(hipStream_t s, const float* tiled, uint32_t w8, float* const out[3], uint32_t out_stride,
+                   uint32_t width, uint32_t height);
 void launch_coeff_retile(hipStream_t s, const void* src, bool src_i16, uint32_t wr, uint32_t hr, uint32_t c,
                          int32_t* dst);
 void launch_coeff_scatter(hipStream_t s, const uint32_t* pos, const void* val, bool val_i16, size_t count,

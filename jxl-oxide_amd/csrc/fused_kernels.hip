@@ -32,9 +32,10 @@ struct PostCfg {
 };
 
 struct FusedArgs {
-    const float* in[3];
+    const float* in[3];      // row-major planes, or in[0] = the cell-tiled transform output (in_w8 != 0)
     float* out[3];
     uint32_t in_stride, out_stride;
+    uint32_t in_w8;          // cells per row of the tiled input (coeff_tiled_index)
     int width, height;
     const float* sigma;
     uint32_t sigma_stride;
@@ -45,6 +46,12 @@ struct FusedArgs {
     // streaming kernel geometry: it covers [sx0, sx1) x [sy0, sy1), strictly inside the image
     int sx0, sx1, sy0, sy1, rows_per_seg, strips, segs;
 };
+
+template <bool TILED>
+__device__ __forceinline__ float load_in(const FusedArgs& a, int c, int x, int y) {
+    if constexpr (TILED) return a.in[0][coeff_tiled_index((uint32_t)x, (uint32_t)y, (uint32_t)c, a.in_w8)];
+    else return a.in[c][(size_t)y * a.in_stride + x];
+}
 
 // Refill the out-of-image cells of the square region [lo, LW-lo) of `buf` (3 planes) from their
 // mirrored in-image cells.  (ox, oy) = image coordinate of LDS cell (0, 0).
@@ -95,7 +102,7 @@ __device__ __forceinline__ void epf_stage(const float* src, float* dst, int lo, 
     }
 }
 
-template <bool GAB, int ITERS>
+template <bool GAB, int ITERS, bool TILED>
 __global__ __launch_bounds__(256) void fused_post_kernel(FusedArgs a) {
     using Cfg = PostCfg<GAB, ITERS>;
     constexpr int LW = Cfg::LW, PLANE = Cfg::PLANE, HALO = Cfg::HALO;
@@ -118,9 +125,8 @@ __global__ __launch_bounds__(256) void fused_post_kernel(FusedArgs a) {
     for (int i = t; i < PLANE; i += 256) {
         int ly = i / LW, lx = i % LW;
         int x = mirror_idx(ox + lx, W), y = mirror_idx(oy + ly, H);
-        size_t g = (size_t)y * a.in_stride + x;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) bufA[c * PLANE + i] = a.in[c][g];
+        for (int c = 0; c < 3; ++c) bufA[c * PLANE + i] = load_in<TILED>(a, c, x, y);
     }
     __syncthreads();
 
@@ -249,7 +255,7 @@ struct StreamConst {
 
 // One row step; P = (j - j_start) & 3 is a compile-time phase so every ring slot below is a
 // fixed register (no rotation moves).
-template <int P, int TF>
+template <int P, int TF, bool TILED>
 __device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst& k, StreamState& st, int j,
                                            const uint32_t* srgb_lut) {
     constexpr int s0 = P & 3, sm1 = (P + 3) & 3, sm2 = (P + 2) & 3, sm3 = (P + 1) & 3;  // rows j, j-1, j-2, j-3 (== j-4 -> s0)
@@ -258,9 +264,8 @@ __device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst
     for (int c = 0; c < 3; ++c) st.I[s0][c] = st.nxt[c];
     {
         int jn = min(j + 1, a.height - 1);
-        size_t gi = (size_t)jn * a.in_stride + k.xl;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) st.nxt[c] = a.in[c][gi];
+        for (int c = 0; c < 3; ++c) st.nxt[c] = load_in<TILED>(a, c, k.xl, jn);
         // sigma of row e+1 = j-2 for the next step; this step's f = e-1 reuses the previous e
         st.sig_f = st.sig_e; st.inv_f = st.inv_e;
         st.sig_e = st.sig_nxt; st.inv_e = st.inv_nxt;
@@ -389,7 +394,7 @@ __device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst
     }
 }
 
-template <int TF>
+template <int TF, bool TILED>
 __global__ __launch_bounds__(256) void post_stream_kernel(FusedArgs a) {
     __shared__ uint32_t srgb_lut[16];
     if (threadIdx.x < 16) srgb_lut[threadIdx.x] = kSrgbMulBits[threadIdx.x];
@@ -424,9 +429,8 @@ __global__ __launch_bounds__(256) void post_stream_kernel(FusedArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) st.I[i][c] = st.G[i][c] = st.V[i][c] = st.H[i][c] = st.E[i][c] = st.Wd[i][c] = 0.0f;
     {
-        size_t gi = (size_t)(k.yb - SH) * a.in_stride + k.xl;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) st.nxt[c] = a.in[c][gi];
+        for (int c = 0; c < 3; ++c) st.nxt[c] = load_in<TILED>(a, c, k.xl, k.yb - SH);
         // first step is j = yb-SH with e = j-3: sig_nxt must hold sigma(row j-3) when it rotates in
         st.sig_e = st.sig_f = 1.0f;
         st.inv_e = st.inv_f = 0.0f;
@@ -436,10 +440,10 @@ __global__ __launch_bounds__(256) void post_stream_kernel(FusedArgs a) {
     }
     // (ye - yb) and 2*SH are multiples of 4: whole groups of four phases
     for (int j = k.yb - SH; j < ye + SH; j += 4) {
-        stream_row<0, TF>(a, k, st, j, srgb_lut);
-        stream_row<1, TF>(a, k, st, j + 1, srgb_lut);
-        stream_row<2, TF>(a, k, st, j + 2, srgb_lut);
-        stream_row<3, TF>(a, k, st, j + 3, srgb_lut);
+        stream_row<0, TF, TILED>(a, k, st, j, srgb_lut);
+        stream_row<1, TF, TILED>(a, k, st, j + 1, srgb_lut);
+        stream_row<2, TF, TILED>(a, k, st, j + 2, srgb_lut);
+        stream_row<3, TF, TILED>(a, k, st, j + 3, srgb_lut);
     }
 }
 
@@ -449,10 +453,13 @@ hipError_t launch_cfg(hipStream_t s, const FusedArgs& a, dim3 grid) {
     // > 64 KiB of dynamic LDS needs the attribute; setting it is idempotent and thread-safe
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_post_kernel<GAB, ITERS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_post_kernel<GAB, ITERS, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_post_kernel<GAB, ITERS, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     });
-    fused_post_kernel<GAB, ITERS><<<grid, 256, lds_bytes, s>>>(a);
+    if (a.in_w8) fused_post_kernel<GAB, ITERS, true><<<grid, 256, lds_bytes, s>>>(a);
+    else fused_post_kernel<GAB, ITERS, false><<<grid, 256, lds_bytes, s>>>(a);
     return hipGetLastError();
 }
 
@@ -479,12 +486,13 @@ bool fused_post_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, bool gab
 // only on success).  If the ring-tile list cannot be allocated the whole frame runs through the
 // tile kernel, which needs no list.
 hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
-                             float* const out[3], uint32_t out_stride, bool gabor, int epf_iters, bool color,
-                             jxlgpu_ctx* ctx) {
+                             uint32_t in_tiled_w8, float* const out[3], uint32_t out_stride, bool gabor, int epf_iters,
+                             bool color, jxlgpu_ctx* ctx) {
     FusedArgs a;
     memset(&a, 0, sizeof(a));
     for (int c = 0; c < 3; ++c) { a.in[c] = in[c]; a.out[c] = out[c]; }
     a.in_stride = in_stride; a.out_stride = out_stride;
+    a.in_w8 = in_tiled_w8;  // != 0: in[0] is the cell-tiled transform output
     a.width = (int)f->width; a.height = (int)f->height;
     a.sigma = f->sigma; a.sigma_stride = f->w8;
     a.fp = f->desc.filter;
@@ -531,8 +539,14 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
     const bool side = ctx && ctx->stream2;
     hipError_t e;
     if (side && (e = hipEventRecord(ctx->ev_fork, s)) != hipSuccess) return e;  // inputs are ready here
-    if (plain_srgb) post_stream_kernel<JXLGPU_TF_SRGB><<<(waves + 3) / 4, 256, 0, s>>>(a);
-    else post_stream_kernel<-1><<<(waves + 3) / 4, 256, 0, s>>>(a);
+    const dim3 sgrid((waves + 3) / 4);
+    if (a.in_w8) {
+        if (plain_srgb) post_stream_kernel<JXLGPU_TF_SRGB, true><<<sgrid, 256, 0, s>>>(a);
+        else post_stream_kernel<-1, true><<<sgrid, 256, 0, s>>>(a);
+    } else {
+        if (plain_srgb) post_stream_kernel<JXLGPU_TF_SRGB, false><<<sgrid, 256, 0, s>>>(a);
+        else post_stream_kernel<-1, false><<<sgrid, 256, 0, s>>>(a);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     a.tiles = f->ring_tiles;
     // the border ring (a few hundred long-latency tiles) runs beside the streaming kernel

@@ -11,22 +11,22 @@
 namespace {
 
 struct UpJpegArgs {
-    const float* in;
+    const float* in;   // the child's transform output: cell-tiled (coeff_tiled_index), channel `c`
     float* out;
-    uint32_t in_stride, in_w, in_h, out_stride, width, height;
+    uint32_t in_w8, c, in_w, in_h, out_stride, width, height;
     int hshift, vshift;
 };
 
 __device__ __forceinline__ float h_value(const UpJpegArgs& a, uint32_t x, uint32_t row) {
-    const float* r = a.in + (size_t)row * a.in_stride;
-    if (!a.hshift) return r[x];
+    auto r = [&](uint32_t xi) { return a.in[coeff_tiled_index(xi, row, a.c, a.in_w8)]; };
+    if (!a.hshift) return r(x);
     const uint32_t i = x >> 1;
-    const float curr = r[i];
+    const float curr = r(i);
     if ((x & 1) == 0) {
-        const float prev = i > 0 ? r[i - 1] : r[0];
+        const float prev = i > 0 ? r(i - 1) : r(0);
         return 0.25f * prev + 0.75f * curr;
     }
-    const float next = i + 1 < a.in_w ? r[i + 1] : r[a.in_w - 1];
+    const float next = i + 1 < a.in_w ? r(i + 1) : r(a.in_w - 1);
     return 0.75f * curr + 0.25f * next;
 }
 
@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void upsample_jpeg_kernel(UpJpegArgs a) {
 
 }  // namespace
 
-void launch_upsample_jpeg(hipStream_t s, const float* in, uint32_t in_stride, uint32_t in_w, uint32_t in_h, int hshift,
-                          int vshift, float* out, uint32_t out_stride, uint32_t width, uint32_t height) {
-    UpJpegArgs a{in, out, in_stride, in_w, in_h, out_stride, width, height, hshift, vshift};
+void launch_upsample_jpeg(hipStream_t s, const float* in_tiled, uint32_t in_w8, uint32_t c, uint32_t in_w, uint32_t in_h,
+                          int hshift, int vshift, float* out, uint32_t out_stride, uint32_t width, uint32_t height) {
+    UpJpegArgs a{in_tiled, out, in_w8, c, in_w, in_h, out_stride, width, height, hshift, vshift};
     hipLaunchKernelGGL(upsample_jpeg_kernel, dim3((width + 255) / 256, height), dim3(256), 0, s, a);
 }

@@ -23,7 +23,8 @@
 #include "common.h"
 
 int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuFilterParams& fp,
-                    uint32_t up_factor, float* cur[3], uint32_t* cur_stride, uint32_t* ow, uint32_t* oh);
+                    uint32_t up_factor, float* cur[3], uint32_t* cur_stride, uint32_t* ow, uint32_t* oh,
+                    bool tiled_in);
 int finish_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stride, uint32_t ow, uint32_t oh,
                   const JxlGpuOut* out);
 int upload_post_params(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuUpsampling& up);
@@ -1512,7 +1513,7 @@ int jxlgpu_modular_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, con
     uint32_t stride = f->wr, ow = f->width, oh = f->height;
     ctx->prof_begin(PROF_POST);
     rc = run_post_stages(ctx, f, stages, f->desc.filter, f->desc.upsampling.factor ? f->desc.upsampling.factor : 1,
-                         cur, &stride, &ow, &oh);
+                         cur, &stride, &ow, &oh, false);
     ctx->prof_end(PROF_POST);
     if (rc) return rc;
     return finish_render(ctx, f, cur, stride, ow, oh, out);

@@ -8,20 +8,47 @@
 // line with a neighbour of another shape (the row-major planes of round 1 fetched every line
 // once per shape class that touched it: 2.4x read amplification).
 //
-// A work item is NBI = 64 / min(W, H) varblocks of one shape.  The wave makes, per channel:
+// A work item is NBI = 64 / min(W, H) varblocks of one shape, handled by one 192-thread workgroup:
+// wave 0 takes channel Y, wave 1 X, wave 2 B.  Each wave makes
 //   row pass   : lane = one row (W coefficients) -> 16-byte loads straight into registers ->
-//                dequantise (+ CfL from the Y row kept in registers) -> 1-D IDCT in registers ->
-//                one ds_write_b32 per sample into a padded LDS tile (bank-conflict free);
+//                dequantise -> (X, B: chroma-from-luma from the Y wave's dequantised rows, handed
+//                over through LDS at the one mid-item barrier) -> 1-D IDCT in registers ->
+//                one ds_write_b32 per sample into the wave's padded LDS tile (bank-conflict free);
 //   column pass: lane = one column: H ds_read_b32 -> 1-D IDCT -> H dword stores.
-// The LDS tile belongs to the wave; LDS operations of one wave execute in order, so the passes
-// are ordered by compiler fences only.  Operation order inside every butterfly is the reference's
+// The tile belongs to the wave; LDS operations of one wave execute in order, so the two passes are
+// ordered by compiler fences only.  Operation order inside every butterfly is the reference's
 // (dct_device.h), hence results are bit-identical to the CPU path.
 #include "common.h"
 #include "dct_device.h"
 
 #include "afv_basis.inc"
 
+#include <mutex>
+
 namespace {
+
+// Phase timing for tools/ (make PROF=1 -> libjxlgpu_prof.so): s_memtime stamps per wave, summed per
+// phase into TransformArgs::prof.  Compiled out of the product library.
+#ifdef JXL_TR_PROFILE
+#define TR_STAMP_DECL unsigned long long tr_t[12]; int tr_n = 0;
+#define TR_STAMP(drain)                                                   \
+    do {                                                                  \
+        if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+        tr_t[tr_n++] = __builtin_amdgcn_s_memtime();                      \
+        asm volatile("" ::: "memory");                                    \
+    } while (0)
+#define TR_STAMP_FLUSH(slot)                                                                      \
+    do {                                                                                          \
+        if (a.prof && (threadIdx.x & 63) == 0 && blockIdx.x % 41 == 0) {                                                \
+            for (int i_ = 1; i_ < tr_n; ++i_) atomicAdd(a.prof + (slot) * 16 + i_, tr_t[i_] - tr_t[i_ - 1]); \
+            atomicAdd(a.prof + (slot) * 16, 1ull);                                                \
+        }                                                                                         \
+    } while (0)
+#else
+#define TR_STAMP_DECL
+#define TR_STAMP(drain) do {} while (0)
+#define TR_STAMP_FLUSH(slot) do {} while (0)
+#endif
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -81,35 +108,14 @@ struct RCfg {
     static constexpr int S = W + 1;               // padded row stride (words)
     static constexpr int BS = block_stride(W, H); // block stride (words)
     static constexpr int T_WORDS = NBI * BS;
-    static constexpr int LLF_WORDS = NBI * 3 * BW * BH;
-    static constexpr int WAVE_WORDS = T_WORDS + LLF_WORDS;
+    static constexpr int LLF_WORDS = NBI * BW * BH;              // one channel
+    static constexpr int WAVE_WORDS = T_WORDS + LLF_WORDS;       // per wave (= per channel)
+    static constexpr int YDQ_WORDS = RP * W * 64;                // dequantised Y rows, [pass][x][lane]
+    static constexpr int WG_WORDS = 256 + YDQ_WORDS + 3 * WAVE_WORDS;
 };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
-constexpr int kWaveWordsA = cmax(cmax(RCfg<8, 8>::WAVE_WORDS, RCfg<16, 16>::WAVE_WORDS),
-                                 cmax(RCfg<8, 16>::WAVE_WORDS, RCfg<16, 8>::WAVE_WORDS));
-constexpr int kWaveWordsB = cmax(cmax(cmax(RCfg<32, 32>::WAVE_WORDS, RCfg<8, 32>::WAVE_WORDS),
-                                      cmax(RCfg<32, 8>::WAVE_WORDS, RCfg<16, 32>::WAVE_WORDS)),
-                                 RCfg<32, 16>::WAVE_WORDS);
 constexpr int kLutWords = 256;
-
-// chroma-from-luma factor of a row that may straddle a 64-px tile column (varblocks need not be
-// aligned): samples x < split take k0, the rest k1 (chroma_from_luma_hf_grouped, mod.rs:589-600)
-struct CflRow {
-    float kx0, kx1, kb0, kb1;
-    int split;
-};
-
-template <int W>
-__device__ __forceinline__ CflRow cfl_row(const TransformArgs& a, uint32_t px0, uint32_t py) {
-    CflRow r;
-    const uint32_t t0 = (py >> 6) * a.w64 + (px0 >> 6), t1 = (py >> 6) * a.w64 + ((px0 + W - 1) >> 6);
-    r.kx0 = a.kx_map[t0]; r.kb0 = a.kb_map[t0];
-    r.kx1 = a.kx_map[t1]; r.kb1 = a.kb_map[t1];
-    r.split = 64 - (int)(px0 & 63u);
-    return r;
-}
-
 // One row of W coefficients of channel c at cell row (cy + y / 8), in-cell row y % 8.
 template <int W>
 __device__ __forceinline__ void load_row(const TransformArgs& a, uint32_t cx, uint32_t cy, int y, int c,
@@ -140,43 +146,144 @@ __device__ __forceinline__ void dequant_row(const int4 (&raw)[W / 4], const floa
     }
 }
 
-template <int W>
-__device__ __forceinline__ void cfl_apply(float (&d)[W], const float (&y)[W], float k0, float k1, int split,
-                                          bool any_straddle) {
-    if (!any_straddle) {  // wave-uniform: every row of this pass lies inside one 64-px tile column
-#pragma unroll
-        for (int x = 0; x < W; ++x) d[x] += k0 * y[x];
-    } else {
-#pragma unroll
-        for (int x = 0; x < W; ++x) d[x] += (x < split ? k0 : k1) * y[x];
-    }
+// Workgroup barrier that only drains LDS traffic: the HBM loads of the NEXT work item stay in
+// flight across it (a __syncthreads() would make the compiler wait for vmcnt(0) first).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// What a lane needs to know about one work item: where its rows / columns / LF block live.
+template <int RP, int CP>
+struct Geo {
+    uint32_t rcx[RP], rcy[RP];
+    float rmul[RP];
+    uint32_t ccx[CP], ccy[CP];
+    uint32_t lpos;  // cell of varblock `lane` (lanes < NBI): its LF samples
+};
+// Everything a lane reads from HBM for one work item (issued one item ahead).
+template <int RP, int W, int BW, int BH>
+struct Pre {
+    int4 raw[RP][W / 4];
+    float k0[RP], k1[RP];
+    int split[RP];
+    float lfv[BH][BW];
+};
+
 // ---------------------------------------------------------------------------------------------
-// One work item: up to NBI varblocks of shape W x H, all three channels.
-template <int W, int H, bool PREFETCH_ALL>
-__device__ __forceinline__ void run_item(const TransformArgs& a, const uint4* __restrict__ ent, int nvalid,
-                                         float* __restrict__ T, const float* __restrict__ lut, int lane) {
+// A persistent workgroup walks the work items wg, wg + n_wgs, ... of ONE shape class; wave 0 takes
+// channel Y, wave 1 X, wave 2 B.  The loop is software-pipelined by hand: at the top of iteration i
+// the entries of item i+2 and the coefficients of item i+1 are requested, so both HBM round trips of
+// an item hide behind a whole iteration of butterflies.
+template <int W, int H, bool PIPE>
+__device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* __restrict__ ent_class,
+                                          uint32_t count, uint32_t wg, uint32_t n_wgs, float* __restrict__ lds,
+                                          int wave, int lane) {
     using C = RCfg<W, H>;
     constexpr int BW = C::BW, BH = C::BH, NBI = C::NBI, RP = C::RP, CP = C::CP, S = C::S, BS = C::BS;
     constexpr int TYPE = type_of<W, H>();
+    float* lut = lds;
+    float* ydq = lds + kLutWords;
+    float* T = ydq + C::YDQ_WORDS + wave * C::WAVE_WORDS;
     float* llf = T + C::T_WORDS;
     const SecLarge sl{a.sec64, a.sec128, a.sec256};
+    const int c = wave == 0 ? 1 : (wave == 1 ? 0 : 2);  // wave 0 = Y: the other two wait for its rows
+    const float* lfp = c == 0 ? a.lf[0] : (c == 1 ? a.lf[1] : a.lf[2]);
+    const float bias = c == 0 ? a.quant_bias[0] : (c == 1 ? a.quant_bias[1] : a.quant_bias[2]);
+    const float qms = c == 0 ? a.qm_scale[0] : (c == 1 ? a.qm_scale[1] : a.qm_scale[2]);
+    const float* mat = a.dequant + (c == 0 ? a.deq_off_v[TYPE * 3] : (c == 1 ? a.deq_off_v[TYPE * 3 + 1] : a.deq_off_v[TYPE * 3 + 2]));
+    const float* kmap = c == 0 ? a.kx_map : a.kb_map;
+    const uint32_t n_items = (count + NBI - 1) / NBI;
 
-    // ---- V6 first half: LF -> lowest-frequency coefficients (transform_common.rs:40-66: copy the
-    //      BW x BH LF samples, forward DCT, divide by the scale_f products); one lane per
-    //      (varblock, channel), parked in LDS for the row lanes.
-    if (lane < NBI * 3) {
-        const int blk = lane / 3, c = lane - blk * 3;
-        if (blk < nvalid) {
-            const uint32_t pos = ent[blk].x;
-            const size_t cell = (size_t)(pos >> 16) * a.w8 + (pos & 0xffffu);
-            const float* lfp = c == 0 ? a.lf[0] : (c == 1 ? a.lf[1] : a.lf[2]);
+    // ---- lane constants: which row / column of which varblock of an item this lane owns
+    int ry[RP], rblk[RP], cxi[CP], cblk[CP];
+#pragma unroll
+    for (int p = 0; p < RP; ++p) { rblk[p] = (p * 64 + lane) / H; ry[p] = (p * 64 + lane) % H; }
+#pragma unroll
+    for (int q = 0; q < CP; ++q) { cblk[q] = (q * 64 + lane) / W; cxi[q] = (q * 64 + lane) % W; }
+    // the dequantisation matrix rows of this lane never change (one shape class per workgroup):
+    // kept in registers across items when they are short, re-read (L2) per item otherwise
+    constexpr bool HOIST_M = RP * W <= 32;
+    float4 mh[HOIST_M ? RP : 1][W / 4];
+    if constexpr (HOIST_M) {
+#pragma unroll
+        for (int p = 0; p < RP; ++p) load_mrow<W>(mat + ry[p] * W, mh[p]);
+    }
+
+    auto load_geo = [&](uint32_t item, Geo<RP, CP>& g) {
+        const uint4* ent = ent_class + (size_t)item * NBI;
+        const int nv = (int)min((uint32_t)NBI, count - item * NBI);
+#pragma unroll
+        for (int p = 0; p < RP; ++p) {
+            const uint4 e = ent[min(rblk[p], nv - 1)];  // lanes past the last varblock shadow it (never stored)
+            g.rcx[p] = e.x & 0xffffu;
+            g.rcy[p] = e.x >> 16;
+            g.rmul[p] = 65536.0f / (a.global_scale * (float)(int32_t)e.z);
+        }
+#pragma unroll
+        for (int q = 0; q < CP; ++q) {
+            const uint32_t pos = ent[min(cblk[q], nv - 1)].x;
+            g.ccx[q] = pos & 0xffffu;
+            g.ccy[q] = pos >> 16;
+        }
+        g.lpos = ent[min(lane, nv - 1)].x;
+    };
+    auto issue_loads = [&](const Geo<RP, CP>& g, Pre<RP, W, BW, BH>& pr) {
+#pragma unroll
+        for (int p = 0; p < RP; ++p) {
+            load_row<W>(a, g.rcx[p], g.rcy[p], ry[p], c, pr.raw[p]);
+            // chroma-from-luma factor of a row that may straddle a 64-px tile column (varblocks need
+            // not be aligned): samples x < split take k0, the rest k1 (mod.rs:589-600)
+            const uint32_t px0 = g.rcx[p] * 8, py = g.rcy[p] * 8 + (uint32_t)ry[p];
+            pr.k0[p] = kmap[(py >> 6) * a.w64 + (px0 >> 6)];
+            pr.k1[p] = kmap[(py >> 6) * a.w64 + ((px0 + W - 1) >> 6)];
+            pr.split[p] = 64 - (int)(px0 & 63u);
+        }
+        if (lane < NBI) {
+            const size_t cell = (size_t)(g.lpos >> 16) * a.w8 + (g.lpos & 0xffffu);
+#pragma unroll
+            for (int y = 0; y < BH; ++y)
+#pragma unroll
+                for (int x = 0; x < BW; ++x) pr.lfv[y][x] = lfp[cell + (size_t)y * a.w8 + x];
+        }
+    };
+
+    // Pipeline: at the top of iteration i the entries of item i+2 and the coefficients of item i+1
+    // are requested; item i's coefficients were requested one iteration ago.
+    // (PIPE = false: no run-ahead, the occupancy of the launch hides the two round trips instead;
+    //  one work item per workgroup then, and the registers of the look-ahead buffers are saved.)
+    Geo<RP, CP> g, gn, gnn;
+    Pre<RP, W, BW, BH> pr, prn;
+    TR_STAMP_DECL
+    TR_STAMP(false);
+    load_geo(wg, g);
+    TR_STAMP(true);   // 1: entries arrived
+    issue_loads(g, pr);
+    if constexpr (PIPE) {
+        if (wg + n_wgs < n_items) load_geo(wg + n_wgs, gn);
+    }
+    for (int i = threadIdx.x; i < kLutWords; i += 192) lut[i] = a.deq_lut[i];
+    TR_STAMP(true);   // 2: coefficients, LF, table arrived
+    lds_barrier();  // the table of quant_bias_numerator / k is in place
+    TR_STAMP(false);  // 3: barrier 0
+
+    for (uint32_t item = wg; item < n_items; item += n_wgs) {
+        const int nvalid = (int)min((uint32_t)NBI, count - item * NBI);
+        const bool has_next = item + n_wgs < n_items;        // workgroup-uniform
+        const bool has_next2 = item + 2 * n_wgs < n_items;
+        if constexpr (PIPE) {
+            if (has_next) issue_loads(gn, prn);
+            if (has_next2) load_geo(item + 2 * n_wgs, gnn);
+        }
+
+        // ---- V6 first half: LF -> lowest-frequency coefficients of this channel
+        //      (transform_common.rs:40-66: copy the BW x BH LF samples, forward DCT, divide by the
+        //      scale_f products); one lane per varblock, parked in LDS for the row lanes.
+        if (lane < NBI) {
             float v[BH][BW];
 #pragma unroll
             for (int y = 0; y < BH; ++y)
 #pragma unroll
-                for (int x = 0; x < BW; ++x) v[y][x] = lfp[cell + (size_t)y * a.w8 + x];
+                for (int x = 0; x < BW; ++x) v[y][x] = pr.lfv[y][x];
             if constexpr (BW * BH > 1) {
                 fdct2d_small<BW, BH>(v, sl);
                 constexpr int sy = 5 - __builtin_ctz(BH), sx = 5 - __builtin_ctz(BW);
@@ -191,265 +298,171 @@ __device__ __forceinline__ void run_item(const TransformArgs& a, const uint4* __
 #pragma unroll
                 for (int x = 0; x < BW; ++x) dst[y * BW + x] = v[y][x];
         }
-    }
-
-    // ---- geometry of this lane's rows (one per row pass) and columns (one per column pass)
-    uint32_t rcx[RP], rcy[RP];
-    int ry[RP], rblk[RP];
-    bool rvalid[RP];
-    float rmul[RP];
-    CflRow cfl[RP];
-    bool straddle = false;
-#pragma unroll
-    for (int p = 0; p < RP; ++p) {
-        const int R = p * 64 + lane;
-        rblk[p] = R / H;
-        ry[p] = R % H;
-        rvalid[p] = rblk[p] < nvalid;
-        const uint4 e = ent[rvalid[p] ? rblk[p] : 0];
-        rcx[p] = e.x & 0xffffu;
-        rcy[p] = e.x >> 16;
-        rmul[p] = 65536.0f / (a.global_scale * (float)(int32_t)e.z);
-        cfl[p] = cfl_row<W>(a, rcx[p] * 8, rcy[p] * 8 + (uint32_t)ry[p]);
-        straddle |= cfl[p].split < W;
-    }
-    const bool any_straddle = __builtin_amdgcn_ballot_w64(straddle) != 0;
-    uint32_t ccx[CP], ccy[CP];
-    int cxi[CP], cblk[CP];
-    bool cvalid[CP];
-#pragma unroll
-    for (int q = 0; q < CP; ++q) {
-        const int Cc = q * 64 + lane;
-        cblk[q] = Cc / W;
-        cxi[q] = Cc % W;
-        cvalid[q] = cblk[q] < nvalid;
-        const uint32_t pos = ent[cvalid[q] ? cblk[q] : 0].x;
-        ccx[q] = pos & 0xffffu;
-        ccy[q] = pos >> 16;
-    }
-    wave_lds_sync();
-
-    // ---- optional: every channel's coefficients in flight at once (few, long items: one wave
-    //      per SIMD, registers to spare, latency is what counts)
-    int4 raw_all[PREFETCH_ALL ? 3 : 1][PREFETCH_ALL ? RP : 1][W / 4];
-    if constexpr (PREFETCH_ALL) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int p = 0; p < RP; ++p)
-                if (rvalid[p]) load_row<W>(a, rcx[p], rcy[p], ry[p], c, raw_all[c][p]);
-    }
-
-    float ydq[RP][W];
-#pragma unroll
-    for (int ci = 0; ci < 3; ++ci) {
-        const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);  // Y first: X and B need its dequantised row
-        const float bias = a.quant_bias[c], qms = a.qm_scale[c];
-        const float* mat = a.dequant + a.deq_off_v[TYPE * 3 + c];
-        float* pixc = a.pix[c];
-        // ---- row passes: V4 dequant, V5 chroma-from-luma, LLF patch, 1-D IDCT of the row (dct.rs:93-96)
+        // ---- V4: dequantise every row of this lane
+        float d[RP][W];
+        bool straddle = false;
+        float k0[RP], k1[RP];
+        int split[RP];
 #pragma unroll
         for (int p = 0; p < RP; ++p) {
-            if (!rvalid[p]) continue;
+            if constexpr (HOIST_M) {
+                dequant_row<W>(pr.raw[p], mh[p], bias, a.quant_bias_numerator, lut, g.rmul[p] * qms, d[p]);
+            } else {
+                float4 m[W / 4];
+                load_mrow<W>(mat + ry[p] * W, m);
+                dequant_row<W>(pr.raw[p], m, bias, a.quant_bias_numerator, lut, g.rmul[p] * qms, d[p]);
+            }
+            k0[p] = pr.k0[p]; k1[p] = pr.k1[p]; split[p] = pr.split[p];
+            straddle |= split[p] < W;
+        }
+        const bool any_straddle = __builtin_amdgcn_ballot_w64(straddle) != 0;
+        TR_STAMP(false);  // 4: LLF + dequant
+
+        // ---- V5: the Y wave publishes its dequantised rows; X and B add k * Y (mod.rs:589-600)
+        if (c == 1) {
+#pragma unroll
+            for (int p = 0; p < RP; ++p)
+#pragma unroll
+                for (int x = 0; x < W; ++x) ydq[(p * W + x) * 64 + lane] = d[p][x];
+        }
+        lds_barrier();
+        TR_STAMP(false);  // 5: Y rows published + barrier 1
+        if (c != 1) {
+#pragma unroll
+            for (int p = 0; p < RP; ++p) {
+                float yv[W];
+#pragma unroll
+                for (int x = 0; x < W; ++x) yv[x] = ydq[(p * W + x) * 64 + lane];
+                if (!any_straddle) {  // wave-uniform: every row lies inside one 64-px tile column
+#pragma unroll
+                    for (int x = 0; x < W; ++x) d[p][x] += k0[p] * yv[x];
+                } else {
+#pragma unroll
+                    for (int x = 0; x < W; ++x) d[p][x] += (x < split[p] ? k0[p] : k1[p]) * yv[x];
+                }
+            }
+        }
+        // ---- LLF patch, 1-D IDCT of every row (dct.rs:93-96), rows into the wave's tile
+#pragma unroll
+        for (int p = 0; p < RP; ++p) {
+            if (rblk[p] >= nvalid) continue;
             const int y = ry[p];
-            float4 m[W / 4];
-            load_mrow<W>(mat + y * W, m);
-            float d[W];
-            if constexpr (PREFETCH_ALL) {
-                dequant_row<W>(raw_all[c][p], m, bias, a.quant_bias_numerator, lut, rmul[p] * qms, d);
-            } else {
-                int4 raw[W / 4];
-                load_row<W>(a, rcx[p], rcy[p], y, c, raw);
-                dequant_row<W>(raw, m, bias, a.quant_bias_numerator, lut, rmul[p] * qms, d);
-            }
-            if (ci == 0) {
-#pragma unroll
-                for (int x = 0; x < W; ++x) ydq[p][x] = d[x];
-            } else if (ci == 1) {
-                cfl_apply<W>(d, ydq[p], cfl[p].kx0, cfl[p].kx1, cfl[p].split, any_straddle);
-            } else {
-                cfl_apply<W>(d, ydq[p], cfl[p].kb0, cfl[p].kb1, cfl[p].split, any_straddle);
-            }
             if (y < BH) {
-                const float* src = llf + (rblk[p] * 3 + c) * (BW * BH) + y * BW;
+                const float* src = llf + rblk[p] * (BW * BH) + y * BW;
 #pragma unroll
-                for (int x = 0; x < BW; ++x) d[x] = src[x];
+                for (int x = 0; x < BW; ++x) d[p][x] = src[x];
             }
-            idct<W>(d, sl);
+            idct<W>(d[p], sl);
             float* row = T + rblk[p] * BS + y * S;
 #pragma unroll
-            for (int x = 0; x < W; ++x) row[x] = d[x];
+            for (int x = 0; x < W; ++x) row[x] = d[p][x];
         }
         wave_lds_sync();
+        TR_STAMP(false);  // 6: CfL + row IDCT + tile writes
         // ---- column passes: 1-D IDCT of the column (dct.rs:109-130), samples straight to HBM
 #pragma unroll
         for (int q = 0; q < CP; ++q) {
-            if (!cvalid[q]) continue;
+            if (cblk[q] >= nvalid) continue;
             const float* col = T + cblk[q] * BS + cxi[q];
             float v[H];
 #pragma unroll
             for (int y = 0; y < H; ++y) v[y] = col[y * S];
             idct<H>(v, sl);
-            float* dst = pixc + (size_t)(ccy[q] * 8) * a.pstride + ccx[q] * 8 + cxi[q];
+            // cell-tiled output: this lane's column runs down H / 8 cells, 8 words apart inside each
+            float* dst = a.pix + ((((size_t)g.ccy[q] * a.w8 + g.ccx[q] + (uint32_t)(cxi[q] >> 3)) * 3 + (uint32_t)c) << 6) + (cxi[q] & 7);
+            const size_t cell_row = (size_t)a.w8 * 192;
 #pragma unroll
-            for (int y = 0; y < H; ++y) dst[(size_t)y * a.pstride] = v[y];
+            for (int y = 0; y < H; ++y) dst[(size_t)(y >> 3) * cell_row + ((y & 7) << 3)] = v[y];
         }
-        wave_lds_sync();
+        TR_STAMP(false);  // 7: column IDCT + stores issued
+        TR_STAMP(true);   // 8: stores drained
+        TR_STAMP_FLUSH(H >= 64 || W >= 64 ? 3 : (H >= 32 || W >= 32 ? 2 : (H >= 16 || W >= 16 ? 1 : 0)));
+#ifdef JXL_TR_PROFILE
+        tr_n = 0;
+        TR_STAMP(false);
+        TR_STAMP(false); TR_STAMP(false); TR_STAMP(false);
+#endif
+        if (has_next) {
+            lds_barrier();  // X and B are done with this item's Y rows before the next ones land
+            if constexpr (PIPE) {
+                g = gn;
+                gn = gnn;
+                pr = prn;
+            } else {
+                load_geo(item + n_wgs, g);
+                issue_loads(g, pr);
+            }
+        }
     }
 }
 
-// Work items of one launch: classes in launch order, `begin[k]` = first item of class k.
-struct ItemTable {
+// Persistent workgroups of one launch: class k owns workgroups [wg_begin[k], wg_begin[k + 1]).
+struct ClassTable {
     uint32_t n_classes;
-    uint32_t begin[6];       // n_classes + 1 entries used
+    uint32_t wg_begin[6];    // n_classes + 1 entries used
     uint32_t cls[5];
     uint32_t first_entry[5]; // into `entries`
     uint32_t count[5];       // varblocks of the class
 };
 
-// FAMILY 0: 8x8 and the 16-px shapes (the bulk: thousands of short items, occupancy hides latency).
-// FAMILY 1: the 32-px shapes (about a thousand long items per 4K frame: roughly one wave per SIMD,
-//           so every channel's loads are issued up front instead).
+// One launch per register class, so that the long-row shapes do not set the occupancy of the
+// short ones: FAMILY 0 = 8x8 (<= 64 VGPRs: eight waves per SIMD keep ~64 KiB of coefficient
+// loads in flight per CU, what 8 TB/s x ~2 us of loaded latency asks for), 1 = the 16-px shapes,
+// 2 = the 32-px shapes, 3 = the 64-px shapes (whole rows of 64 in registers).
 template <int FAMILY>
-__global__ __launch_bounds__(256) void transform_rows_kernel(TransformArgs a, ItemTable it,
-                                                             const uint4* __restrict__ entries) {
+struct FamCfg;
+template <> struct FamCfg<0> { static constexpr int WAVES = 8; static constexpr int WORDS = RCfg<8, 8>::WG_WORDS; };
+template <> struct FamCfg<1> {
+    static constexpr int WAVES = 4;
+    static constexpr int WORDS = cmax(RCfg<16, 16>::WG_WORDS, cmax(RCfg<8, 16>::WG_WORDS, RCfg<16, 8>::WG_WORDS));
+};
+template <> struct FamCfg<2> {
+    static constexpr int WAVES = 2;
+    static constexpr int WORDS = cmax(cmax(cmax(RCfg<32, 32>::WG_WORDS, RCfg<8, 32>::WG_WORDS),
+                                           cmax(RCfg<32, 8>::WG_WORDS, RCfg<16, 32>::WG_WORDS)), RCfg<32, 16>::WG_WORDS);
+};
+template <> struct FamCfg<3> {
+    static constexpr int WAVES = 1;
+    static constexpr int WORDS = cmax(cmax(RCfg<64, 64>::WG_WORDS, RCfg<32, 64>::WG_WORDS), RCfg<64, 32>::WG_WORDS);
+};
+
+template <int FAMILY, bool PIPE>
+__global__ __launch_bounds__(192, FamCfg<FAMILY>::WAVES) void transform_items_kernel(TransformArgs a, ClassTable ct,
+                                                                                     const uint4* __restrict__ entries) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int WAVE_WORDS = FAMILY == 0 ? kWaveWordsA : kWaveWordsB;
-    float* lut = lds;
-    lut[threadIdx.x] = a.deq_lut[threadIdx.x];
-    __syncthreads();  // the only workgroup barrier: from here on the four waves are independent
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const uint32_t item = blockIdx.x * 4 + wave;
-    if (item >= it.begin[it.n_classes]) return;
     uint32_t k = 0;
-    while (item >= it.begin[k + 1]) ++k;
-    float* T = lds + kLutWords + wave * WAVE_WORDS;
-    const uint32_t idx = item - it.begin[k];
-#define RUN(W, H, PF)                                                                      \
-    {                                                                                      \
-        constexpr int NBI = RCfg<W, H>::NBI;                                               \
-        const uint32_t first = idx * NBI;                                                  \
-        run_item<W, H, PF>(a, entries + it.first_entry[k] + first,                         \
-                           (int)min((uint32_t)NBI, it.count[k] - first), T, lut, lane);    \
-    }
+    while (blockIdx.x >= ct.wg_begin[k + 1]) ++k;
+    const uint32_t wg = blockIdx.x - ct.wg_begin[k], n_wgs = ct.wg_begin[k + 1] - ct.wg_begin[k];
+#define RUN(W, H) run_class<W, H, PIPE>(a, entries + ct.first_entry[k], ct.count[k], wg, n_wgs, lds, wave, lane);
     if constexpr (FAMILY == 0) {
-        switch (it.cls[k]) {
-            case CLS_DCT8: RUN(8, 8, false) break;
-            case CLS_16x16: RUN(16, 16, false) break;
-            case CLS_8x16: RUN(8, 16, false) break;
-            case CLS_16x8: RUN(16, 8, false) break;
+        RUN(8, 8)
+    } else if constexpr (FAMILY == 1) {
+        switch (ct.cls[k]) {
+            case CLS_16x16: RUN(16, 16) break;
+            case CLS_8x16: RUN(8, 16) break;
+            case CLS_16x8: RUN(16, 8) break;
+            default: break;
+        }
+    } else if constexpr (FAMILY == 2) {
+        switch (ct.cls[k]) {
+            case CLS_32x32: RUN(32, 32) break;
+            case CLS_8x32: RUN(8, 32) break;
+            case CLS_32x8: RUN(32, 8) break;
+            case CLS_16x32: RUN(16, 32) break;
+            case CLS_32x16: RUN(32, 16) break;
             default: break;
         }
     } else {
-        switch (it.cls[k]) {
-            case CLS_32x32: RUN(32, 32, true) break;
-            case CLS_8x32: RUN(8, 32, true) break;
-            case CLS_32x8: RUN(32, 8, true) break;
-            case CLS_16x32: RUN(16, 32, true) break;
-            case CLS_32x16: RUN(32, 16, true) break;
+        switch (ct.cls[k]) {
+            case CLS_64x64: RUN(64, 64) break;
+            case CLS_32x64: RUN(32, 64) break;
+            case CLS_64x32: RUN(64, 32) break;
             default: break;
         }
     }
 #undef RUN
-}
-
-// ---------------------------------------------------------------------------------------------
-// 64-px shapes (Dct64, Dct64x32, Dct32x64): one wave per (varblock, channel), row lane / column
-// lane as above with the whole row (up to 64 coefficients) in registers.  X and B recompute the
-// dequantised Y row for chroma-from-luma instead of sharing it, which makes the three channels of
-// a block independent waves — there are only a few hundred such blocks in a 4K frame, latency per
-// wave is what matters.  The LF -> LLF forward DCT (up to 8x8) runs one row / one column per lane
-// (dct_2d general case: rows, then columns).
-template <int W, int H>
-__global__ __launch_bounds__(64) void transform_kernel64(TransformArgs a, const uint4* __restrict__ entries) {
-    constexpr int S = W + 1, BW = W / 8, BH = H / 8, LS = BW + 1;
-    constexpr int TYPE = type_of<W, H>();
-    __shared__ float T[H * S + BH * LS + kLutWords];
-    float* llf = T + H * S;
-    float* lut = llf + BH * LS;
-    const SecLarge sl{a.sec64, a.sec128, a.sec256};
-    const int lane = threadIdx.x;
-    const int c = blockIdx.y;
-    const uint4 e = entries[blockIdx.x];
-    const uint32_t cx = e.x & 0xffffu, cy = e.x >> 16;
-    const size_t cell = (size_t)cy * a.w8 + cx;
-    const float* lfp = c == 0 ? a.lf[0] : (c == 1 ? a.lf[1] : a.lf[2]);
-    float* pixc = c == 0 ? a.pix[0] : (c == 1 ? a.pix[1] : a.pix[2]);
-
-    // coefficient rows in flight first (lane = row)
-    int4 raw[W / 4], rawy[W / 4];
-    if (lane < H) {
-        load_row<W>(a, cx, cy, lane, c, raw);
-        if (c != 1) load_row<W>(a, cx, cy, lane, 1, rawy);
-    }
-#pragma unroll
-    for (int i = 0; i < kLutWords / 64; ++i) lut[i * 64 + lane] = a.deq_lut[i * 64 + lane];
-    for (int i = lane; i < BW * BH; i += 64) {
-        const int y = i / BW, x = i % BW;
-        llf[y * LS + x] = lfp[cell + (size_t)y * a.w8 + x];
-    }
-    wave_lds_sync();
-    if (lane < BH) {
-        float v[BW];
-#pragma unroll
-        for (int x = 0; x < BW; ++x) v[x] = llf[lane * LS + x];
-        fdct<BW>(v, sl);
-#pragma unroll
-        for (int x = 0; x < BW; ++x) llf[lane * LS + x] = v[x];
-    }
-    wave_lds_sync();
-    if (lane < BW) {
-        float v[BH];
-#pragma unroll
-        for (int y = 0; y < BH; ++y) v[y] = llf[y * LS + lane];
-        fdct<BH>(v, sl);
-        constexpr int sy = 5 - __builtin_ctz(BH), sx = 5 - __builtin_ctz(BW);
-#pragma unroll
-        for (int y = 0; y < BH; ++y) llf[y * LS + lane] = v[y] / (kScaleF[y << sy] * kScaleF[lane << sx]);
-    }
-    wave_lds_sync();
-
-    const float mul_base = 65536.0f / (a.global_scale * (float)(int32_t)e.z);
-    if (lane < H) {
-        const int y = lane;
-        float d[W];
-        {
-            float4 m[W / 4];
-            load_mrow<W>(a.dequant + a.deq_off_v[TYPE * 3 + c] + y * W, m);
-            const float bias = c == 0 ? a.quant_bias[0] : (c == 1 ? a.quant_bias[1] : a.quant_bias[2]);
-            const float qms = c == 0 ? a.qm_scale[0] : (c == 1 ? a.qm_scale[1] : a.qm_scale[2]);
-            dequant_row<W>(raw, m, bias, a.quant_bias_numerator, lut, mul_base * qms, d);
-        }
-        if (c != 1) {
-            float4 m[W / 4];
-            load_mrow<W>(a.dequant + a.deq_off_v[TYPE * 3 + 1] + y * W, m);
-            float yd[W];
-            dequant_row<W>(rawy, m, a.quant_bias[1], a.quant_bias_numerator, lut, mul_base * a.qm_scale[1], yd);
-            const CflRow k = cfl_row<W>(a, cx * 8, cy * 8 + (uint32_t)y);
-            const bool any_straddle = __builtin_amdgcn_ballot_w64(k.split < W) != 0;
-            cfl_apply<W>(d, yd, c == 0 ? k.kx0 : k.kb0, c == 0 ? k.kx1 : k.kb1, k.split, any_straddle);
-        }
-        if (y < BH) {
-#pragma unroll
-            for (int x = 0; x < BW; ++x) d[x] = llf[y * LS + x];
-        }
-        idct<W>(d, sl);
-        float* row = T + y * S;
-#pragma unroll
-        for (int x = 0; x < W; ++x) row[x] = d[x];
-    }
-    wave_lds_sync();
-    if (lane < W) {
-        const float* col = T + lane;
-        float v[H];
-#pragma unroll
-        for (int y = 0; y < H; ++y) v[y] = col[y * S];
-        idct<H>(v, sl);
-        float* dst = pixc + (size_t)(cy * 8) * a.pstride + cx * 8 + lane;
-#pragma unroll
-        for (int y = 0; y < H; ++y) dst[(size_t)y * a.pstride] = v[y];
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -722,26 +735,20 @@ __global__ __launch_bounds__(64) void transform_special_kernel(TransformArgs a, 
         default: break;
     }
     if (valid) {
-        float* pixc = c == 0 ? a.pix[0] : (c == 1 ? a.pix[1] : a.pix[2]);
-        float* dst = pixc + (size_t)(cy * 8) * a.pstride + cx * 8;
+        float* dst = a.pix + ((cell * 3 + (uint32_t)c) << 6);  // one contiguous 256-byte run of the tiled output
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
-            *reinterpret_cast<float4*>(dst + (size_t)y * a.pstride) = make_float4(b[y][0], b[y][1], b[y][2], b[y][3]);
-            *reinterpret_cast<float4*>(dst + (size_t)y * a.pstride + 4) = make_float4(b[y][4], b[y][5], b[y][6], b[y][7]);
+            *reinterpret_cast<float4*>(dst + y * 8) = make_float4(b[y][0], b[y][1], b[y][2], b[y][3]);
+            *reinterpret_cast<float4*>(dst + y * 8 + 4) = make_float4(b[y][4], b[y][5], b[y][6], b[y][7]);
         }
     }
-}
-
-template <int W, int H>
-void launch_tk64(hipStream_t s, const TransformArgs& a, const uint4* entries, uint32_t count) {
-    transform_kernel64<W, H><<<dim3(count, 3), 64, 0, s>>>(a, entries);
 }
 
 }  // namespace
 
 void launch_big_blocks(hipStream_t s, const TransformArgs& a, const uint4* entries, uint32_t count);
 
-// Varblocks per work item of the row-lane kernels (host side of RCfg<W, H>::NBI)
+// Varblocks per work item (host side of RCfg<W, H>::NBI)
 int transform_items_nbi(int cls) {
     switch (cls) {
         case CLS_DCT8: return RCfg<8, 8>::NBI;
@@ -753,38 +760,84 @@ int transform_items_nbi(int cls) {
         case CLS_32x8: return RCfg<32, 8>::NBI;
         case CLS_16x32: return RCfg<16, 32>::NBI;
         case CLS_32x16: return RCfg<32, 16>::NBI;
+        case CLS_64x64: return RCfg<64, 64>::NBI;
+        case CLS_32x64: return RCfg<32, 64>::NBI;
+        case CLS_64x32: return RCfg<64, 32>::NBI;
         default: return 1;
     }
 }
 
-// One launch per family: `classes` in launch order (long items first).
-hipError_t launch_transform_rows(hipStream_t s, int family, const TransformArgs& a, const uint4* entries,
-                                 const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT]) {
-    static const int kFamA[] = {CLS_16x16, CLS_8x16, CLS_16x8, CLS_DCT8};
-    static const int kFamB[] = {CLS_32x32, CLS_16x32, CLS_32x16, CLS_8x32, CLS_32x8};
-    const int* classes = family == 0 ? kFamA : kFamB;
-    const int n = family == 0 ? 4 : 5;
-    ItemTable it;
-    memset(&it, 0, sizeof(it));
-    uint32_t items = 0;
+// One launch per family.  Each shape class gets a share of the family's persistent workgroups
+// proportional to its work (pixels, weighted by the depth of its butterflies), never more than it
+// has items; classes with long items come first so they start first.
+hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs& a, const uint4* entries,
+                                  const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT],
+                                  uint32_t num_cus, int wgs_per_cu) {
+    static const int kFam0[] = {CLS_DCT8};
+    static const int kFam1[] = {CLS_16x16, CLS_8x16, CLS_16x8};
+    static const int kFam2[] = {CLS_32x32, CLS_16x32, CLS_32x16, CLS_8x32, CLS_32x8};
+    static const int kFam3[] = {CLS_64x64, CLS_32x64, CLS_64x32};
+    static const double kCost[CLS_COUNT] = {/*8x8*/ 1.0, 0, /*16x16*/ 1.25, /*8x16*/ 1.12, /*16x8*/ 1.12, /*32x32*/ 1.5,
+                                            /*8x32*/ 1.25, /*32x8*/ 1.25, /*16x32*/ 1.38, /*32x16*/ 1.38,
+                                            /*64x64*/ 1.75, /*32x64*/ 1.62, /*64x32*/ 1.62, 0};
+    static const int kArea[CLS_COUNT] = {64, 0, 256, 128, 128, 1024, 256, 256, 512, 512, 4096, 2048, 2048, 0};
+    static const int* const kFam[4] = {kFam0, kFam1, kFam2, kFam3};
+    static const int kFamN[4] = {1, 3, 5, 3};
+    if (family < 0 || family > 3) return hipErrorInvalidValue;
+    const int* classes = kFam[family];
+    const int n = kFamN[family];
+    // wgs_per_cu = resident workgroups per CU the kernel's registers / LDS allow (3 waves each);
+    // 0 = one workgroup per work item (no persistence, no run-ahead)
+    const uint32_t budget = wgs_per_cu > 0 ? std::max(1u, num_cus) * (uint32_t)wgs_per_cu : 0xffffffu;
+    double work[5] = {}, total = 0;
+    uint32_t items[5] = {};
     for (int i = 0; i < n; ++i) {
         const int cls = classes[i];
-        if (!list_count[cls]) continue;
-        const uint32_t k = it.n_classes++;
-        it.begin[k] = items;
-        it.cls[k] = (uint32_t)cls;
-        it.first_entry[k] = class_first[cls];
-        it.count[k] = list_count[cls];
-        items += ceil_div(list_count[cls], (uint32_t)transform_items_nbi(cls));
+        items[i] = ceil_div(list_count[cls], (uint32_t)transform_items_nbi(cls));
+        work[i] = (double)list_count[cls] * kArea[cls] * kCost[cls];
+        total += work[i];
     }
-    it.begin[it.n_classes] = items;
-    if (!items) return hipSuccess;
-    const uint32_t wgs = ceil_div(items, 4);
-    if (family == 0) {
-        transform_rows_kernel<0><<<wgs, 256, (kLutWords + 4 * kWaveWordsA) * sizeof(float), s>>>(a, it, entries);
-    } else {
-        transform_rows_kernel<1><<<wgs, 256, (kLutWords + 4 * kWaveWordsB) * sizeof(float), s>>>(a, it, entries);
+    if (total == 0) return hipSuccess;
+    ClassTable ct;
+    memset(&ct, 0, sizeof(ct));
+    uint32_t wgs = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!items[i]) continue;
+        const int cls = classes[i];
+        uint32_t share = (uint32_t)(budget * (work[i] / total) + 0.5);
+        share = std::min(items[i], std::max(1u, share));
+        const uint32_t k = ct.n_classes++;
+        ct.wg_begin[k] = wgs;
+        ct.cls[k] = (uint32_t)cls;
+        ct.first_entry[k] = class_first[cls];
+        ct.count[k] = list_count[cls];
+        wgs += share;
     }
+    ct.wg_begin[ct.n_classes] = wgs;
+    for (uint32_t k = ct.n_classes + 1; k < 6; ++k) ct.wg_begin[k] = 0xffffffffu;
+    const bool pipe = wgs_per_cu > 0;
+#define LAUNCH(F)                                                                                              \
+    do {                                                                                                       \
+        constexpr size_t bytes = FamCfg<F>::WORDS * sizeof(float);                                             \
+        if (bytes > 65536) { /* > 64 KiB of dynamic LDS needs the attribute; idempotent and thread-safe */     \
+            static std::once_flag once;                                                                        \
+            std::call_once(once, [] {                                                                          \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&transform_items_kernel<F, true>),     \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);             \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&transform_items_kernel<F, false>),    \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);             \
+            });                                                                                                \
+        }                                                                                                      \
+        if (pipe) transform_items_kernel<F, true><<<wgs, 192, bytes, s>>>(a, ct, entries);                     \
+        else transform_items_kernel<F, false><<<wgs, 192, bytes, s>>>(a, ct, entries);                         \
+    } while (0)
+    switch (family) {
+        case 0: LAUNCH(0); break;
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        default: LAUNCH(3); break;
+    }
+#undef LAUNCH
     return hipGetLastError();
 }
 
@@ -795,9 +848,6 @@ void launch_transform_class(hipStream_t s, int cls, const TransformArgs& a, cons
         case CLS_SPECIAL8:
             transform_special_kernel<<<ceil_div(count, kSpecialPerWave), 64, 0, s>>>(a, entries, count);
             break;
-        case CLS_64x64: launch_tk64<64, 64>(s, a, entries, count); break;
-        case CLS_32x64: launch_tk64<32, 64>(s, a, entries, count); break;
-        case CLS_64x32: launch_tk64<64, 32>(s, a, entries, count); break;
         case CLS_BIG: launch_big_blocks(s, a, entries, count); break;
         default: break;
     }

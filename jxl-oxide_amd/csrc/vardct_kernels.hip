@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void nometa_kernel(TransformArgs a, const uint
         if (px >= a.w8 * 8) break;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            a.pix[c][(size_t)py * a.pstride + px] = a.lf[c][(size_t)(py / 8) * a.w8 + px / 8];
+            a.pix[coeff_tiled_index(px, py, c, a.w8)] = a.lf[c][(size_t)(py / 8) * a.w8 + px / 8];
     }
 }
 
@@ -92,4 +92,21 @@ void launch_nometa_groups(hipStream_t s, const TransformArgs& a, const uint32_t*
                           uint32_t count, uint32_t group_dim, uint32_t groups_per_row) {
     if (!count) return;
     nometa_kernel<<<dim3(group_dim, count), 256, 0, s>>>(a, groups, group_dim, groups_per_row);
+}
+
+// ---------------------------------------------------------------- tiled -> row-major planes
+// Only for renders that stop after the transform (tests, `stages` without a post stage) and for
+// the one-kernel-per-stage fallback: the fused post kernels read the tiled layout directly.
+__global__ __launch_bounds__(256) void untile_kernel(const float* __restrict__ tiled, uint32_t w8, float* o0, float* o1,
+                                                     float* o2, uint32_t out_stride, uint32_t width, uint32_t height) {
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= width) return;
+    float* const out[3] = {o0, o1, o2};
+#pragma unroll
+    for (uint32_t c = 0; c < 3; ++c) out[c][(size_t)y * out_stride + x] = tiled[coeff_tiled_index(x, y, c, w8)];
+}
+
+void launch_untile(hipStream_t s, const float* tiled, uint32_t w8, float* const out[3], uint32_t out_stride,
+                   uint32_t width, uint32_t height) {
+    untile_kernel<<<dim3(ceil_div(width, 256), height), 256, 0, s>>>(tiled, w8, out[0], out[1], out[2], out_stride, width, height);
 }
