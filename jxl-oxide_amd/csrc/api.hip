@@ -448,6 +448,8 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     if (d->num_lf_groups != f->num_lf_groups || !d->lf_groups)
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "num_lf_groups does not match the frame size");
     if (d->coeff_stride < f->wr) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "coeff_stride < width_rounded");
+    if ((uint64_t)f->wr * f->hr * 3 >= (1ull << 30))  // kernels address the tiled planes with 32-bit word offsets
+        return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "frame larger than 357 megapixels");
 
     const size_t ncell = (size_t)f->w8 * f->h8, ntile = (size_t)f->w64 * f->h64;
     const size_t npix = (size_t)f->wr * f->hr;

@@ -58,16 +58,26 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // dequant_hf_varblock_grouped inner loop (vardct/mod.rs:527-537) with `qbn / q` from a table of
 // quant_bias_numerator / k (k = |q| < 256, built on the host with the same correctly rounded f32
-// division): qbn / q == sign(q) * (qbn / |q|) exactly, so only |q| >= 256 still divides.
-__device__ __forceinline__ float dequant_lut(int32_t qn, float quant_bias, float qbn, const float* qlut, float m,
-                                             float mul) {
+// division): qbn / q == sign(q) * (qbn / |q|) exactly.  Branch-free; the caller tracks the largest
+// |q| of its rows in `amax` and redoes a row with dequant_div when it reaches 256 (never, in
+// practice: a d1 stream keeps |q| in the tens).
+__device__ __forceinline__ float dequant_lut(int32_t qn, float quant_bias, const float* qlut, float m, float mul,
+                                             uint32_t& amax) {
     float q = (float)qn;
-    const uint32_t aq = qn < 0 ? 0u - (uint32_t)qn : (uint32_t)qn;
-    float t = qlut[min(aq, 255u)];
-    if (__builtin_expect(aq > 255u, 0)) t = qbn / fabsf(q);
-    const float big = q - (qn < 0 ? -t : t);
+    const uint32_t aq = (uint32_t)max(qn, -qn);
+    amax = max(amax, aq);
+    const float t = qlut[min(aq, 255u)];
+    const float big = q - __builtin_copysignf(t, q);
     const float small = q * quant_bias;
     q = aq <= 1u ? small : big;
+    q *= m;
+    q *= mul;
+    return q;
+}
+__device__ __forceinline__ float dequant_div(int32_t qn, float quant_bias, float qbn, float m, float mul) {
+    float q = (float)qn;
+    if (fabsf(q) <= 1.0f) q *= quant_bias;
+    else q -= qbn / q;
     q *= m;
     q *= mul;
     return q;
@@ -110,8 +120,9 @@ struct RCfg {
     static constexpr int T_WORDS = NBI * BS;
     static constexpr int LLF_WORDS = NBI * BW * BH;              // one channel
     static constexpr int WAVE_WORDS = T_WORDS + LLF_WORDS;       // per wave (= per channel)
-    static constexpr int YDQ_WORDS = RP * W * 64;                // dequantised Y rows, [pass][x][lane]
-    static constexpr int WG_WORDS = 256 + YDQ_WORDS + 3 * WAVE_WORDS;
+    // The dequantised Y rows, [pass][x][lane] = RP * W * 64 = NBI * H * W words, are handed to the X and
+    // B waves INSIDE those waves' own (still unused) tiles: no extra LDS.
+    static constexpr int WG_WORDS = 256 + 3 * WAVE_WORDS;
 };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -120,11 +131,12 @@ constexpr int kLutWords = 256;
 template <int W>
 __device__ __forceinline__ void load_row(const TransformArgs& a, uint32_t cx, uint32_t cy, int y, int c,
                                          int4 (&raw)[W / 4]) {
-    const int32_t* src = a.coeff + (((((size_t)(cy + (uint32_t)(y >> 3)) * a.w8 + cx) * 3 + (uint32_t)c) << 6) + ((y & 7) << 3));
+    // 32-bit lane offset from the uniform base (frames are checked at upload to fit)
+    const uint32_t off = ((((cy + (uint32_t)(y >> 3)) * a.w8 + cx) * 3 + (uint32_t)c) << 6) + (uint32_t)((y & 7) << 3);
 #pragma unroll
     for (int i = 0; i < W / 8; ++i) {
-        raw[2 * i] = *reinterpret_cast<const int4*>(src + i * 192);
-        raw[2 * i + 1] = *reinterpret_cast<const int4*>(src + i * 192 + 4);
+        raw[2 * i] = *reinterpret_cast<const int4*>(a.coeff + off + i * 192);
+        raw[2 * i + 1] = *reinterpret_cast<const int4*>(a.coeff + off + i * 192 + 4);
     }
 }
 
@@ -135,14 +147,31 @@ __device__ __forceinline__ void load_mrow(const float* mrow, float4 (&m)[W / 4])
 }
 
 template <int W>
-__device__ __forceinline__ void dequant_row(const int4 (&raw)[W / 4], const float4 (&m)[W / 4], float bias, float qbn,
-                                            const float* lut, float mul, float (&d)[W]) {
+__device__ __forceinline__ void dequant_row(const int4 (&raw)[W / 4], const float4 (&m)[W / 4], float bias,
+                                            const float* lut, float mul, float (&d)[W], uint32_t& amax) {
 #pragma unroll
     for (int i = 0; i < W / 4; ++i) {
-        d[4 * i + 0] = dequant_lut(raw[i].x, bias, qbn, lut, m[i].x, mul);
-        d[4 * i + 1] = dequant_lut(raw[i].y, bias, qbn, lut, m[i].y, mul);
-        d[4 * i + 2] = dequant_lut(raw[i].z, bias, qbn, lut, m[i].z, mul);
-        d[4 * i + 3] = dequant_lut(raw[i].w, bias, qbn, lut, m[i].w, mul);
+        d[4 * i + 0] = dequant_lut(raw[i].x, bias, lut, m[i].x, mul, amax);
+        d[4 * i + 1] = dequant_lut(raw[i].y, bias, lut, m[i].y, mul, amax);
+        d[4 * i + 2] = dequant_lut(raw[i].z, bias, lut, m[i].z, mul, amax);
+        d[4 * i + 3] = dequant_lut(raw[i].w, bias, lut, m[i].w, mul, amax);
+    }
+}
+
+// Cold path: the row again, from memory, with the division (some |q| >= 256).
+template <int W>
+__device__ __forceinline__ void dequant_row_div(const TransformArgs& a, uint32_t cx, uint32_t cy, int y, int c,
+                                                const float* mrow, float bias, float mul, float (&d)[W]) {
+    int4 raw[W / 4];
+    float4 m[W / 4];
+    load_row<W>(a, cx, cy, y, c, raw);
+    load_mrow<W>(mrow, m);
+#pragma unroll
+    for (int i = 0; i < W / 4; ++i) {
+        d[4 * i + 0] = dequant_div(raw[i].x, bias, a.quant_bias_numerator, m[i].x, mul);
+        d[4 * i + 1] = dequant_div(raw[i].y, bias, a.quant_bias_numerator, m[i].y, mul);
+        d[4 * i + 2] = dequant_div(raw[i].z, bias, a.quant_bias_numerator, m[i].z, mul);
+        d[4 * i + 3] = dequant_div(raw[i].w, bias, a.quant_bias_numerator, m[i].w, mul);
     }
 }
 
@@ -182,9 +211,10 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
     constexpr int BW = C::BW, BH = C::BH, NBI = C::NBI, RP = C::RP, CP = C::CP, S = C::S, BS = C::BS;
     constexpr int TYPE = type_of<W, H>();
     float* lut = lds;
-    float* ydq = lds + kLutWords;
-    float* T = ydq + C::YDQ_WORDS + wave * C::WAVE_WORDS;
+    float* T = lds + kLutWords + wave * C::WAVE_WORDS;
     float* llf = T + C::T_WORDS;
+    float* Tx = lds + kLutWords + 1 * C::WAVE_WORDS;   // tiles of the X and B waves: the Y wave parks its
+    float* Tb = lds + kLutWords + 2 * C::WAVE_WORDS;   // dequantised rows there for chroma-from-luma
     const SecLarge sl{a.sec64, a.sec128, a.sec256};
     const int c = wave == 0 ? 1 : (wave == 1 ? 0 : 2);  // wave 0 = Y: the other two wait for its rows
     const float* lfp = c == 0 ? a.lf[0] : (c == 1 ? a.lf[1] : a.lf[2]);
@@ -202,7 +232,10 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
     for (int q = 0; q < CP; ++q) { cblk[q] = (q * 64 + lane) / W; cxi[q] = (q * 64 + lane) % W; }
     // the dequantisation matrix rows of this lane never change (one shape class per workgroup):
     // kept in registers across items when they are short, re-read (L2) per item otherwise
-    constexpr bool HOIST_M = RP * W <= 32;
+    // Long rows (W >= 32): the matrix row is consumed 8 values at a time so the compiler is free to
+    // keep as few or as many of those (L2-hit) loads in flight as the register budget allows.
+    constexpr bool STREAM = W >= 32;
+    constexpr bool HOIST_M = PIPE && !STREAM && RP * W <= 32;
     float4 mh[HOIST_M ? RP : 1][W / 4];
     if constexpr (HOIST_M) {
 #pragma unroll
@@ -305,12 +338,32 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
         int split[RP];
 #pragma unroll
         for (int p = 0; p < RP; ++p) {
-            if constexpr (HOIST_M) {
-                dequant_row<W>(pr.raw[p], mh[p], bias, a.quant_bias_numerator, lut, g.rmul[p] * qms, d[p]);
+            const float* mrow = mat + ry[p] * W;
+            const float mul = g.rmul[p] * qms;
+            uint32_t amax = 0;
+            if constexpr (STREAM) {
+#pragma unroll
+                for (int i = 0; i < W / 8; ++i) {
+                    const float4 m0 = *reinterpret_cast<const float4*>(mrow + 8 * i), m1 = *reinterpret_cast<const float4*>(mrow + 8 * i + 4);
+                    const int4 r0 = pr.raw[p][2 * i], r1 = pr.raw[p][2 * i + 1];
+                    d[p][8 * i + 0] = dequant_lut(r0.x, bias, lut, m0.x, mul, amax);
+                    d[p][8 * i + 1] = dequant_lut(r0.y, bias, lut, m0.y, mul, amax);
+                    d[p][8 * i + 2] = dequant_lut(r0.z, bias, lut, m0.z, mul, amax);
+                    d[p][8 * i + 3] = dequant_lut(r0.w, bias, lut, m0.w, mul, amax);
+                    d[p][8 * i + 4] = dequant_lut(r1.x, bias, lut, m1.x, mul, amax);
+                    d[p][8 * i + 5] = dequant_lut(r1.y, bias, lut, m1.y, mul, amax);
+                    d[p][8 * i + 6] = dequant_lut(r1.z, bias, lut, m1.z, mul, amax);
+                    d[p][8 * i + 7] = dequant_lut(r1.w, bias, lut, m1.w, mul, amax);
+                }
+            } else if constexpr (HOIST_M) {
+                dequant_row<W>(pr.raw[p], mh[p], bias, lut, mul, d[p], amax);
             } else {
                 float4 m[W / 4];
-                load_mrow<W>(mat + ry[p] * W, m);
-                dequant_row<W>(pr.raw[p], m, bias, a.quant_bias_numerator, lut, g.rmul[p] * qms, d[p]);
+                load_mrow<W>(mrow, m);
+                dequant_row<W>(pr.raw[p], m, bias, lut, mul, d[p], amax);
+            }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(amax > 255u) != 0, 0)) {
+                if (amax > 255u) dequant_row_div<W>(a, g.rcx[p], g.rcy[p], ry[p], c, mrow, bias, mul, d[p]);
             }
             k0[p] = pr.k0[p]; k1[p] = pr.k1[p]; split[p] = pr.split[p];
             straddle |= split[p] < W;
@@ -323,24 +376,26 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
 #pragma unroll
             for (int p = 0; p < RP; ++p)
 #pragma unroll
-                for (int x = 0; x < W; ++x) ydq[(p * W + x) * 64 + lane] = d[p][x];
+                for (int x = 0; x < W; ++x) {
+                    Tx[(p * W + x) * 64 + lane] = d[p][x];
+                    Tb[(p * W + x) * 64 + lane] = d[p][x];
+                }
         }
         lds_barrier();
         TR_STAMP(false);  // 5: Y rows published + barrier 1
         if (c != 1) {
+            // all of these reads precede (program order, one wave) the row writes into the same tile
 #pragma unroll
             for (int p = 0; p < RP; ++p) {
-                float yv[W];
-#pragma unroll
-                for (int x = 0; x < W; ++x) yv[x] = ydq[(p * W + x) * 64 + lane];
                 if (!any_straddle) {  // wave-uniform: every row lies inside one 64-px tile column
 #pragma unroll
-                    for (int x = 0; x < W; ++x) d[p][x] += k0[p] * yv[x];
+                    for (int x = 0; x < W; ++x) d[p][x] += k0[p] * T[(p * W + x) * 64 + lane];
                 } else {
 #pragma unroll
-                    for (int x = 0; x < W; ++x) d[p][x] += (x < split[p] ? k0[p] : k1[p]) * yv[x];
+                    for (int x = 0; x < W; ++x) d[p][x] += (x < split[p] ? k0[p] : k1[p]) * T[(p * W + x) * 64 + lane];
                 }
             }
+            wave_lds_sync();
         }
         // ---- LLF patch, 1-D IDCT of every row (dct.rs:93-96), rows into the wave's tile
 #pragma unroll
@@ -368,11 +423,15 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
 #pragma unroll
             for (int y = 0; y < H; ++y) v[y] = col[y * S];
             idct<H>(v, sl);
-            // cell-tiled output: this lane's column runs down H / 8 cells, 8 words apart inside each
-            float* dst = a.pix + ((((size_t)g.ccy[q] * a.w8 + g.ccx[q] + (uint32_t)(cxi[q] >> 3)) * 3 + (uint32_t)c) << 6) + (cxi[q] & 7);
-            const size_t cell_row = (size_t)a.w8 * 192;
+            // cell-tiled output: this lane's column runs down H / 8 cells, 8 words apart inside each.
+            // 32-bit lane offset + uniform row base: one address register for all H stores.
+            const uint32_t off = (((g.ccy[q] * a.w8 + g.ccx[q] + (uint32_t)(cxi[q] >> 3)) * 3 + (uint32_t)c) << 6) + (uint32_t)(cxi[q] & 7);
+            const uint32_t cell_row = a.w8 * 192;
 #pragma unroll
-            for (int y = 0; y < H; ++y) dst[(size_t)(y >> 3) * cell_row + ((y & 7) << 3)] = v[y];
+            for (int y = 0; y < H; ++y) {
+                float* rowbase = a.pix + (size_t)((uint32_t)(y >> 3) * cell_row + (uint32_t)((y & 7) << 3));  // uniform
+                rowbase[off] = v[y];
+            }
         }
         TR_STAMP(false);  // 7: column IDCT + stores issued
         TR_STAMP(true);   // 8: stores drained
@@ -699,7 +758,19 @@ __global__ __launch_bounds__(64) void transform_special_kernel(TransformArgs a, 
             raw[1] = *reinterpret_cast<const int4*>(src + y * 8 + 4);
             m[0] = *reinterpret_cast<const float4*>(mat + y * 8);
             m[1] = *reinterpret_cast<const float4*>(mat + y * 8 + 4);
-            dequant_row<8>(raw, m, bias, a.quant_bias_numerator, lut, mul, b[y]);
+            uint32_t amax = 0;
+            dequant_row<8>(raw, m, bias, lut, mul, b[y], amax);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(amax > 255u) != 0, 0)) {
+                if (amax > 255u) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        b[y][4 * i + 0] = dequant_div(raw[i].x, bias, a.quant_bias_numerator, m[i].x, mul);
+                        b[y][4 * i + 1] = dequant_div(raw[i].y, bias, a.quant_bias_numerator, m[i].y, mul);
+                        b[y][4 * i + 2] = dequant_div(raw[i].z, bias, a.quant_bias_numerator, m[i].z, mul);
+                        b[y][4 * i + 3] = dequant_div(raw[i].w, bias, a.quant_bias_numerator, m[i].w, mul);
+                    }
+                }
+            }
         }
     }
     // ---- V5: an 8x8 varblock lies inside one 64x64 tile; lanes (X, Y, B) = (3b, 3b+1, 3b+2)
