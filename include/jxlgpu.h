@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 11u
+#define JXLGPU_ABI_VERSION 12u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -253,6 +253,16 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* desc, jxlgpu_f
  * buffers, e.g. for benchmarking); otherwise the result of the last selected stage is written to
  * `out` (D2H copy for JXLGPU_MEM_HOST, followed by a stream synchronisation).                     */
 int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* frame, uint32_t stages, const JxlGpuOut* out);
+/* Batch variant: `n` uploaded frames, one launch per stage for all of them — what the
+ * reference's callers do with a parallel loop over keyframes (jxl-oxide-cli/src/decode.rs:293-304).
+ * Asynchronous, like a render with out == NULL: after jxlgpu_synchronize the results are on the
+ * device (jxlgpu_frame_result_plane / jxlgpu_frame_download_result / jxlgpu_frame_format_output).
+ * Frames of different sizes may be mixed.  Frames or stage masks outside the batched default
+ * pipeline (all stages; Gabor + EPF iters 2; no upsampling / noise; plain XYB -> sRGB; no varblock
+ * >= 128 px; no chroma subsampling) are rendered one by one by the same call: same results.        */
+int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uint32_t n, uint32_t stages);
+/* Copy the result of the frame's last render to `out` (planar f32; host or device memory). */
+int jxlgpu_frame_download_result(jxlgpu_ctx* ctx, jxlgpu_frame* frame, const JxlGpuOut* out);
 /* upload + render(stages) + free in one call: the drop-in for `render_vardct` + filters + colour. */
 int jxlgpu_vardct_render_host(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* desc, uint32_t stages,
                               const JxlGpuOut* out);

@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -262,6 +262,8 @@ _SYMBOLS = [
     ("jxlgpu_profile_read", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("jxlgpu_vardct_upload", C.c_int, [C.c_void_p, C.POINTER(VardctDesc), C.POINTER(C.c_void_p)]),
     ("jxlgpu_vardct_render", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Out)]),
+    ("jxlgpu_vardct_render_batch", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32]),
+    ("jxlgpu_frame_download_result", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Out)]),
     ("jxlgpu_vardct_render_host", C.c_int, [C.c_void_p, C.POINTER(VardctDesc), C.c_uint32, C.POINTER(Out)]),
     ("jxlgpu_frame_free", None, [C.c_void_p, C.c_void_p]),
     ("jxlgpu_frame_out_size", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -55,6 +55,9 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
                              uint32_t in_tiled_w8, float* const out[3], uint32_t out_stride, bool gabor, int epf_iters,
                              bool color, jxlgpu_ctx* ctx);
 bool fused_post_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, bool gabor, int epf_iters);
+hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
+                         uint32_t in_tiled_w8, float* const out[3], uint32_t out_stride, bool gabor, int epf_iters,
+                         bool color, FusedArgs* pa, bool* stream_out, bool* plain_srgb);
 
 struct UploadOpts {
     uint32_t lfg_cells_x = 0, lfg_cells_y = 0;  // LF group size in cells (0: group_dim)
@@ -1035,6 +1038,44 @@ int upload_subsampled(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_frame**
     return JXLGPU_OK;
 }
 
+// Kernel arguments of one frame's V1-V3 / V4-V8 (shared by the single-frame and the batched path).
+static void fill_lf_args(const jxlgpu_frame* f, LfArgs* la, SmoothArgs* sa) {
+    for (int c = 0; c < 3; ++c) { la->lfq[c] = f->lfq[c]; la->out[c] = f->lf_a[c]; }
+    la->is_i16 = f->lf_is_i16; la->scale = f->lf_scale;
+    la->w8 = f->w8; la->h8 = f->h8; la->lf_groups_per_row = f->lf_groups_per_row;
+    la->group_cells_x = f->lfg_cells_x; la->group_cells_y = f->lfg_cells_y;
+    la->kx = f->kx_lf; la->kb = f->kb_lf;
+    for (int c = 0; c < 3; ++c) { sa->in[c] = f->lf_a[c]; sa->out[c] = f->lf[c]; sa->lf_div[c] = f->lf_div[c]; }
+    sa->w8 = f->w8; sa->h8 = f->h8;
+}
+
+static void fill_transform_args(jxlgpu_ctx* ctx, const jxlgpu_frame* f, TransformArgs* pta) {
+    TransformArgs& ta = *pta;
+    memset(&ta, 0, sizeof(ta));
+    const JxlGpuVardctDesc& d = f->desc;
+    float* const* lf = d.skip_adaptive_lf_smoothing ? f->lf_a : f->lf;
+    ta.coeff = f->coeff;
+    ta.pix = f->pix_t;
+    for (int c = 0; c < 3; ++c) {
+        ta.lf[c] = lf[c];
+        ta.qm_scale[c] = f->qm_scale[c]; ta.quant_bias[c] = d.quant_bias[c];
+    }
+    ta.kind = f->kind; ta.hf_mul = f->hf_mul; ta.kx_map = f->kx_map; ta.kb_map = f->kb_map;
+    ta.dequant = f->dequant; ta.deq_off = f->deq_off;
+    memcpy(ta.deq_off_v, f->deq_off_host, sizeof(ta.deq_off_v));
+    ta.sec64 = f->sec[0]; ta.sec128 = f->sec[1]; ta.sec256 = f->sec[2];
+    ta.pstride = f->wr; ta.w8 = f->w8; ta.h8 = f->h8; ta.w64 = f->w64;
+    ta.global_scale = (float)d.global_scale;
+    ta.quant_bias_numerator = d.quant_bias_numerator;
+    ta.big_tmp = f->big_tmp;
+    ta.deq_lut = f->deq_lut;
+#ifdef JXL_TR_PROFILE
+    ta.prof = ctx->tr_prof;
+#else
+    (void)ctx;
+#endif
+}
+
 extern "C" int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuOut* out);
 
 int render_subsampled(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuOut* out) {
@@ -1069,21 +1110,11 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
 
     // ---- V1-V3
     LfArgs la;
-    for (int c = 0; c < 3; ++c) { la.lfq[c] = f->lfq[c]; la.out[c] = f->lf_a[c]; }
-    la.is_i16 = f->lf_is_i16; la.scale = f->lf_scale;
-    la.w8 = f->w8; la.h8 = f->h8; la.lf_groups_per_row = f->lf_groups_per_row;
-    la.group_cells_x = f->lfg_cells_x; la.group_cells_y = f->lfg_cells_y;
-    la.kx = f->kx_lf; la.kb = f->kb_lf;
+    SmoothArgs sa;
+    fill_lf_args(f, &la, &sa);
     ctx->prof_begin(PROF_LF);
     launch_lf_dequant_cfl(s, la);
-    float* const* lf = f->lf_a;
-    if (!d.skip_adaptive_lf_smoothing) {
-        SmoothArgs sa;
-        for (int c = 0; c < 3; ++c) { sa.in[c] = f->lf_a[c]; sa.out[c] = f->lf[c]; sa.lf_div[c] = f->lf_div[c]; }
-        sa.w8 = f->w8; sa.h8 = f->h8;
-        launch_lf_smooth(s, sa);
-        lf = f->lf;
-    }
+    if (!d.skip_adaptive_lf_smoothing) launch_lf_smooth(s, sa);
     ctx->prof_end(PROF_LF);
     if (!(stages & JXLGPU_STAGE_TRANSFORM)) {
         HIP_TRY(ctx, hipGetLastError());
@@ -1093,28 +1124,7 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
 
     // ---- V4-V8
     TransformArgs ta;
-    ta.coeff = f->coeff;
-    ta.pix = f->pix_t;
-    for (int c = 0; c < 3; ++c) {
-        ta.lf[c] = lf[c];
-        ta.qm_scale[c] = f->qm_scale[c]; ta.quant_bias[c] = d.quant_bias[c];
-    }
-    ta.kind = f->kind; ta.hf_mul = f->hf_mul; ta.kx_map = f->kx_map; ta.kb_map = f->kb_map;
-    ta.dequant = f->dequant; ta.deq_off = f->deq_off;
-    memcpy(ta.deq_off_v, f->deq_off_host, sizeof(ta.deq_off_v));
-    ta.sec64 = f->sec[0]; ta.sec128 = f->sec[1]; ta.sec256 = f->sec[2];
-    ta.pstride = f->wr; ta.w8 = f->w8; ta.h8 = f->h8; ta.w64 = f->w64;
-    ta.global_scale = (float)d.global_scale;
-    ta.quant_bias_numerator = d.quant_bias_numerator;
-    ta.big_tmp = f->big_tmp;
-    ta.deq_lut = f->deq_lut;
-#ifdef JXL_TR_PROFILE
-    if (!ctx->tr_prof) {
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->tr_prof, 64 * 8));
-        HIP_TRY(ctx, hipMemset(ctx->tr_prof, 0, 64 * 8));
-    }
-    ta.prof = ctx->tr_prof;
-#endif
+    fill_transform_args(ctx, f, &ta);
     ctx->prof_begin(PROF_TRANSFORM);
     // few, long work items first (64-px, 32-px shapes, the special 8x8 family), the bulk last
     for (int fam : {3, 2}) HIP_TRY(ctx, launch_transform_items(s, fam, ta, f->entries, f->class_first, f->list_count, ctx->num_cus, ctx->tune.tr_wgs_per_cu[fam]));
@@ -1134,6 +1144,113 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
     TRY(run_post_stages(ctx, f, stages, d.filter, d.upsampling.factor ? d.upsampling.factor : 1, cur, &stride, &ow, &oh, true));
     ctx->prof_end(PROF_POST);
     return finish_render(ctx, f, cur, stride, ow, oh, out);
+}
+
+// Device block of the default pipeline's arguments (FrameDev) for the batched launches; decides once
+// per frame whether it qualifies.
+static int ensure_dev_args(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
+    if (f->dev_args_ready) return JXLGPU_OK;
+    f->dev_args_ready = true;
+    f->batch_ok = false;
+    const JxlGpuVardctDesc& d = f->desc;
+    const uint32_t upf = d.upsampling.factor ? d.upsampling.factor : 1;
+    if (f->kind_of_frame != 0 || !f->subs.empty() || !f->buf_a[0] || f->list_count[CLS_BIG] || f->nometa_count) return JXLGPU_OK;
+    if (!d.filter.gab_enabled || d.filter.epf_iters != 2 || upf != 1 || d.noise.enabled || !d.color.enabled || d.color.ycbcr)
+        return JXLGPU_OK;
+    if (!fused_post_supported(ctx, f, true, 2)) return JXLGPU_OK;
+    FrameDev h;
+    memset(&h, 0, sizeof(h));
+    fill_lf_args(f, &h.lf, &h.smooth);
+    h.skip_smooth = d.skip_adaptive_lf_smoothing ? 1u : 0u;
+    fill_transform_args(ctx, f, &h.tr);
+    for (int fam = 0; fam < 4; ++fam) {
+        build_class_table(fam, f->class_first, f->list_count, ctx->num_cus, 0, &h.ct[fam]);
+        f->batch_wgs[fam] = h.ct[fam].wg_begin[h.ct[fam].n_classes];
+    }
+    h.entries = f->entries;
+    h.special_first = f->class_first[CLS_SPECIAL8];
+    h.special_count = f->list_count[CLS_SPECIAL8];
+    const float* in[3] = {f->pix_t, nullptr, nullptr};
+    bool stream = false, plain_srgb = false;
+    HIP_TRY(ctx, fused_prepare(ctx, f, in, f->wr, f->w8, f->buf_a, f->wr, true, 2, true, &h.post, &stream, &plain_srgb));
+    if (!stream || !plain_srgb) return JXLGPU_OK;
+    h.post.tiles = f->ring_tiles;
+    h.n_ring_tiles = f->n_ring_tiles;
+    f->batch_stream_wgs = (uint32_t)(h.post.strips * h.post.segs + 3) / 4;
+    TRY(dev_alloc(ctx, f, &f->dev_args, 1));
+    HIP_TRY(ctx, hipMemcpy(f->dev_args, &h, sizeof(h), hipMemcpyHostToDevice));
+    f->batch_ok = true;
+    return JXLGPU_OK;
+}
+
+// N frames, one launch per stage (SURVEY §8b "batch variants taking N descs"; the caller pattern is
+// jxl-oxide-cli/src/decode.rs:293-304, keyframes rendered in a parallel loop).  Asynchronous like a
+// render without an output descriptor: results stay on the device (jxlgpu_frame_result_plane,
+// jxlgpu_frame_format_output) after jxlgpu_synchronize.  Frames that do not qualify for the batched
+// default pipeline (other filter settings, upsampling, noise, >= 128-px varblocks, chroma
+// subsampling, ...) or a `stages` mask without the full pipeline are rendered one by one.
+int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uint32_t n, uint32_t stages) {
+    if (!ctx || (!frames && n)) return JXLGPU_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < n; ++i)
+        if (!frames[i] || frames[i]->kind_of_frame != 0) return JXLGPU_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t need = JXLGPU_STAGE_LF | JXLGPU_STAGE_TRANSFORM | JXLGPU_STAGE_GABOR | JXLGPU_STAGE_EPF | JXLGPU_STAGE_COLOR;
+    bool batched = (stages & need) == need;
+    for (uint32_t i = 0; i < n && batched; ++i) {
+        TRY(ensure_dev_args(ctx, frames[i]));
+        batched = frames[i]->batch_ok;
+    }
+    if (!batched) {
+        for (uint32_t i = 0; i < n; ++i) TRY(jxlgpu_vardct_render(ctx, frames[i], stages, nullptr));
+        return JXLGPU_OK;
+    }
+    hipStream_t s = ctx->stream;
+    for (uint32_t i0 = 0; i0 < n; i0 += JXLGPU_MAX_BATCH) {
+        const uint32_t m = std::min<uint32_t>(JXLGPU_MAX_BATCH, n - i0);
+        FrameBatch b;
+        memset(&b, 0, sizeof(b));
+        uint32_t max_w8 = 0, max_h8 = 0, max_wgs[4] = {}, max_special = 0, max_stream = 0, max_ring = 0;
+        bool any_smooth = false;
+        for (uint32_t i = 0; i < m; ++i) {
+            jxlgpu_frame* f = frames[i0 + i];
+            b.f[i] = f->dev_args;
+            max_w8 = std::max(max_w8, f->w8); max_h8 = std::max(max_h8, f->h8);
+            for (int fam = 0; fam < 4; ++fam) max_wgs[fam] = std::max(max_wgs[fam], f->batch_wgs[fam]);
+            max_special = std::max(max_special, f->list_count[CLS_SPECIAL8]);
+            max_stream = std::max(max_stream, f->batch_stream_wgs);
+            max_ring = std::max(max_ring, f->n_ring_tiles);
+            any_smooth |= !f->desc.skip_adaptive_lf_smoothing;
+        }
+        ctx->prof_begin(PROF_LF);
+        HIP_TRY(ctx, launch_lf_batch(s, b, m, max_w8, max_h8, any_smooth));
+        ctx->prof_end(PROF_LF);
+        ctx->prof_begin(PROF_TRANSFORM);
+        HIP_TRY(ctx, launch_transform_batch(s, b, m, max_wgs, max_special));
+        ctx->prof_end(PROF_TRANSFORM);
+        ctx->prof_begin(PROF_POST);
+        // one fork / join per batch: the border rings (few, long tiles) run beside the streaming kernel
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        HIP_TRY(ctx, launch_post_batch(s, ctx->stream2, b, m, max_stream, max_ring));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+        ctx->prof_end(PROF_POST);
+        for (uint32_t i = 0; i < m; ++i) {
+            jxlgpu_frame* f = frames[i0 + i];
+            for (int c = 0; c < 3; ++c) f->result[c] = f->buf_a[c];
+            f->result_stride = f->wr; f->result_w = f->width; f->result_h = f->height;
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return JXLGPU_OK;
+}
+
+int jxlgpu_frame_download_result(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuOut* out) {
+    if (!ctx || !f || !out) return JXLGPU_ERR_INVALID_ARG;
+    if (!f->result[0]) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "the frame has not been rendered");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float* cur[3] = {const_cast<float*>(f->result[0]), const_cast<float*>(f->result[1]), const_cast<float*>(f->result[2])};
+    return finish_render(ctx, f, cur, f->result_stride, f->result_w, f->result_h, out);
 }
 
 int jxlgpu_vardct_render_host(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* desc, uint32_t stages, const JxlGpuOut* out) {

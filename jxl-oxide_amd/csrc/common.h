@@ -123,6 +123,61 @@ struct ColorArgs {
     float tm_gamut_sat;
 };
 
+// Fused post stage (fused_kernels.hip): Gabor -> EPF -> colour in one pass.
+struct FusedArgs {
+    const float* in[3];      // row-major planes, or in[0] = the cell-tiled transform output (in_w8 != 0)
+    float* out[3];
+    uint32_t in_stride, out_stride;
+    uint32_t in_w8;          // cells per row of the tiled input (coeff_tiled_index)
+    int width, height;
+    const float* sigma;
+    uint32_t sigma_stride;
+    JxlGpuFilterParams fp;
+    ColorArgs color;
+    uint32_t do_color;
+    const uint32_t* tiles;   // optional list of tiles (tx | ty << 16); null = full 2-D grid
+    // streaming kernel geometry: it covers [sx0, sx1) x [sy0, sy1), strictly inside the image
+    int sx0, sx1, sy0, sy1, rows_per_seg, strips, segs;
+};
+
+// Workgroups of one transform launch: class k owns workgroups [wg_begin[k], wg_begin[k + 1]).
+struct ClassTable {
+    uint32_t n_classes;
+    uint32_t wg_begin[6];    // n_classes + 1 entries used
+    uint32_t cls[5];
+    uint32_t first_entry[5]; // into `entries`
+    uint32_t count[5];       // varblocks of the class
+};
+
+// Batched launches (jxlgpu_vardct_render_batch): every frame keeps a device-resident copy of the
+// arguments of its default pipeline (all stages, Gabor + EPF iters 2 through the streaming kernel,
+// colour fused); a launch takes up to JXLGPU_MAX_BATCH pointers to those blocks by value and picks
+// its frame with blockIdx.y / .z, so N frames cost one launch per stage instead of N.
+struct FrameDev {
+    LfArgs lf;
+    SmoothArgs smooth;
+    uint32_t skip_smooth;
+    TransformArgs tr;
+    ClassTable ct[4];
+    const uint4* entries;
+    uint32_t special_first, special_count;
+    FusedArgs post;
+    uint32_t n_ring_tiles;
+};
+constexpr int JXLGPU_MAX_BATCH = 32;
+struct FrameBatch {
+    const FrameDev* f[JXLGPU_MAX_BATCH];
+};
+// The blocks are read-only for the kernels: constant address space makes every field a scalar load.
+typedef const FrameDev __attribute__((address_space(4))) * FrameDevC;
+// by-value copy of one member of a block (the compiler keeps only the fields a kernel uses, as SGPRs)
+template <typename T>
+__device__ __forceinline__ T load_const(const T __attribute__((address_space(4))) * p) {
+    T v;
+    __builtin_memcpy(&v, p, sizeof(T));
+    return v;
+}
+
 // Kernel groups that can be bracketed with HIP events (jxlgpu_profile_*).
 enum ProfGroup : int { PROF_LF = 0, PROF_TRANSFORM = 1, PROF_POST = 2, PROF_MODULAR = 3, PROF_COUNT = 4 };
 
@@ -242,6 +297,10 @@ struct jxlgpu_frame {
     uint32_t noise_group_dim = 256;
     float noise_corr_x = 0.0f, noise_corr_b = 1.0f;  // base_correlations_xb (render.rs:175-180)
     float* deq_lut = nullptr;            // quant_bias_numerator / k, k < 256 (dequant_one_lut)
+    FrameDev* dev_args = nullptr;        // device copy of the default pipeline's arguments (batched launches)
+    bool dev_args_ready = false;
+    bool batch_ok = false;               // the frame qualifies for the batched default pipeline
+    uint32_t batch_wgs[4] = {}, batch_stream_wgs = 0;
     uint32_t* ring_tiles = nullptr;      // outer ring of 32x32 tiles for the fused tile kernel
     uint32_t n_ring_tiles = 0;
     float* up_weights[3] = {};  // expanded 5x5 kernels per phase for 2x/4x/8x
@@ -269,6 +328,14 @@ void launch_lf_dequant_cfl(hipStream_t s, const LfArgs& a);
 void launch_lf_smooth(hipStream_t s, const SmoothArgs& a);
 void launch_transform_class(hipStream_t s, int cls, const TransformArgs& a, const uint4* entries,
                             uint32_t count);
+// batched launches over FrameDev blocks (n <= JXLGPU_MAX_BATCH)
+void build_class_table(int family, const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT],
+                       uint32_t num_cus, int wgs_per_cu, ClassTable* ct);
+hipError_t launch_lf_batch(hipStream_t s, const FrameBatch& b, uint32_t n, uint32_t max_w8, uint32_t max_h8, bool any_smooth);
+hipError_t launch_transform_batch(hipStream_t s, const FrameBatch& b, uint32_t n, const uint32_t max_wgs[4],
+                                  uint32_t max_special);
+hipError_t launch_post_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, uint32_t max_stream_wgs,
+                             uint32_t max_ring);
 hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs& a, const uint4* entries,
                                   const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT],
                                   uint32_t num_cus, int wgs_per_cu);

@@ -31,22 +31,6 @@ struct PostCfg {
     static constexpr int PLANE = LW * LW;
 };
 
-struct FusedArgs {
-    const float* in[3];      // row-major planes, or in[0] = the cell-tiled transform output (in_w8 != 0)
-    float* out[3];
-    uint32_t in_stride, out_stride;
-    uint32_t in_w8;          // cells per row of the tiled input (coeff_tiled_index)
-    int width, height;
-    const float* sigma;
-    uint32_t sigma_stride;
-    JxlGpuFilterParams fp;
-    ColorArgs color;
-    uint32_t do_color;
-    const uint32_t* tiles;   // optional list of tiles (tx | ty << 16); null = full 2-D grid
-    // streaming kernel geometry: it covers [sx0, sx1) x [sy0, sy1), strictly inside the image
-    int sx0, sx1, sy0, sy1, rows_per_seg, strips, segs;
-};
-
 template <bool TILED>
 __device__ __forceinline__ float load_in(const FusedArgs& a, int c, int x, int y) {
     if constexpr (TILED) return a.in[0][coeff_tiled_index((uint32_t)x, (uint32_t)y, (uint32_t)c, a.in_w8)];
@@ -103,10 +87,9 @@ __device__ __forceinline__ void epf_stage(const float* src, float* dst, int lo, 
 }
 
 template <bool GAB, int ITERS, bool TILED>
-__global__ __launch_bounds__(256) void fused_post_kernel(FusedArgs a) {
+__device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds) {
     using Cfg = PostCfg<GAB, ITERS>;
     constexpr int LW = Cfg::LW, PLANE = Cfg::PLANE, HALO = Cfg::HALO;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     float* bufA = lds;
     float* bufB = lds + 3 * PLANE;
     const int t = threadIdx.x;
@@ -211,6 +194,21 @@ __global__ __launch_bounds__(256) void fused_post_kernel(FusedArgs a) {
     }
 }
 
+
+template <bool GAB, int ITERS, bool TILED>
+__global__ __launch_bounds__(256) void fused_post_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    fused_post_body<GAB, ITERS, TILED>(a, lds);
+}
+
+// the border ring of n frames in one launch (blockIdx.y = frame; default pipeline only)
+__global__ __launch_bounds__(256) void post_ring_batch_kernel(FrameBatch b) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const FrameDevC fd = (FrameDevC)b.f[blockIdx.y];
+    if (blockIdx.x >= fd->n_ring_tiles) return;
+    const FusedArgs a = load_const(&fd->post);
+    fused_post_body<true, 2, true>(a, lds);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Streaming form of the same pipeline for the interior of the image (Gabor + EPF steps 1,2 +
@@ -395,10 +393,7 @@ __device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst
 }
 
 template <int TF, bool TILED>
-__global__ __launch_bounds__(256) void post_stream_kernel(FusedArgs a) {
-    __shared__ uint32_t srgb_lut[16];
-    if (threadIdx.x < 16) srgb_lut[threadIdx.x] = kSrgbMulBits[threadIdx.x];
-    __syncthreads();
+__device__ __forceinline__ void post_stream_body(const FusedArgs& a, const uint32_t* srgb_lut) {
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int strip = wave % a.strips, seg = wave / a.strips;
@@ -447,6 +442,23 @@ __global__ __launch_bounds__(256) void post_stream_kernel(FusedArgs a) {
     }
 }
 
+template <int TF, bool TILED>
+__global__ __launch_bounds__(256) void post_stream_kernel(FusedArgs a) {
+    __shared__ uint32_t srgb_lut[16];
+    if (threadIdx.x < 16) srgb_lut[threadIdx.x] = kSrgbMulBits[threadIdx.x];
+    __syncthreads();
+    post_stream_body<TF, TILED>(a, srgb_lut);
+}
+
+// n frames in one launch (blockIdx.y = frame): plain XYB -> sRGB from the cell-tiled transform output
+__global__ __launch_bounds__(256) void post_stream_batch_kernel(FrameBatch b) {
+    __shared__ uint32_t srgb_lut[16];
+    if (threadIdx.x < 16) srgb_lut[threadIdx.x] = kSrgbMulBits[threadIdx.x];
+    __syncthreads();
+    const FusedArgs a = load_const(&((FrameDevC)b.f[blockIdx.y])->post);
+    post_stream_body<JXLGPU_TF_SRGB, true>(a, srgb_lut);
+}
+
 template <bool GAB, int ITERS>
 hipError_t launch_cfg(hipStream_t s, const FusedArgs& a, dim3 grid) {
     constexpr size_t lds_bytes = 2 * 3 * PostCfg<GAB, ITERS>::PLANE * sizeof(float);
@@ -482,13 +494,13 @@ bool fused_post_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, bool gab
     return !(ctx && ctx->tune.no_fused);
 }
 
-// Returns a HIP error instead of silently skipping the launch (the caller switches `cur` to `out`
-// only on success).  If the ring-tile list cannot be allocated the whole frame runs through the
-// tile kernel, which needs no list.
-hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
-                             uint32_t in_tiled_w8, float* const out[3], uint32_t out_stride, bool gabor, int epf_iters,
-                             bool color, jxlgpu_ctx* ctx) {
-    FusedArgs a;
+// Fills the arguments of the fused post stage of one frame and decides whether the streaming kernel
+// applies (Gabor + 2 EPF steps on a frame with an interior; the ring-tile list is created on first
+// use).  *plain_srgb: the colour tail is the plain XYB -> sRGB list (branch-free epilogue).
+hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
+                         uint32_t in_tiled_w8, float* const out[3], uint32_t out_stride, bool gabor, int epf_iters,
+                         bool color, FusedArgs* pa, bool* stream_out, bool* plain_srgb) {
+    FusedArgs& a = *pa;
     memset(&a, 0, sizeof(a));
     for (int c = 0; c < 3; ++c) { a.in[c] = in[c]; a.out[c] = out[c]; }
     a.in_stride = in_stride; a.out_stride = out_stride;
@@ -499,11 +511,9 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
     a.color = f->color;
     a.do_color = color ? 1u : 0u;
     a.tiles = nullptr;
-    const dim3 full_grid(ceil_div(f->width, T), ceil_div(f->height, T));
-
     // Default configuration (Gabor + 2 EPF steps) on a frame with an interior: the streaming
     // kernel takes everything except the outer ring of tiles.
-    const int ntx = (int)full_grid.x, nty = (int)full_grid.y;
+    const int ntx = (int)ceil_div(f->width, T), nty = (int)ceil_div(f->height, T);
     int tx_hi = ntx - 1, ty_hi = nty - 1;
     while (tx_hi > 1 && T * tx_hi + SH > (int)f->width) --tx_hi;
     while (ty_hi > 1 && T * ty_hi + SH > (int)f->height) --ty_hi;
@@ -526,18 +536,33 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
             f->n_ring_tiles = (uint32_t)ring.size();
         }
     }
-    if (!stream) return launch_tile_kernel(s, a, gabor, epf_iters, full_grid);
-
-    a.sx0 = T; a.sx1 = T * tx_hi; a.sy0 = T; a.sy1 = T * ty_hi;
-    a.rows_per_seg = ctx ? ctx->tune.stream_rows : 48;
-    a.strips = (a.sx1 - a.sx0 + SW - 1) / SW;
-    a.segs = (a.sy1 - a.sy0 + a.rows_per_seg - 1) / a.rows_per_seg;
-    const int waves = a.strips * a.segs;
+    *stream_out = stream;
+    if (stream) {
+        a.sx0 = T; a.sx1 = T * tx_hi; a.sy0 = T; a.sy1 = T * ty_hi;
+        a.rows_per_seg = ctx ? ctx->tune.stream_rows : 48;
+        a.strips = (a.sx1 - a.sx0 + SW - 1) / SW;
+        a.segs = (a.sy1 - a.sy0 + a.rows_per_seg - 1) / a.rows_per_seg;
+    }
     // plain XYB -> sRGB (no gamut map / second matrix) gets a branch-free colour epilogue
-    const bool plain_srgb = a.color.tf == JXLGPU_TF_SRGB && !a.color.gamut_map && !a.color.has_matrix2 &&
-                            !a.color.tone_map && !a.color.ycbcr;
+    *plain_srgb = a.color.tf == JXLGPU_TF_SRGB && !a.color.gamut_map && !a.color.has_matrix2 &&
+                  !a.color.tone_map && !a.color.ycbcr;
+    return hipSuccess;
+}
+
+// Returns a HIP error instead of silently skipping the launch (the caller switches `cur` to `out`
+// only on success).  If the ring-tile list cannot be allocated the whole frame runs through the
+// tile kernel, which needs no list.
+hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
+                             uint32_t in_tiled_w8, float* const out[3], uint32_t out_stride, bool gabor, int epf_iters,
+                             bool color, jxlgpu_ctx* ctx) {
+    FusedArgs a;
+    bool stream = false, plain_srgb = false;
+    hipError_t e = fused_prepare(ctx, f, in, in_stride, in_tiled_w8, out, out_stride, gabor, epf_iters, color, &a, &stream,
+                                 &plain_srgb);
+    if (e != hipSuccess) return e;
+    if (!stream) return launch_tile_kernel(s, a, gabor, epf_iters, dim3(ceil_div(f->width, T), ceil_div(f->height, T)));
+    const int waves = a.strips * a.segs;
     const bool side = ctx && ctx->stream2;
-    hipError_t e;
     if (side && (e = hipEventRecord(ctx->ev_fork, s)) != hipSuccess) return e;  // inputs are ready here
     const dim3 sgrid((waves + 3) / 4);
     if (a.in_w8) {
@@ -557,4 +582,19 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
         return hipStreamWaitEvent(s, ctx->ev_join, 0);
     }
     return launch_tile_kernel(s, a, true, 2, dim3(f->n_ring_tiles));
+}
+
+// Default pipeline of n frames: streaming kernel on `s`, border rings beside it on `side` (may be
+// null: same stream).  The caller forks / joins the two streams once per batch.
+hipError_t launch_post_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, uint32_t max_stream_wgs,
+                             uint32_t max_ring) {
+    constexpr size_t lds_bytes = 2 * 3 * PostCfg<true, 2>::PLANE * sizeof(float);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&post_ring_batch_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    });
+    if (max_ring) post_ring_batch_kernel<<<dim3(max_ring, n), 256, lds_bytes, side ? side : s>>>(b);
+    if (max_stream_wgs) post_stream_batch_kernel<<<dim3(max_stream_wgs, n), 256, 0, s>>>(b);
+    return hipGetLastError();
 }

@@ -50,6 +50,14 @@ namespace {
 #define TR_STAMP_FLUSH(slot) do {} while (0)
 #endif
 
+// value of channel c (wave-uniform) out of three: by VALUE on purpose — `c == 0 ? s.x[0] : s.x[1]`
+// on struct members is an lvalue select, i.e. a dynamically indexed load, which forces a by-value
+// argument struct into scratch memory
+template <typename T>
+__device__ __forceinline__ T pick3(int c, T v0, T v1, T v2) {
+    return c == 0 ? v0 : (c == 1 ? v1 : v2);
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -217,11 +225,11 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
     float* Tb = lds + kLutWords + 2 * C::WAVE_WORDS;   // dequantised rows there for chroma-from-luma
     const SecLarge sl{a.sec64, a.sec128, a.sec256};
     const int c = wave == 0 ? 1 : (wave == 1 ? 0 : 2);  // wave 0 = Y: the other two wait for its rows
-    const float* lfp = c == 0 ? a.lf[0] : (c == 1 ? a.lf[1] : a.lf[2]);
-    const float bias = c == 0 ? a.quant_bias[0] : (c == 1 ? a.quant_bias[1] : a.quant_bias[2]);
-    const float qms = c == 0 ? a.qm_scale[0] : (c == 1 ? a.qm_scale[1] : a.qm_scale[2]);
-    const float* mat = a.dequant + (c == 0 ? a.deq_off_v[TYPE * 3] : (c == 1 ? a.deq_off_v[TYPE * 3 + 1] : a.deq_off_v[TYPE * 3 + 2]));
-    const float* kmap = c == 0 ? a.kx_map : a.kb_map;
+    const float* lfp = pick3<const float*>(c, a.lf[0], a.lf[1], a.lf[2]);
+    const float bias = pick3(c, a.quant_bias[0], a.quant_bias[1], a.quant_bias[2]);
+    const float qms = pick3(c, a.qm_scale[0], a.qm_scale[1], a.qm_scale[2]);
+    const float* mat = a.dequant + pick3(c, a.deq_off_v[TYPE * 3], a.deq_off_v[TYPE * 3 + 1], a.deq_off_v[TYPE * 3 + 2]);
+    const float* kmap = pick3<const float*>(c, a.kx_map, a.kb_map, a.kb_map);
     const uint32_t n_items = (count + NBI - 1) / NBI;
 
     // ---- lane constants: which row / column of which varblock of an item this lane owns
@@ -242,7 +250,7 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
         for (int p = 0; p < RP; ++p) load_mrow<W>(mat + ry[p] * W, mh[p]);
     }
 
-    auto load_geo = [&](uint32_t item, Geo<RP, CP>& g) {
+    auto load_geo = [&](uint32_t item, Geo<RP, CP>& g) __attribute__((always_inline)) {
         const uint4* ent = ent_class + (size_t)item * NBI;
         const int nv = (int)min((uint32_t)NBI, count - item * NBI);
 #pragma unroll
@@ -260,7 +268,7 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
         }
         g.lpos = ent[min(lane, nv - 1)].x;
     };
-    auto issue_loads = [&](const Geo<RP, CP>& g, Pre<RP, W, BW, BH>& pr) {
+    auto issue_loads = [&](const Geo<RP, CP>& g, Pre<RP, W, BW, BH>& pr) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < RP; ++p) {
             load_row<W>(a, g.rcx[p], g.rcy[p], ry[p], c, pr.raw[p]);
@@ -455,15 +463,6 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
     }
 }
 
-// Persistent workgroups of one launch: class k owns workgroups [wg_begin[k], wg_begin[k + 1]).
-struct ClassTable {
-    uint32_t n_classes;
-    uint32_t wg_begin[6];    // n_classes + 1 entries used
-    uint32_t cls[5];
-    uint32_t first_entry[5]; // into `entries`
-    uint32_t count[5];       // varblocks of the class
-};
-
 // One launch per register class, so that the long-row shapes do not set the occupancy of the
 // short ones: FAMILY 0 = 8x8 (<= 64 VGPRs: eight waves per SIMD keep ~64 KiB of coefficient
 // loads in flight per CU, what 8 TB/s x ~2 us of loaded latency asks for), 1 = the 16-px shapes,
@@ -485,27 +484,46 @@ template <> struct FamCfg<3> {
     static constexpr int WORDS = cmax(cmax(RCfg<64, 64>::WG_WORDS, RCfg<32, 64>::WG_WORDS), RCfg<64, 32>::WG_WORDS);
 };
 
+// Field-by-field copy of a frame's TransformArgs out of its device block (a memcpy of the whole
+// struct is not scalarised by the compiler and ends up in scratch; this form becomes SGPRs).
+__device__ __forceinline__ TransformArgs load_transform_args(FrameDevC fd) {
+    TransformArgs a;
+    a.coeff = fd->tr.coeff; a.pix = fd->tr.pix;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a.lf[c] = fd->tr.lf[c]; a.qm_scale[c] = fd->tr.qm_scale[c]; a.quant_bias[c] = fd->tr.quant_bias[c];
+    }
+    a.kind = fd->tr.kind; a.hf_mul = fd->tr.hf_mul; a.kx_map = fd->tr.kx_map; a.kb_map = fd->tr.kb_map;
+    a.dequant = fd->tr.dequant; a.deq_off = fd->tr.deq_off;
+#pragma unroll
+    for (int i = 0; i < 27 * 3; ++i) a.deq_off_v[i] = fd->tr.deq_off_v[i];
+    a.sec64 = fd->tr.sec64; a.sec128 = fd->tr.sec128; a.sec256 = fd->tr.sec256;
+    a.pstride = fd->tr.pstride; a.w8 = fd->tr.w8; a.h8 = fd->tr.h8; a.w64 = fd->tr.w64;
+    a.global_scale = fd->tr.global_scale; a.quant_bias_numerator = fd->tr.quant_bias_numerator;
+    a.big_tmp = fd->tr.big_tmp; a.deq_lut = fd->tr.deq_lut;
+#ifdef JXL_TR_PROFILE
+    a.prof = fd->tr.prof;
+#endif
+    return a;
+}
+
 template <int FAMILY, bool PIPE>
-__global__ __launch_bounds__(192, FamCfg<FAMILY>::WAVES) void transform_items_kernel(TransformArgs a, ClassTable ct,
-                                                                                     const uint4* __restrict__ entries) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void items_body(const TransformArgs& a, uint32_t cls, const uint4* __restrict__ ent_class,
+                                           uint32_t count, uint32_t wg, uint32_t n_wgs, float* lds) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    uint32_t k = 0;
-    while (blockIdx.x >= ct.wg_begin[k + 1]) ++k;
-    const uint32_t wg = blockIdx.x - ct.wg_begin[k], n_wgs = ct.wg_begin[k + 1] - ct.wg_begin[k];
-#define RUN(W, H) run_class<W, H, PIPE>(a, entries + ct.first_entry[k], ct.count[k], wg, n_wgs, lds, wave, lane);
+#define RUN(W, H) run_class<W, H, PIPE>(a, ent_class, count, wg, n_wgs, lds, wave, lane);
     if constexpr (FAMILY == 0) {
         RUN(8, 8)
     } else if constexpr (FAMILY == 1) {
-        switch (ct.cls[k]) {
+        switch (cls) {
             case CLS_16x16: RUN(16, 16) break;
             case CLS_8x16: RUN(8, 16) break;
             case CLS_16x8: RUN(16, 8) break;
             default: break;
         }
     } else if constexpr (FAMILY == 2) {
-        switch (ct.cls[k]) {
+        switch (cls) {
             case CLS_32x32: RUN(32, 32) break;
             case CLS_8x32: RUN(8, 32) break;
             case CLS_32x8: RUN(32, 8) break;
@@ -514,7 +532,7 @@ __global__ __launch_bounds__(192, FamCfg<FAMILY>::WAVES) void transform_items_ke
             default: break;
         }
     } else {
-        switch (ct.cls[k]) {
+        switch (cls) {
             case CLS_64x64: RUN(64, 64) break;
             case CLS_32x64: RUN(32, 64) break;
             case CLS_64x32: RUN(64, 32) break;
@@ -522,6 +540,32 @@ __global__ __launch_bounds__(192, FamCfg<FAMILY>::WAVES) void transform_items_ke
         }
     }
 #undef RUN
+}
+
+template <int FAMILY, bool PIPE>
+__global__ __launch_bounds__(192, FamCfg<FAMILY>::WAVES) void transform_items_kernel(TransformArgs a, ClassTable ct,
+                                                                                     const uint4* __restrict__ entries) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint32_t k = 0;
+    while (blockIdx.x >= ct.wg_begin[k + 1]) ++k;
+    const uint32_t wg = blockIdx.x - ct.wg_begin[k], n_wgs = ct.wg_begin[k + 1] - ct.wg_begin[k];
+    items_body<FAMILY, PIPE>(a, ct.cls[k], entries + ct.first_entry[k], ct.count[k], wg, n_wgs, lds);
+}
+
+// Batched form: blockIdx.y picks the frame; its arguments come from the frame's device block.
+template <int FAMILY>
+__global__ __launch_bounds__(192, FamCfg<FAMILY>::WAVES) void transform_items_batch_kernel(FrameBatch b) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const FrameDevC fd = (FrameDevC)b.f[blockIdx.y];
+    const uint32_t ncls = fd->ct[FAMILY].n_classes;
+    if (blockIdx.x >= fd->ct[FAMILY].wg_begin[ncls]) return;
+    uint32_t k = 0;
+    while (blockIdx.x >= fd->ct[FAMILY].wg_begin[k + 1]) ++k;
+    const uint32_t wg = blockIdx.x - fd->ct[FAMILY].wg_begin[k];
+    const uint32_t n_wgs = fd->ct[FAMILY].wg_begin[k + 1] - fd->ct[FAMILY].wg_begin[k];
+    const TransformArgs a = load_transform_args(fd);
+    items_body<FAMILY, false>(a, fd->ct[FAMILY].cls[k], fd->entries + fd->ct[FAMILY].first_entry[k],
+                              fd->ct[FAMILY].count[k], wg, n_wgs, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -726,9 +770,8 @@ __device__ __forceinline__ void transform_afv(Blk8& b, const SecLarge& sl) {
 
 constexpr int kSpecialPerWave = 21;  // varblocks per wave: 63 lanes
 
-__global__ __launch_bounds__(64) void transform_special_kernel(TransformArgs a, const uint4* __restrict__ entries,
-                                                               uint32_t count) {
-    __shared__ float lut[kLutWords];
+__device__ __forceinline__ void special_body(const TransformArgs& a, const uint4* __restrict__ entries, uint32_t count,
+                                             float* lut) {
     const int lane = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < kLutWords / 64; ++i) lut[i * 64 + lane] = a.deq_lut[i * 64 + lane];
@@ -747,8 +790,8 @@ __global__ __launch_bounds__(64) void transform_special_kernel(TransformArgs a, 
     {
         const int32_t* src = a.coeff + ((cell * 3 + (uint32_t)c) << 6);
         const float* mat = a.dequant + a.deq_off[type * 3 + c];
-        const float bias = c == 0 ? a.quant_bias[0] : (c == 1 ? a.quant_bias[1] : a.quant_bias[2]);
-        const float qms = c == 0 ? a.qm_scale[0] : (c == 1 ? a.qm_scale[1] : a.qm_scale[2]);
+        const float bias = pick3(c, a.quant_bias[0], a.quant_bias[1], a.quant_bias[2]);
+        const float qms = pick3(c, a.qm_scale[0], a.qm_scale[1], a.qm_scale[2]);
         const float mul = 65536.0f / (a.global_scale * (float)(int32_t)e.z) * qms;
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
@@ -789,7 +832,7 @@ __global__ __launch_bounds__(64) void transform_special_kernel(TransformArgs a, 
     }
     // ---- V6: 1x1 LF block -> coefficient (0, 0) (transform_common.rs:40-48)
     {
-        const float* lfp = c == 0 ? a.lf[0] : (c == 1 ? a.lf[1] : a.lf[2]);
+        const float* lfp = pick3<const float*>(c, a.lf[0], a.lf[1], a.lf[2]);
         b[0][0] = lfp[cell];
     }
     // ---- V8 (transform.rs:225-240 dispatch)
@@ -815,6 +858,22 @@ __global__ __launch_bounds__(64) void transform_special_kernel(TransformArgs a, 
     }
 }
 
+__global__ __launch_bounds__(64) void transform_special_kernel(TransformArgs a, const uint4* __restrict__ entries,
+                                                               uint32_t count) {
+    __shared__ float lut[kLutWords];
+    special_body(a, entries, count, lut);
+}
+
+__global__ __launch_bounds__(64) void transform_special_batch_kernel(FrameBatch b) {
+    __shared__ float lut[kLutWords];
+    const FrameDevC fd = (FrameDevC)b.f[blockIdx.y];
+    const uint32_t count = fd->special_count;
+    if (blockIdx.x * kSpecialPerWave >= count) return;
+    const TransformArgs a = load_transform_args(fd);
+    special_body(a, fd->entries + fd->special_first, count, lut);
+}
+
+
 }  // namespace
 
 void launch_big_blocks(hipStream_t s, const TransformArgs& a, const uint4* entries, uint32_t count);
@@ -838,12 +897,12 @@ int transform_items_nbi(int cls) {
     }
 }
 
-// One launch per family.  Each shape class gets a share of the family's persistent workgroups
-// proportional to its work (pixels, weighted by the depth of its butterflies), never more than it
-// has items; classes with long items come first so they start first.
-hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs& a, const uint4* entries,
-                                  const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT],
-                                  uint32_t num_cus, int wgs_per_cu) {
+// Workgroups of one family launch.  wgs_per_cu = 0: one workgroup per work item (the default: the
+// occupancy of the launch hides latency).  > 0: persistent workgroups with run-ahead; each shape
+// class gets a share of num_cus * wgs_per_cu proportional to its work (pixels, weighted by the depth
+// of its butterflies), never more than it has items.  Classes with long items come first.
+void build_class_table(int family, const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT],
+                       uint32_t num_cus, int wgs_per_cu, ClassTable* out) {
     static const int kFam0[] = {CLS_DCT8};
     static const int kFam1[] = {CLS_16x16, CLS_8x16, CLS_16x8};
     static const int kFam2[] = {CLS_32x32, CLS_16x32, CLS_32x16, CLS_8x32, CLS_32x8};
@@ -854,11 +913,10 @@ hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs
     static const int kArea[CLS_COUNT] = {64, 0, 256, 128, 128, 1024, 256, 256, 512, 512, 4096, 2048, 2048, 0};
     static const int* const kFam[4] = {kFam0, kFam1, kFam2, kFam3};
     static const int kFamN[4] = {1, 3, 5, 3};
-    if (family < 0 || family > 3) return hipErrorInvalidValue;
+    ClassTable& ct = *out;
+    memset(&ct, 0, sizeof(ct));
     const int* classes = kFam[family];
     const int n = kFamN[family];
-    // wgs_per_cu = resident workgroups per CU the kernel's registers / LDS allow (3 waves each);
-    // 0 = one workgroup per work item (no persistence, no run-ahead)
     const uint32_t budget = wgs_per_cu > 0 ? std::max(1u, num_cus) * (uint32_t)wgs_per_cu : 0xffffffu;
     double work[5] = {}, total = 0;
     uint32_t items[5] = {};
@@ -868,9 +926,6 @@ hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs
         work[i] = (double)list_count[cls] * kArea[cls] * kCost[cls];
         total += work[i];
     }
-    if (total == 0) return hipSuccess;
-    ClassTable ct;
-    memset(&ct, 0, sizeof(ct));
     uint32_t wgs = 0;
     for (int i = 0; i < n; ++i) {
         if (!items[i]) continue;
@@ -886,21 +941,41 @@ hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs
     }
     ct.wg_begin[ct.n_classes] = wgs;
     for (uint32_t k = ct.n_classes + 1; k < 6; ++k) ct.wg_begin[k] = 0xffffffffu;
+}
+
+namespace {
+template <int F>
+void set_lds_attr() {
+    constexpr size_t bytes = FamCfg<F>::WORDS * sizeof(float);
+    if constexpr (bytes > 65536) {  // > 64 KiB of dynamic LDS needs the attribute; idempotent and thread-safe
+        static std::once_flag once;
+        std::call_once(once, [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&transform_items_kernel<F, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&transform_items_kernel<F, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&transform_items_batch_kernel<F>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        });
+    }
+}
+}  // namespace
+
+hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs& a, const uint4* entries,
+                                  const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT],
+                                  uint32_t num_cus, int wgs_per_cu) {
+    if (family < 0 || family > 3) return hipErrorInvalidValue;
+    ClassTable ct;
+    build_class_table(family, class_first, list_count, num_cus, wgs_per_cu, &ct);
+    const uint32_t wgs = ct.wg_begin[ct.n_classes];
+    if (!ct.n_classes || !wgs) return hipSuccess;
     const bool pipe = wgs_per_cu > 0;
-#define LAUNCH(F)                                                                                              \
-    do {                                                                                                       \
-        constexpr size_t bytes = FamCfg<F>::WORDS * sizeof(float);                                             \
-        if (bytes > 65536) { /* > 64 KiB of dynamic LDS needs the attribute; idempotent and thread-safe */     \
-            static std::once_flag once;                                                                        \
-            std::call_once(once, [] {                                                                          \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&transform_items_kernel<F, true>),     \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);             \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&transform_items_kernel<F, false>),    \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);             \
-            });                                                                                                \
-        }                                                                                                      \
-        if (pipe) transform_items_kernel<F, true><<<wgs, 192, bytes, s>>>(a, ct, entries);                     \
-        else transform_items_kernel<F, false><<<wgs, 192, bytes, s>>>(a, ct, entries);                         \
+#define LAUNCH(F)                                                                          \
+    do {                                                                                   \
+        constexpr size_t bytes = FamCfg<F>::WORDS * sizeof(float);                         \
+        set_lds_attr<F>();                                                                 \
+        if (pipe) transform_items_kernel<F, true><<<wgs, 192, bytes, s>>>(a, ct, entries); \
+        else transform_items_kernel<F, false><<<wgs, 192, bytes, s>>>(a, ct, entries);     \
     } while (0)
     switch (family) {
         case 0: LAUNCH(0); break;
@@ -909,6 +984,24 @@ hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs
         default: LAUNCH(3); break;
     }
 #undef LAUNCH
+    return hipGetLastError();
+}
+
+// All four families + the special 8x8 family of n frames: long work items first, the bulk last.
+hipError_t launch_transform_batch(hipStream_t s, const FrameBatch& b, uint32_t n, const uint32_t max_wgs[4],
+                                  uint32_t max_special) {
+#define LAUNCHB(F)                                                                                          \
+    if (max_wgs[F]) {                                                                                       \
+        set_lds_attr<F>();                                                                                  \
+        transform_items_batch_kernel<F><<<dim3(max_wgs[F], n), 192, FamCfg<F>::WORDS * sizeof(float), s>>>(b); \
+    }
+    LAUNCHB(3)
+    LAUNCHB(2)
+    if (max_special)
+        transform_special_batch_kernel<<<dim3(ceil_div(max_special, kSpecialPerWave), n), 64, 0, s>>>(b);
+    LAUNCHB(1)
+    LAUNCHB(0)
+#undef LAUNCHB
     return hipGetLastError();
 }
 

@@ -5,10 +5,10 @@
 
 // ---------------------------------------------------------------- V1 + V2
 // copy_lf_dequant (jxl-render/src/vardct/mod.rs:387-412) + chroma_from_luma_lf (:544-568).
-__global__ __launch_bounds__(256) void lf_dequant_cfl_kernel(LfArgs a) {
+__device__ __forceinline__ void lf_dequant_cfl_body(const LfArgs& a) {
     uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t y = blockIdx.y;
-    if (x >= a.w8) return;
+    if (x >= a.w8 || y >= a.h8) return;
     uint32_t g = (y / a.group_cells_y) * a.lf_groups_per_row + x / a.group_cells_x;
     size_t i = (size_t)y * a.w8 + x;
     float v[3];
@@ -24,6 +24,12 @@ __global__ __launch_bounds__(256) void lf_dequant_cfl_kernel(LfArgs a) {
     for (int c = 0; c < 3; ++c) a.out[c][i] = v[c];
 }
 
+__global__ __launch_bounds__(256) void lf_dequant_cfl_kernel(LfArgs a) { lf_dequant_cfl_body(a); }
+__global__ __launch_bounds__(256) void lf_dequant_cfl_batch_kernel(FrameBatch b) {
+    const LfArgs a = load_const(&((FrameDevC)b.f[blockIdx.z])->lf);
+    lf_dequant_cfl_body(a);
+}
+
 void launch_lf_dequant_cfl(hipStream_t s, const LfArgs& a) {
     dim3 grid(ceil_div(a.w8, 256), a.h8);
     lf_dequant_cfl_kernel<<<grid, 256, 0, s>>>(a);
@@ -33,11 +39,11 @@ void launch_lf_dequant_cfl(hipStream_t s, const LfArgs& a) {
 // adaptive_lf_smoothing_impl (jxl-render/src/vardct/generic/mod.rs:11-103).  The CPU code runs
 // in place but only ever reads unsmoothed neighbours (udsum scratch + `prev` carry), so it is an
 // out-of-place 3x3 stencil; border samples are copied.
-__global__ __launch_bounds__(256) void lf_smooth_kernel(SmoothArgs a) {
+__device__ __forceinline__ void lf_smooth_body(const SmoothArgs& a) {
     const float SCALE_SELF = 0.052262735f, SCALE_SIDE = 0.2034514f, SCALE_DIAG = 0.03348292f;
     uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t y = blockIdx.y;
-    if (x >= a.w8) return;
+    if (x >= a.w8 || y >= a.h8) return;
     size_t w = a.w8;
     size_t i = (size_t)y * w + x;
     bool interior = a.w8 > 2 && a.h8 > 2 && x >= 1 && x + 1 < a.w8 && y >= 1 && y + 1 < a.h8;
@@ -63,6 +69,21 @@ __global__ __launch_bounds__(256) void lf_smooth_kernel(SmoothArgs a) {
     float gap_scale = fmaxf(3.0f - 4.0f * gap, 0.0f);
 #pragma unroll
     for (int c = 0; c < 3; ++c) a.out[c][i] = (wa[c] - self[c]) * gap_scale + self[c];
+}
+
+__global__ __launch_bounds__(256) void lf_smooth_kernel(SmoothArgs a) { lf_smooth_body(a); }
+__global__ __launch_bounds__(256) void lf_smooth_batch_kernel(FrameBatch b) {
+    const FrameDevC fd = (FrameDevC)b.f[blockIdx.z];
+    if (fd->skip_smooth) return;
+    const SmoothArgs a = load_const(&fd->smooth);
+    lf_smooth_body(a);
+}
+
+hipError_t launch_lf_batch(hipStream_t s, const FrameBatch& b, uint32_t n, uint32_t max_w8, uint32_t max_h8, bool any_smooth) {
+    const dim3 grid(ceil_div(max_w8, 256), max_h8, n);
+    lf_dequant_cfl_batch_kernel<<<grid, 256, 0, s>>>(b);
+    if (any_smooth) lf_smooth_batch_kernel<<<grid, 256, 0, s>>>(b);
+    return hipGetLastError();
 }
 
 void launch_lf_smooth(hipStream_t s, const SmoothArgs& a) {

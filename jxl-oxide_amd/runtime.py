@@ -105,6 +105,23 @@ class Context:
         self._check(self.lib.jxlgpu_vardct_render(self.handle, frame.handle, stages, C.byref(o)))
         return out
 
+    def vardct_render_batch(self, frames, stages):
+        """One launch per stage for all `frames` (asynchronous; results stay on the device)."""
+        arr = (C.c_void_p * len(frames))(*[f.handle for f in frames])
+        self._check(self.lib.jxlgpu_vardct_render_batch(self.handle, arr, len(frames), stages))
+
+    def download_result(self, frame, stages=abi.STAGE_ALL):
+        """Planar f32 result of the frame's last render."""
+        w, h = frame.out_size(stages)
+        out = np.zeros((3, h, w), dtype=np.float32)
+        o = abi.Out()
+        for c in range(3):
+            o.planes[c] = out[c].ctypes.data_as(abi.f32p)
+        o.stride = w
+        o.mem = abi.MEM_HOST
+        self._check(self.lib.jxlgpu_frame_download_result(self.handle, frame.handle, C.byref(o)))
+        return out
+
     def vardct_render_host(self, desc, stages, out_w, out_h, out=None):
         """One-shot host-to-host call.  `out`: optional preallocated (3, out_h, out_w) float32 array
         (a decoder reuses its frame buffers; a fresh np.zeros pays a page fault per 4 KB)."""

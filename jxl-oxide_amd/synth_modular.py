@@ -442,6 +442,12 @@ class ModularWorkload:
             self.buffers = [idx.astype(self.dtype), np.zeros((H, W), self.dtype), np.zeros((H, W), self.dtype)]
             self.expected = None
             self.index_plane, self.palette = idx, pal
+        elif kind == "predictor_random":
+            # single-leaf tree: random small residuals (any residual plane decodes to SOME image; the
+            # oracle defines which).  No Python-side encode, so usable at 8K.
+            self.residual_predictor = predictor
+            self.residual_offset = pred_offset
+            self.buffers = [rng.integers(-3, 4, size=(H, W)).astype(self.dtype) for _ in range(3)]
         elif kind == "raw":
             # arbitrary data straight into the inverse chain: wrapping arithmetic included
             info = np.iinfo(self.dtype)

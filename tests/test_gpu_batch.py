@@ -1,0 +1,73 @@
+"""jxlgpu_vardct_render_batch: N frames, one launch per stage — bit-identical to rendering them one
+by one (and to the oracle), for mixed sizes, and for frames outside the batched default pipeline
+(rendered one by one by the same call)."""
+import numpy as np
+import pytest
+
+from jxl_oxide_amd import abi
+from jxl_oxide_amd.synth import VardctWorkload
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(ctx, wl):
+    f = ctx.vardct_upload(wl.desc())
+    try:
+        return ctx.vardct_render(f, abi.STAGE_ALL)
+    finally:
+        f.free()
+
+
+def test_batch_matches_single_and_oracle(gpu_ctx, oracle):
+    wls = [VardctWorkload(520, 264, seed=1), VardctWorkload(300, 520, seed=2), VardctWorkload(264, 200, seed=3),
+           VardctWorkload(1040, 330, seed=4)]
+    frames = [gpu_ctx.vardct_upload(w.desc()) for w in wls]
+    try:
+        for _ in range(2):  # repeatable from the uploaded state
+            gpu_ctx.vardct_render_batch(frames, abi.STAGE_ALL)
+            gpu_ctx.synchronize()
+            for w, f in zip(wls, frames):
+                got = gpu_ctx.download_result(f)
+                exp, _ = oracle.vardct_render(w.desc(), abi.STAGE_ALL, w.width, w.height)
+                assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (w.width, w.height)
+    finally:
+        for f in frames:
+            f.free()
+
+
+def test_batch_larger_than_one_launch(gpu_ctx):
+    """More frames than one launch takes (JXLGPU_MAX_BATCH = 32): chunks."""
+    wl = VardctWorkload(264, 200, seed=5)
+    ref = _single(gpu_ctx, wl)
+    frames = [gpu_ctx.vardct_upload(wl.desc()) for _ in range(35)]
+    try:
+        gpu_ctx.vardct_render_batch(frames, abi.STAGE_ALL)
+        gpu_ctx.synchronize()
+        for f in (frames[0], frames[31], frames[32], frames[34]):
+            assert np.array_equal(gpu_ctx.download_result(f).view(np.uint32), ref.view(np.uint32))
+    finally:
+        for f in frames:
+            f.free()
+
+
+def test_batch_with_frames_outside_the_default_pipeline(gpu_ctx):
+    """EPF iters 3 / no Gabor / a PQ target do not qualify: the call renders frame by frame."""
+    wls = [VardctWorkload(264, 200, seed=6), VardctWorkload(264, 200, seed=7, epf_iters=3),
+           VardctWorkload(200, 136, seed=8, gabor=False), VardctWorkload(200, 136, seed=9, intensity_target=4000.0, hdr_pq=True)]
+    refs = [_single(gpu_ctx, w) for w in wls]
+    frames = [gpu_ctx.vardct_upload(w.desc()) for w in wls]
+    try:
+        gpu_ctx.vardct_render_batch(frames, abi.STAGE_ALL)
+        gpu_ctx.synchronize()
+        for f, r in zip(frames, refs):
+            assert np.array_equal(gpu_ctx.download_result(f).view(np.uint32), r.view(np.uint32))
+        # a stage mask without the full pipeline: also frame by frame
+        gpu_ctx.vardct_render_batch(frames[:1], abi.STAGE_LF | abi.STAGE_TRANSFORM)
+        gpu_ctx.synchronize()
+        f0 = gpu_ctx.vardct_upload(wls[0].desc())
+        exp = gpu_ctx.vardct_render(f0, abi.STAGE_LF | abi.STAGE_TRANSFORM)
+        f0.free()
+        assert np.array_equal(gpu_ctx.download_result(frames[0]).view(np.uint32), exp.view(np.uint32))
+    finally:
+        for f in frames:
+            f.free()

@@ -41,6 +41,24 @@ def main():
                 ctx.vardct_render(f, stages, to_host=False)
         ms, n = ctx.profile_read()
         print(f"{v or '(default)':50s} transform group {ms / n * 1e3:8.1f} us / frame ({n} frames)", flush=True)
+        # the same frames through the batched launches (all stages: that is what a batch runs)
+        for g, name in ((1, "transform"), (2, "post")):
+            ctx.vardct_render_batch(frames, abi.STAGE_ALL)
+            ctx.synchronize()
+            ctx.profile_select(g)
+            for _ in range(reps):
+                ctx.vardct_render_batch(frames, abi.STAGE_ALL)
+            ms, n = ctx.profile_read()
+            print(f"{'':50s} batched {name:9s} {ms / (n * len(frames)) * 1e3:8.1f} us / frame ({n} batches of {len(frames)})", flush=True)
+        ctx.profile_select(-1)
+        import time
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.vardct_render_batch(frames, abi.STAGE_ALL)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"{'':50s} batched all stages: {dt / (reps * len(frames)) * 1e6:8.1f} us / frame wall = {3840 * 2160 * reps * len(frames) / dt / 1e9:.1f} GP/s", flush=True)
         for f in frames:
             f.free()
         ctx.close()
