@@ -372,7 +372,10 @@ typedef struct {
      * residuals (`unpack_signed` tokens) of that Predictor (jxl-modular/src/predictor.rs:26-41),
      * applied per group_dim x group_dim tile with a fresh PredictorState per tile.  6 =
      * SelfCorrecting with `wp_params`.  MA trees with more than one leaf choose the entropy-coding
-     * context from the neighbours, so they stay with the entropy decoder on the host.             */
+     * context from the neighbours, so they stay with the entropy decoder on the host.
+     * Restriction: only with transform chains made of RCT (or none).  With Squeeze or Palette the
+     * reference predicts every carved sub-channel and meta channel separately, on its own tile grid
+     * (group_dim >> shift, image.rs:209-371); that combination returns JXLGPU_ERR_UNSUPPORTED.     */
     uint32_t residual_predictor;
     int32_t residual_multiplier; /* MaTreeLeafClustered.multiplier (1 for a default leaf)            */
     int32_t residual_offset;     /* MaTreeLeafClustered.offset                                       */

@@ -57,7 +57,7 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
 bool fused_post_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, bool gabor, int epf_iters);
 hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
                          uint32_t in_tiled_w8, float* const out[3], uint32_t out_stride, bool gabor, int epf_iters,
-                         bool color, FusedArgs* pa, bool* stream_out, bool* plain_srgb);
+                         bool color, FusedArgs* pa, bool* stream_out, bool* plain_srgb, int rows_per_seg);
 
 struct UploadOpts {
     uint32_t lfg_cells_x = 0, lfg_cells_y = 0;  // LF group size in cells (0: group_dim)
@@ -289,6 +289,10 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     if (const char* v = getenv("JXLGPU_STREAM_ROWS")) {
         const int r = atoi(v);
         if (r >= 8 && r <= 1024 && r % 4 == 0) ctx->tune.stream_rows = r;
+    }
+    if (const char* v = getenv("JXLGPU_BATCH_STREAM_ROWS")) {
+        const int r = atoi(v);
+        if (r >= 8 && r <= 4096 && r % 4 == 0) ctx->tune.batch_stream_rows = r;
     }
     ctx->tune.no_stream = getenv("JXLGPU_NO_STREAM") != nullptr;
     ctx->tune.no_fused = getenv("JXLGPU_NO_FUSED") != nullptr;
@@ -1172,7 +1176,9 @@ static int ensure_dev_args(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     h.special_count = f->list_count[CLS_SPECIAL8];
     const float* in[3] = {f->pix_t, nullptr, nullptr};
     bool stream = false, plain_srgb = false;
-    HIP_TRY(ctx, fused_prepare(ctx, f, in, f->wr, f->w8, f->buf_a, f->wr, true, 2, true, &h.post, &stream, &plain_srgb));
+    // batched launches have waves to spare: taller wave segments (less halo-row recompute)
+    HIP_TRY(ctx, fused_prepare(ctx, f, in, f->wr, f->w8, f->buf_a, f->wr, true, 2, true, &h.post, &stream, &plain_srgb,
+                               ctx->tune.batch_stream_rows));
     if (!stream || !plain_srgb) return JXLGPU_OK;
     h.post.tiles = f->ring_tiles;
     h.n_ring_tiles = f->n_ring_tiles;

@@ -249,7 +249,32 @@ struct StreamConst {
     float sm1_in, sm1_bd, sm2_in, sm2_bd;
     bool x_bd, store_lane;
     int x, xl, yb;
+    // lane parts of the addresses, in BYTES (a 32-bit byte offset from a uniform base is the
+    // `global_load saddr + voffset` form: no vector address arithmetic per row)
+    uint32_t in_off;   // input: (tiled: cell column * 192 + x & 7; planes: x) * 4
+    uint32_t sig_off;  // sigma: (x >> 3) * 4
+    uint32_t out_off;  // output: x * 4
 };
+
+__device__ __forceinline__ float ld_off(const float* uniform_base, uint32_t byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(uniform_base) + byte_off);
+}
+__device__ __forceinline__ void st_off(float* uniform_base, uint32_t byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(uniform_base) + byte_off) = v;
+}
+
+// Input sample (x = this lane's column, row y) of channel c: uniform row base (scalar unit) + the
+// lane's constant 32-bit offset, so a row costs no vector address arithmetic.
+template <bool TILED>
+__device__ __forceinline__ float load_row_in(const FusedArgs& a, const StreamConst& k, int c, int y) {
+    if constexpr (TILED) {
+        const float* rowbase = a.in[0] + ((size_t)(uint32_t)(y >> 3) * a.in_w8 * 192u + (uint32_t)((y & 7) << 3) + (uint32_t)c * 64u);
+        return ld_off(rowbase, k.in_off);
+    } else {
+        const float* rowbase = a.in[c] + (size_t)y * a.in_stride;
+        return ld_off(rowbase, k.in_off);
+    }
+}
 
 // One row step; P = (j - j_start) & 3 is a compile-time phase so every ring slot below is a
 // fixed register (no rotation moves).
@@ -263,12 +288,13 @@ __device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst
     {
         int jn = min(j + 1, a.height - 1);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) st.nxt[c] = load_in<TILED>(a, c, k.xl, jn);
+        for (int c = 0; c < 3; ++c) st.nxt[c] = load_row_in<TILED>(a, k, c, jn);
         // sigma of row e+1 = j-2 for the next step; this step's f = e-1 reuses the previous e
         st.sig_f = st.sig_e; st.inv_f = st.inv_e;
         st.sig_e = st.sig_nxt; st.inv_e = st.inv_nxt;
         if (((j - 2) & 7) == 0) {  // wave-uniform: a new row of 8x8 cells starts
-            st.sig_nxt = a.sigma[(size_t)((j - 2) >> 3) * a.sigma_stride + (k.xl >> 3)];
+            const float* srow = a.sigma + (size_t)(uint32_t)((j - 2) >> 3) * a.sigma_stride;  // uniform
+            st.sig_nxt = ld_off(srow, k.sig_off);
             st.inv_nxt = k.K / st.sig_nxt;
         }
     }
@@ -386,15 +412,17 @@ __device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst
             if constexpr (TF == JXLGPU_TF_SRGB) color_pixel_srgb_lut(a.color, o, srgb_lut);
             else color_pixel(a.color, o);
         }
-        size_t go = (size_t)f * a.out_stride + k.x;
+        const size_t orow = (size_t)(uint32_t)f * a.out_stride;  // uniform
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a.out[c][go] = o[c];
+        for (int c = 0; c < 3; ++c) st_off(a.out[c] + orow, k.out_off, o[c]);
     }
 }
 
 template <int TF, bool TILED>
 __device__ __forceinline__ void post_stream_body(const FusedArgs& a, const uint32_t* srgb_lut) {
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // readfirstlane: the wave index is uniform, and telling the compiler so turns the whole row
+    // bookkeeping (row index, 8x8 border tests, row base addresses) into scalar-unit work
+    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int strip = wave % a.strips, seg = wave / a.strips;
     if (seg >= a.segs) return;
@@ -404,6 +432,9 @@ __device__ __forceinline__ void post_stream_body(const FusedArgs& a, const uint3
     k.yb = a.sy0 + seg * a.rows_per_seg;
     const int ye = min(k.yb + a.rows_per_seg, a.sy1);
     k.store_lane = lane >= SH && lane < SH + SW && k.x < a.sx1;
+    k.in_off = (TILED ? (uint32_t)(k.xl >> 3) * 192u + (uint32_t)(k.xl & 7) : (uint32_t)k.xl) * 4u;
+    k.sig_off = (uint32_t)(k.xl >> 3) * 4u;
+    k.out_off = (uint32_t)k.x * 4u;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         k.gw0[c] = a.fp.gab_weights[c][0];
@@ -425,12 +456,12 @@ __device__ __forceinline__ void post_stream_body(const FusedArgs& a, const uint3
         for (int c = 0; c < 3; ++c) st.I[i][c] = st.G[i][c] = st.V[i][c] = st.H[i][c] = st.E[i][c] = st.Wd[i][c] = 0.0f;
     {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) st.nxt[c] = load_in<TILED>(a, c, k.xl, k.yb - SH);
+        for (int c = 0; c < 3; ++c) st.nxt[c] = load_row_in<TILED>(a, k, c, k.yb - SH);
         // first step is j = yb-SH with e = j-3: sig_nxt must hold sigma(row j-3) when it rotates in
         st.sig_e = st.sig_f = 1.0f;
         st.inv_e = st.inv_f = 0.0f;
         st.d1_dn = st.d2_dn = 0.0f;
-        st.sig_nxt = a.sigma[(size_t)((k.yb - SH - 3) >> 3) * a.sigma_stride + (k.xl >> 3)];
+        st.sig_nxt = ld_off(a.sigma + (size_t)(uint32_t)((k.yb - SH - 3) >> 3) * a.sigma_stride, k.sig_off);
         st.inv_nxt = k.K / st.sig_nxt;
     }
     // (ye - yb) and 2*SH are multiples of 4: whole groups of four phases
@@ -499,7 +530,7 @@ bool fused_post_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, bool gab
 // use).  *plain_srgb: the colour tail is the plain XYB -> sRGB list (branch-free epilogue).
 hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
                          uint32_t in_tiled_w8, float* const out[3], uint32_t out_stride, bool gabor, int epf_iters,
-                         bool color, FusedArgs* pa, bool* stream_out, bool* plain_srgb) {
+                         bool color, FusedArgs* pa, bool* stream_out, bool* plain_srgb, int rows_per_seg) {
     FusedArgs& a = *pa;
     memset(&a, 0, sizeof(a));
     for (int c = 0; c < 3; ++c) { a.in[c] = in[c]; a.out[c] = out[c]; }
@@ -539,7 +570,7 @@ hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in
     *stream_out = stream;
     if (stream) {
         a.sx0 = T; a.sx1 = T * tx_hi; a.sy0 = T; a.sy1 = T * ty_hi;
-        a.rows_per_seg = ctx ? ctx->tune.stream_rows : 48;
+        a.rows_per_seg = rows_per_seg > 0 ? rows_per_seg : (ctx ? ctx->tune.stream_rows : 48);
         a.strips = (a.sx1 - a.sx0 + SW - 1) / SW;
         a.segs = (a.sy1 - a.sy0 + a.rows_per_seg - 1) / a.rows_per_seg;
     }
@@ -558,7 +589,7 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
     FusedArgs a;
     bool stream = false, plain_srgb = false;
     hipError_t e = fused_prepare(ctx, f, in, in_stride, in_tiled_w8, out, out_stride, gabor, epf_iters, color, &a, &stream,
-                                 &plain_srgb);
+                                 &plain_srgb, 0);
     if (e != hipSuccess) return e;
     if (!stream) return launch_tile_kernel(s, a, gabor, epf_iters, dim3(ceil_div(f->width, T), ceil_div(f->height, T)));
     const int waves = a.strips * a.segs;

@@ -1370,6 +1370,40 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
     if (d->xyb_encoded)
         if (const char* why = color_params_unsupported(d->color)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, why);
     if (d->residual_predictor <= 13 && d->group_dim > 256) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tiles larger than 256");
+    if (d->num_transforms && !d->transforms) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null transform list");
+    if (d->num_meta_channels && !d->meta_channels) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null meta channel list");
+    for (uint32_t c = 0; c < d->num_meta_channels; ++c)
+        if (!d->meta_channels[c].data || !d->meta_channels[c].width || !d->meta_channels[c].height)
+            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "empty meta channel");
+    {
+        // The separable predictor pass (M4) runs on whole top-level channel buffers in group_dim
+        // tiles.  With Squeeze or Palette in the chain the reference predicts every carved
+        // sub-channel / meta channel on its own tile grid (group_dim >> shift,
+        // jxl-modular/src/image.rs:209-371): not the same image, so that combination stays on the
+        // caller's CPU path instead of silently decoding something else.
+        uint32_t meta_used = 0;
+        for (uint32_t t = 0; t < d->num_transforms; ++t) {
+            const JxlGpuTransform& tr = d->transforms[t];
+            if (tr.kind > JXLGPU_TR_SQUEEZE) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "unknown transform kind");
+            if (d->residual_predictor <= 13 && (tr.kind == JXLGPU_TR_SQUEEZE || tr.kind == JXLGPU_TR_PALETTE))
+                return fail(ctx, JXLGPU_ERR_UNSUPPORTED,
+                            "residual_predictor together with Squeeze / Palette (the reference predicts each carved sub-channel separately)");
+            if (tr.kind == JXLGPU_TR_PALETTE) {
+                if (meta_used >= d->num_meta_channels) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "Palette transform without its meta channel");
+                const JxlGpuModularChannel& mc = d->meta_channels[meta_used++];
+                if (mc.width < tr.nb_colours || mc.height < tr.num_c)
+                    return fail(ctx, JXLGPU_ERR_INVALID_ARG, "palette meta channel smaller than nb_colours x num_c");
+            }
+        }
+    }
+    {
+        const uint32_t upf = d->upsampling.factor ? d->upsampling.factor : 1;
+        if (upf != 1 && upf != 2 && upf != 4 && upf != 8) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "bad upsampling factor");
+        const float* need = upf == 2 ? d->upsampling.up2_weight : upf == 4 ? d->upsampling.up4_weight
+                          : upf == 8 ? d->upsampling.up8_weight : (const float*)d;
+        if (!need) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "upsampling weights missing");
+        if (d->filter.epf_iters > 3) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "epf_iters > 3");
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     jxlgpu_frame* f = new (std::nothrow) jxlgpu_frame();
     ModularState* m = new (std::nothrow) ModularState();

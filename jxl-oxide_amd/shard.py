@@ -107,3 +107,29 @@ def gather_formatted(ctx, frame, sample_format, orientation=1, dst=0, group=None
                                                   abi.MEM_DEVICE, C.byref(rw), C.byref(rh)))
     ctx.synchronize()
     return gather_planes(local, dst=dst, group=group)
+
+
+def gather_formatted_batch(ctx, frames, sample_format, orientation=1, dst=0, group=None):
+    """Config 4's stitched output: every frame of this rank formatted on the device into ONE tensor
+    (n, h, w, 3), then ONE gather to `dst` (RCCL over xGMI for world > 1; nothing to move for
+    world == 1).  Frames must have the same size.  Returns the list of per-rank tensors on `dst`."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    from . import abi
+    w, h = frames[0].out_size(abi.STAGE_ALL)
+    ow, oh = (w, h) if orientation <= 4 else (h, w)
+    dt = {abi.FMT_F32: torch.float32, abi.FMT_U16: torch.uint16, abi.FMT_U8: torch.uint8}[sample_format]
+    local = torch.empty((len(frames), oh, ow, 3), dtype=dt, device="cuda")
+    fmt = abi.FormatDesc(sample_format, orientation)
+    rw, rh = C.c_uint32(), C.c_uint32()
+    step = local[0].numel() * local.element_size()
+    for i, f in enumerate(frames):
+        ctx._check(ctx.lib.jxlgpu_frame_format_output(ctx.handle, f.handle, C.byref(fmt), local.data_ptr() + i * step,
+                                                      abi.MEM_DEVICE, C.byref(rw), C.byref(rh)))
+    ctx.synchronize()
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [local]
+    return gather_planes(local, dst=dst, group=group)

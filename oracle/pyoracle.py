@@ -10,7 +10,20 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "_build", "liboracle.so")
 f32p = C.POINTER(C.c_float)
+_LIB_NATIVE = os.path.join(_HERE, "_build", "liboracle_native.so")
 _lib = None
+
+
+def use_native(on=True):
+    """Switch to the -O3 -march=native build (the cpu_baseline timing copy; `make -C oracle native`
+    on this box first).  Bit-identical results: tests/test_oracle_native.py."""
+    global _LIB, _lib
+    if on:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "native"])
+        _LIB = _LIB_NATIVE
+    else:
+        _LIB = os.path.join(_HERE, "_build", "liboracle.so")
+    _lib = None
 
 
 def build(force=False):

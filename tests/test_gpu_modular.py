@@ -206,3 +206,40 @@ print("FIXUP_OK")
     assert "FIXUP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     redone = [int(l.rsplit(":", 1)[1]) for l in r.stderr.splitlines() if "redone serially" in l]
     assert sum(redone) > 0, "the test did not exercise the serial fix-up path"
+
+
+def test_upload_rejects_what_the_device_path_would_get_wrong(gpu_ctx):
+    """Descriptor validation of jxlgpu_modular_upload: predictor + Squeeze / Palette is
+    UNSUPPORTED (the reference predicts each carved sub-channel separately); malformed upsampling /
+    EPF / meta-channel parameters are INVALID_ARG instead of out-of-bounds device accesses."""
+    from jxl_oxide_amd.runtime import JxlGpuError
+    wl = ModularWorkload(64, 48, kind="squeeze", lossy=False, xyb=False, seed=1)
+    wl.residual_predictor = 5
+    with pytest.raises(JxlGpuError) as e:
+        gpu_ctx.modular_upload(wl.desc())
+    assert e.value.code == abi.ERR_UNSUPPORTED
+    wl = ModularWorkload(64, 48, kind="squeeze", lossy=False, xyb=False, seed=1)
+    d = wl.desc()
+    d.upsampling.factor = 3
+    with pytest.raises(JxlGpuError) as e:
+        gpu_ctx.modular_upload(d)
+    assert e.value.code == abi.ERR_INVALID_ARG
+    d = wl.desc()
+    d.filter.epf_iters = 4
+    with pytest.raises(JxlGpuError) as e:
+        gpu_ctx.modular_upload(d)
+    assert e.value.code == abi.ERR_INVALID_ARG
+    d = wl.desc()
+    d.upsampling.factor = 2  # weights missing
+    with pytest.raises(JxlGpuError) as e:
+        gpu_ctx.modular_upload(d)
+    assert e.value.code == abi.ERR_INVALID_ARG
+
+
+def test_all_rct_codes(gpu_ctx, oracle):
+    """M2: all 42 RCT codes (7 types x 6 permutations), lossless round trip through the device."""
+    for rct_type in range(42):
+        wl = ModularWorkload(72, 40, kind="squeeze", lossy=False, xyb=False, rct_type=rct_type, seed=rct_type)
+        got = _inverse_both(gpu_ctx, oracle, wl)
+        for c in range(3):
+            assert np.array_equal(got[c], wl.expected[c]), rct_type
