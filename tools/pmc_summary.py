@@ -14,5 +14,5 @@ for d in sys.argv[1:]:
 for k, cs in acc.items():
     if "rocclr" in k or "at::native" in k:
         continue
-    name = k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+    name = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     print(name[:60], " ".join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(cs.items())), f"n={len(next(iter(cs.values())))}")
