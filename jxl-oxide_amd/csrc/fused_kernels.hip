@@ -278,7 +278,7 @@ __device__ __forceinline__ float load_row_in(const FusedArgs& a, const StreamCon
 
 // One row step; P = (j - j_start) & 3 is a compile-time phase so every ring slot below is a
 // fixed register (no rotation moves).
-template <int P, int TF, bool TILED>
+template <int P, int TF, bool TILED, bool GAB>
 __device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst& k, StreamState& st, int j,
                                            const uint32_t* srgb_lut) {
     constexpr int s0 = P & 3, sm1 = (P + 3) & 3, sm2 = (P + 2) & 3, sm3 = (P + 1) & 3;  // rows j, j-1, j-2, j-3 (== j-4 -> s0)
@@ -303,9 +303,14 @@ __device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float It = st.I[sm2][c], Ic = st.I[sm1][c], Ib = st.I[s0][c];
-        float sum_side = It + from_left(Ic) + from_right(Ic) + Ib;
-        float sum_diag = from_left(It) + from_right(It) + from_left(Ib) + from_right(Ib);
-        float g = (Ic + sum_side * k.gw0[c] + sum_diag * k.gw1[c]) * k.ggw[c];
+        float g;
+        if constexpr (GAB) {
+            float sum_side = It + from_left(Ic) + from_right(Ic) + Ib;
+            float sum_diag = from_left(It) + from_right(It) + from_left(Ib) + from_right(Ib);
+            g = (Ic + sum_side * k.gw0[c] + sum_diag * k.gw1[c]) * k.ggw[c];
+        } else {
+            g = Ic;  // no Gabor-like stage (Modular frames): the EPF reads the input rows directly
+        }
         st.V[sm1][c] = fabsf(g - st.G[sm2][c]);
         st.G[sm1][c] = g;
         st.H[sm1][c] = fabsf(g - from_left(g));
@@ -418,7 +423,7 @@ __device__ __forceinline__ void stream_row(const FusedArgs& a, const StreamConst
     }
 }
 
-template <int TF, bool TILED>
+template <int TF, bool TILED, bool GAB>
 __device__ __forceinline__ void post_stream_body(const FusedArgs& a, const uint32_t* srgb_lut) {
     // readfirstlane: the wave index is uniform, and telling the compiler so turns the whole row
     // bookkeeping (row index, 8x8 border tests, row base addresses) into scalar-unit work
@@ -466,19 +471,19 @@ __device__ __forceinline__ void post_stream_body(const FusedArgs& a, const uint3
     }
     // (ye - yb) and 2*SH are multiples of 4: whole groups of four phases
     for (int j = k.yb - SH; j < ye + SH; j += 4) {
-        stream_row<0, TF, TILED>(a, k, st, j, srgb_lut);
-        stream_row<1, TF, TILED>(a, k, st, j + 1, srgb_lut);
-        stream_row<2, TF, TILED>(a, k, st, j + 2, srgb_lut);
-        stream_row<3, TF, TILED>(a, k, st, j + 3, srgb_lut);
+        stream_row<0, TF, TILED, GAB>(a, k, st, j, srgb_lut);
+        stream_row<1, TF, TILED, GAB>(a, k, st, j + 1, srgb_lut);
+        stream_row<2, TF, TILED, GAB>(a, k, st, j + 2, srgb_lut);
+        stream_row<3, TF, TILED, GAB>(a, k, st, j + 3, srgb_lut);
     }
 }
 
-template <int TF, bool TILED>
+template <int TF, bool TILED, bool GAB>
 __global__ __launch_bounds__(256) void post_stream_kernel(FusedArgs a) {
     __shared__ uint32_t srgb_lut[16];
     if (threadIdx.x < 16) srgb_lut[threadIdx.x] = kSrgbMulBits[threadIdx.x];
     __syncthreads();
-    post_stream_body<TF, TILED>(a, srgb_lut);
+    post_stream_body<TF, TILED, GAB>(a, srgb_lut);
 }
 
 // n frames in one launch (blockIdx.y = frame): plain XYB -> sRGB from the cell-tiled transform output
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(256) void post_stream_batch_kernel(FrameBatch b) {
     if (threadIdx.x < 16) srgb_lut[threadIdx.x] = kSrgbMulBits[threadIdx.x];
     __syncthreads();
     const FusedArgs a = load_const(&((FrameDevC)b.f[blockIdx.y])->post);
-    post_stream_body<JXLGPU_TF_SRGB, true>(a, srgb_lut);
+    post_stream_body<JXLGPU_TF_SRGB, true, true>(a, srgb_lut);
 }
 
 template <bool GAB, int ITERS>
@@ -542,14 +547,14 @@ hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in
     a.color = f->color;
     a.do_color = color ? 1u : 0u;
     a.tiles = nullptr;
-    // Default configuration (Gabor + 2 EPF steps) on a frame with an interior: the streaming
-    // kernel takes everything except the outer ring of tiles.
+    // EPF steps 1, 2 (with or without the Gabor-like stage in front) on a frame with an interior: the
+    // streaming kernel takes everything except the outer ring of tiles.
     const int ntx = (int)ceil_div(f->width, T), nty = (int)ceil_div(f->height, T);
     int tx_hi = ntx - 1, ty_hi = nty - 1;
     while (tx_hi > 1 && T * tx_hi + SH > (int)f->width) --tx_hi;
     while (ty_hi > 1 && T * ty_hi + SH > (int)f->height) --ty_hi;
     const bool no_stream = ctx && ctx->tune.no_stream;
-    bool stream = gabor && epf_iters == 2 && tx_hi > 1 && ty_hi > 1 && !no_stream;
+    bool stream = epf_iters == 2 && tx_hi > 1 && ty_hi > 1 && !no_stream;
     if (stream && !f->ring_tiles) {
         std::vector<uint32_t> ring;
         for (int ty = 0; ty < nty; ++ty)
@@ -596,23 +601,27 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
     const bool side = ctx && ctx->stream2;
     if (side && (e = hipEventRecord(ctx->ev_fork, s)) != hipSuccess) return e;  // inputs are ready here
     const dim3 sgrid((waves + 3) / 4);
+#define STREAM(TF, TILED)                                                            \
+    do {                                                                              \
+        if (gabor) post_stream_kernel<TF, TILED, true><<<sgrid, 256, 0, s>>>(a);      \
+        else post_stream_kernel<TF, TILED, false><<<sgrid, 256, 0, s>>>(a);           \
+    } while (0)
     if (a.in_w8) {
-        if (plain_srgb) post_stream_kernel<JXLGPU_TF_SRGB, true><<<sgrid, 256, 0, s>>>(a);
-        else post_stream_kernel<-1, true><<<sgrid, 256, 0, s>>>(a);
+        if (plain_srgb) STREAM(JXLGPU_TF_SRGB, true); else STREAM(-1, true);
     } else {
-        if (plain_srgb) post_stream_kernel<JXLGPU_TF_SRGB, false><<<sgrid, 256, 0, s>>>(a);
-        else post_stream_kernel<-1, false><<<sgrid, 256, 0, s>>>(a);
+        if (plain_srgb) STREAM(JXLGPU_TF_SRGB, false); else STREAM(-1, false);
     }
+#undef STREAM
     if ((e = hipGetLastError()) != hipSuccess) return e;
     a.tiles = f->ring_tiles;
     // the border ring (a few hundred long-latency tiles) runs beside the streaming kernel
     if (side) {
         if ((e = hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0)) != hipSuccess) return e;
-        if ((e = launch_tile_kernel(ctx->stream2, a, true, 2, dim3(f->n_ring_tiles))) != hipSuccess) return e;
+        if ((e = launch_tile_kernel(ctx->stream2, a, gabor, 2, dim3(f->n_ring_tiles))) != hipSuccess) return e;
         if ((e = hipEventRecord(ctx->ev_join, ctx->stream2)) != hipSuccess) return e;
         return hipStreamWaitEvent(s, ctx->ev_join, 0);
     }
-    return launch_tile_kernel(s, a, true, 2, dim3(f->n_ring_tiles));
+    return launch_tile_kernel(s, a, gabor, 2, dim3(f->n_ring_tiles));
 }
 
 // Default pipeline of n frames: streaming kernel on `s`, border rings beside it on `side` (may be

@@ -235,12 +235,9 @@ struct SegArgs {
 };
 
 template <typename S>
-__global__ __launch_bounds__(64) void squeeze_v_seg_kernel(SegArgs g) {
+__device__ __forceinline__ void squeeze_v_seg_body(const SegArgs& g, uint32_t x, uint32_t seg) {
     constexpr int PF = 16, OV = 16;
     const SqzArgs& a = g.a;
-    const uint32_t x = blockIdx.x * 64 + threadIdx.x;
-    if (x >= a.width) return;
-    const uint32_t seg = blockIdx.y;
     const S* avgp = (const S*)a.avg + x;
     const S* resp = (const S*)a.res + x;
     S* out = (S*)a.out + x;
@@ -326,15 +323,12 @@ __device__ __forceinline__ void squeeze_v_line(const SqzArgs& a, uint32_t x) {
 
 // Horizontal, vector path only (16-byte aligned rectangles): lane = row, blockIdx.y = segment.
 template <typename S>
-__global__ __launch_bounds__(64) void squeeze_h_seg_kernel(SegArgs g) {
+__device__ __forceinline__ void squeeze_h_seg_body(const SegArgs& g, uint32_t y, uint32_t seg) {
     constexpr int N = 16 / sizeof(S);
     constexpr int OV = 8;  // pairs of run-in (multiple of N)
     using V = int4;
     union Pack { V v; S s[N]; };
     const SqzArgs& a = g.a;
-    const uint32_t y = blockIdx.x * 64 + threadIdx.x;
-    if (y >= a.height) return;
-    const uint32_t seg = blockIdx.y;
     const uint32_t avg_w = (a.width + 1) / 2, pairs = a.width / 2;
     const S* avgp = (const S*)a.avg + (size_t)y * a.avg_stride;
     const S* resp = (const S*)a.res + (size_t)y * a.res_stride;
@@ -412,6 +406,165 @@ __global__ __launch_bounds__(64) void squeeze_check_kernel(SegArgs g, int* redo_
     if (redo_count) atomicAdd(redo_count, 1);
     if (HORIZONTAL) squeeze_h_line<S>(g.a, i);
     else squeeze_v_line<S>(g.a, i);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round-2 forms of the segment kernels: up to three channels of one squeeze step in ONE launch
+// (blockIdx.z picks the channel: the channels of a step are independent), and a vertical kernel in
+// which a lane owns NC adjacent columns instead of one: the one-column form moves 2 bytes per lane
+// per load with 16-bit samples (a 128-byte line per wave instruction).  NC is a trade: wider loads
+// against fewer, longer lanes (NC = 8 left an 8K step with 240 waves per channel: measured 2x slower
+// than NC = 1); two 16-bit columns per lane keep ~1000 waves per channel and halve the memory
+// instructions.
+struct SegArgs3 {
+    SegArgs g[3];
+};
+
+template <int BYTES> struct VecOf;
+template <> struct VecOf<4> { using type = uint32_t; };
+template <> struct VecOf<8> { using type = uint2; };
+template <> struct VecOf<16> { using type = int4; };
+
+template <typename S, int NC>
+__global__ __launch_bounds__(64) void squeeze_v_seg3_kernel(SegArgs3 g3) {
+    constexpr int PF = 16 / NC < 4 ? 4 : 16 / NC, OV = 16;
+    using V = typename VecOf<NC * sizeof(S)>::type;
+    union Pack { V v; S s[NC]; };
+    const SegArgs& g = g3.g[blockIdx.z];
+    const SqzArgs& a = g.a;
+    const uint32_t nvec = a.width / NC, rem = a.width - nvec * NC;
+    const uint32_t lane_id = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t seg = blockIdx.y;
+    if (seg >= g.nseg || lane_id >= nvec + rem) return;
+    S* chk = (S*)g.chk;
+    const uint32_t avg_h = (a.height + 1) / 2, pairs = a.height / 2;
+    const uint32_t y_s = seg * g.seg_pairs;
+    const uint32_t y_e = (seg + 1 == g.nseg) ? pairs : y_s + g.seg_pairs;
+    uint32_t y = (seg == 0 || !g.runin) ? y_s : y_s - OV;
+    if (lane_id >= nvec) {
+        // the last width % NC columns: one column per lane
+        const uint32_t x = nvec * NC + (lane_id - nvec);
+        const S* avgp = (const S*)a.avg + x;
+        const S* resp = (const S*)a.res + x;
+        S* out = (S*)a.out + x;
+        S avg = avgp[(size_t)y * a.avg_stride];
+        S top = y == 0 ? avg : avgp[(size_t)(y - 1) * a.avg_stride];
+        for (; y < y_e; ++y) {
+            if (y == y_s) chk[((size_t)seg * 2 + 0) * a.width + x] = top;
+            S r = resp[(size_t)y * a.res_stride];
+            S next_avg = (y + 1 < avg_h) ? avgp[(size_t)(y + 1) * a.avg_stride] : avg;
+            S first, second;
+            squeeze_pair<S>(r, next_avg, avg, top, first, second);
+            if (y >= y_s) {
+                out[(size_t)(2 * y) * a.out_stride] = first;
+                out[(size_t)(2 * y + 1) * a.out_stride] = second;
+            }
+        }
+        chk[((size_t)seg * 2 + 1) * a.width + x] = top;
+        if (seg + 1 == g.nseg && (a.height & 1))
+            out[(size_t)(a.height - 1) * a.out_stride] = avgp[(size_t)(avg_h - 1) * a.avg_stride];
+        return;
+    }
+    const uint32_t x0 = lane_id * NC;
+    const S* avgp = (const S*)a.avg + x0;
+    const S* resp = (const S*)a.res + x0;
+    S* out = (S*)a.out + x0;
+    Pack avg, top;
+    avg.v = *reinterpret_cast<const V*>(avgp + (size_t)y * a.avg_stride);
+    if (y == 0) top = avg;  // exact; otherwise the guess: the previous pair's average
+    else top.v = *reinterpret_cast<const V*>(avgp + (size_t)(y - 1) * a.avg_stride);
+    auto step = [&](const Pack& r, const Pack& n, uint32_t yy, bool has_next) __attribute__((always_inline)) {
+        Pack o0, o1;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            S next_avg = has_next ? n.s[j] : avg.s[j];
+            squeeze_pair<S>(r.s[j], next_avg, avg.s[j], top.s[j], o0.s[j], o1.s[j]);
+        }
+        if (yy >= y_s) {
+            *reinterpret_cast<V*>(out + (size_t)(2 * yy) * a.out_stride) = o0.v;
+            *reinterpret_cast<V*>(out + (size_t)(2 * yy + 1) * a.out_stride) = o1.v;
+        }
+    };
+    auto put_chk = [&](uint32_t which) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) chk[((size_t)seg * 2 + which) * a.width + x0 + j] = top.s[j];
+    };
+    for (; y + PF <= y_e; y += PF) {
+        if (y == y_s) put_chk(0);
+        Pack r[PF], n[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            r[k].v = *reinterpret_cast<const V*>(resp + (size_t)(y + k) * a.res_stride);
+            const uint32_t ny = min(y + k + 1, avg_h - 1);
+            n[k].v = *reinterpret_cast<const V*>(avgp + (size_t)ny * a.avg_stride);
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) step(r[k], n[k], y + k, y + k + 1 < avg_h);
+    }
+    for (; y < y_e; ++y) {
+        if (y == y_s) put_chk(0);
+        Pack r, n;
+        r.v = *reinterpret_cast<const V*>(resp + (size_t)y * a.res_stride);
+        n.v = *reinterpret_cast<const V*>(avgp + (size_t)min(y + 1, avg_h - 1) * a.avg_stride);
+        step(r, n, y, y + 1 < avg_h);
+    }
+    put_chk(1);
+    if (seg + 1 == g.nseg && (a.height & 1))
+        *reinterpret_cast<V*>(out + (size_t)(a.height - 1) * a.out_stride) =
+            *reinterpret_cast<const V*>(avgp + (size_t)(avg_h - 1) * a.avg_stride);
+}
+
+template <typename S, bool HORIZONTAL>
+__global__ __launch_bounds__(64) void squeeze_seg3_kernel(SegArgs3 g3) {
+    const SegArgs& g = g3.g[blockIdx.z];
+    const uint32_t lines = HORIZONTAL ? g.a.height : g.a.width;
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= lines || blockIdx.y >= g.nseg) return;
+    if (HORIZONTAL) squeeze_h_seg_body<S>(g, i, blockIdx.y);
+    else squeeze_v_seg_body<S>(g, i, blockIdx.y);
+}
+
+template <typename S, bool HORIZONTAL>
+__global__ __launch_bounds__(64) void squeeze_check3_kernel(SegArgs3 g3, int* redo_count) {
+    const SegArgs& g = g3.g[blockIdx.y];
+    const uint32_t lines = HORIZONTAL ? g.a.height : g.a.width;
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= lines) return;
+    const S* chk = (const S*)g.chk;
+    bool ok = true;
+    for (uint32_t s = 1; s < g.nseg; ++s)
+        ok &= chk[((size_t)s * 2 + 0) * lines + i] == chk[((size_t)(s - 1) * 2 + 1) * lines + i];
+    if (ok) return;
+    if (redo_count) atomicAdd(redo_count, 1);
+    if (HORIZONTAL) squeeze_h_line<S>(g.a, i);
+    else squeeze_v_line<S>(g.a, i);
+}
+
+// The smallest levels of the pyramid (chains of a few dozen pairs, a few hundred lines) are pure
+// launch latency as kernels of their own: one workgroup per channel walks all of them, one lane
+// per line, a workgroup barrier between levels (the data goes through L2; a level is a few KB).
+constexpr int kChainMaxSteps = 16;
+struct ChainArgs {
+    SqzArgs a[3][kChainMaxSteps];
+    uint32_t horizontal[3][kChainMaxSteps];
+    uint32_t n[3];
+};
+
+template <typename S>
+__global__ __launch_bounds__(1024) void squeeze_chain_kernel(ChainArgs c) {
+    const uint32_t ch = blockIdx.x;
+    const uint32_t n = c.n[ch];
+    for (uint32_t i = 0; i < n; ++i) {
+        const SqzArgs a = c.a[ch][i];
+        const bool horizontal = c.horizontal[ch][i] != 0;
+        const uint32_t lines = horizontal ? a.height : a.width;
+        for (uint32_t l = threadIdx.x; l < lines; l += 1024) {
+            if (horizontal) squeeze_h_line<S>(a, l);
+            else squeeze_v_line<S>(a, l);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------- device: RCT, palette, gradient
@@ -1050,7 +1203,7 @@ struct ModularState {
     size_t esz = 4;
     std::vector<uint32_t> cw, ch;             // channel buffer sizes
     std::vector<void*> orig;                  // uploaded buffers (never modified)
-    std::vector<void*> work[3];               // working copies
+    std::vector<void*> work[4];               // three working copies; [3] aliases `orig` (read-only location)
     std::vector<void*> meta;
     std::vector<uint32_t> mw, mh;
     std::vector<JxlGpuTransform> transforms;
@@ -1098,37 +1251,84 @@ int fail(jxlgpu_ctx* ctx, int code, const char* msg) {
     return code;
 }
 
+// One squeeze step over `count` (<= 3) independent channels.  Long chains are cut into segments
+// (one launch for all channels + one check launch); steps too small for that are appended to
+// `chain` (flushed by the caller as ONE launch for all the small levels) when they are tiny, or run
+// through the whole-line kernels.
+struct SqueezePlan {
+    ChainArgs chain;
+    bool chain_used = false;
+};
+
 template <typename S>
-void launch_squeeze(hipStream_t s, const Tuning& tune, bool horizontal, const SqzArgs& a, void* chk, size_t chk_bytes,
-                    int* redo_count) {
-    const int seg_env = tune.sqz_seg;  // pairs per segment
+void flush_chain(hipStream_t s, SqueezePlan& plan) {
+    if (!plan.chain_used) return;
+    squeeze_chain_kernel<S><<<3, 1024, 0, s>>>(plan.chain);
+    memset(&plan.chain, 0, sizeof(plan.chain));
+    plan.chain_used = false;
+}
+
+template <typename S>
+void launch_squeeze_step(hipStream_t s, const Tuning& tune, bool horizontal, const SqzArgs* a, const int* chain_slot,
+                         int count, void* chk, size_t chk_bytes, int* redo_count, SqueezePlan& plan) {
     auto al = [](const void* p, uint32_t stride) { return ((uintptr_t)p % 16 == 0) && ((stride * sizeof(S)) % 16 == 0); };
-    const bool vec = al(a.avg, a.avg_stride) && al(a.res, a.res_stride) && al(a.out, a.out_stride);
-    const uint32_t len = horizontal ? a.width : a.height, lines = horizontal ? a.height : a.width;
-    const uint32_t pairs = len / 2;
-    // segment length: a multiple of the chunk (16 covers both directions and both sample types)
-    const uint32_t L = seg_env > 0 ? std::max(16u, (uint32_t)seg_env / 16u * 16u) : 0;
-    uint32_t nseg = L ? pairs / L : 0;
-    const bool segmented = nseg >= 2 && (!horizontal || vec) && chk &&
-                           (size_t)nseg * 2 * lines * sizeof(S) <= chk_bytes;
-    if (segmented) {
-        const uint32_t runin = tune.sqz_runin;
-        SegArgs g{a, L, nseg, chk, runin};
-        dim3 grid(ceil_div(lines, 64), nseg);
-        if (horizontal) {
-            squeeze_h_seg_kernel<S><<<grid, 64, 0, s>>>(g);
-            squeeze_check_kernel<S, true><<<ceil_div(lines, 64), 64, 0, s>>>(g, redo_count);
+    SegArgs3 g3;
+    memset(&g3, 0, sizeof(g3));
+    int nseg_ch = 0;
+    uint32_t max_lines = 0, max_nseg = 0;
+    bool all_vec = true;
+    const size_t chk_each = chk_bytes / 3;
+    for (int k = 0; k < count; ++k) {
+        const SqzArgs& ak = a[k];
+        const bool vec = al(ak.avg, ak.avg_stride) && al(ak.res, ak.res_stride) && al(ak.out, ak.out_stride);
+        const uint32_t len = horizontal ? ak.width : ak.height, lines = horizontal ? ak.height : ak.width;
+        const uint32_t pairs = len / 2;
+        // segment length: about an eighth of the chain, a multiple of 16, within [32, JXLGPU_SQZ_SEG]
+        uint32_t L = (pairs / 8 + 15) / 16 * 16;
+        L = std::min<uint32_t>(std::max<uint32_t>(L, 32u), std::max<uint32_t>(32u, (uint32_t)tune.sqz_seg / 16u * 16u));
+        const uint32_t nseg = pairs / L;
+        const uint32_t avg_len = (len + 1) / 2;
+        const bool segmented = nseg >= 2 && (!horizontal || (vec && avg_len >= 2u * (16 / sizeof(S)))) && chk &&
+                               (size_t)nseg * 2 * lines * sizeof(S) <= chk_each;
+        if (segmented) {
+            SegArgs& g = g3.g[nseg_ch];
+            g.a = ak; g.seg_pairs = L; g.nseg = nseg; g.runin = tune.sqz_runin;
+            g.chk = (char*)chk + (size_t)nseg_ch * chk_each;
+            ++nseg_ch;
+            max_lines = std::max(max_lines, lines);
+            max_nseg = std::max(max_nseg, nseg);
+            all_vec &= vec;
+        } else if ((uint64_t)pairs * lines <= (1u << 16) && plan.chain.n[chain_slot[k]] < (uint32_t)kChainMaxSteps) {
+            const int c = chain_slot[k];
+            const uint32_t i = plan.chain.n[c]++;
+            plan.chain.a[c][i] = ak;
+            plan.chain.horizontal[c][i] = horizontal ? 1u : 0u;
+            plan.chain_used = true;
         } else {
-            squeeze_v_seg_kernel<S><<<grid, 64, 0, s>>>(g);
-            squeeze_check_kernel<S, false><<<ceil_div(lines, 64), 64, 0, s>>>(g, redo_count);
+            flush_chain<S>(s, plan);
+            if (horizontal) {
+                if (vec) squeeze_h_kernel<S, true><<<ceil_div(ak.height, 64), 64, 0, s>>>(ak);
+                else squeeze_h_kernel<S, false><<<ceil_div(ak.height, 64), 64, 0, s>>>(ak);
+            } else {
+                squeeze_v_kernel<S><<<ceil_div(ak.width, 64), 64, 0, s>>>(ak);
+            }
         }
-        return;
     }
+    if (!nseg_ch) return;
+    flush_chain<S>(s, plan);  // the segmented step reads what the small levels produced
     if (horizontal) {
-        if (vec) squeeze_h_kernel<S, true><<<ceil_div(a.height, 64), 64, 0, s>>>(a);
-        else squeeze_h_kernel<S, false><<<ceil_div(a.height, 64), 64, 0, s>>>(a);
+        squeeze_seg3_kernel<S, true><<<dim3(ceil_div(max_lines, 64), max_nseg, nseg_ch), 64, 0, s>>>(g3);
+        squeeze_check3_kernel<S, true><<<dim3(ceil_div(max_lines, 64), nseg_ch), 64, 0, s>>>(g3, redo_count);
     } else {
-        squeeze_v_kernel<S><<<ceil_div(a.width, 64), 64, 0, s>>>(a);
+        constexpr uint32_t NC = 4 / sizeof(S);  // i16: two columns per lane; i32: the one-column kernel
+        if (all_vec && NC > 1) {
+            // lanes: width / NC vectors of columns + the width % NC leftover columns
+            const uint32_t lanes = max_lines / NC + NC;
+            squeeze_v_seg3_kernel<S, (NC > 1 ? NC : 2)><<<dim3(ceil_div(lanes, 64), max_nseg, nseg_ch), 64, 0, s>>>(g3);
+        } else {
+            squeeze_seg3_kernel<S, false><<<dim3(ceil_div(max_lines, 64), max_nseg, nseg_ch), 64, 0, s>>>(g3);
+        }
+        squeeze_check3_kernel<S, false><<<dim3(ceil_div(max_lines, 64), nseg_ch), 64, 0, s>>>(g3, redo_count);
     }
 }
 
@@ -1139,8 +1339,14 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     const bool i16 = m->desc.sample_type == JXLGPU_SAMPLE_I16;
     const size_t esz = m->esz;
     const uint32_t nch = (uint32_t)m->orig.size();
-    for (uint32_t c = 0; c < nch; ++c)
-        HIP_TRY(ctx, hipMemcpyAsync(m->work[0][c], m->orig[c], (size_t)m->cw[c] * m->ch[c] * esz, hipMemcpyDeviceToDevice, s));
+    // The uploaded buffers are location 3, read-only: a squeeze step reads its rectangles where they
+    // are and writes the merged one into a working copy, so nothing has to be copied up front.  Only
+    // the in-place passes (predictor, RCT, palette) need a writable copy first.
+    m->work[3] = m->orig;
+    const bool predict = m->desc.residual_predictor <= 13;
+    if (predict)
+        for (uint32_t c = 0; c < nch; ++c)
+            HIP_TRY(ctx, hipMemcpyAsync(m->work[0][c], m->orig[c], (size_t)m->cw[c] * m->ch[c] * esz, hipMemcpyDeviceToDevice, s));
 
     if (m->desc.residual_predictor <= 13) {
         const uint32_t gd = m->desc.group_dim ? m->desc.group_dim : 256;
@@ -1166,7 +1372,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     // forward bookkeeping (transform_channel_info): which rectangle is which transformed channel
     std::vector<Grid> l;
     int nb_meta = 0;
-    for (uint32_t c = 0; c < nch; ++c) l.push_back(Grid{(int)c, 0, 0, m->cw[c], m->ch[c], 0, {}});
+    for (uint32_t c = 0; c < nch; ++c) l.push_back(Grid{(int)c, 0, 0, m->cw[c], m->ch[c], predict ? 0 : 3, {}});
     int meta_next = 0;
     m->steps.assign(m->transforms.size(), {});
     for (size_t t = 0; t < m->transforms.size(); ++t) {
@@ -1225,41 +1431,64 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
         return (char*)m->meta[~g.buf];
     };
 
+    // in-place passes: move a rectangle that still lives in the read-only upload into working copy 0
+    auto ensure_writable = [&](Grid& g) -> hipError_t {
+        if (g.buf < 0 || g.loc != 3) return hipSuccess;
+        uint32_t stride = 0;
+        char* src = ptr(g, 3, &stride);
+        char* dst = ptr(g, 0, &stride);
+        g.loc = 0;
+        return hipMemcpy2DAsync(dst, (size_t)stride * esz, src, (size_t)stride * esz, (size_t)g.w * esz, g.h, hipMemcpyDeviceToDevice, s);
+    };
+
     // inverse, last transform first (transform.rs:75-86)
     for (int t = (int)m->transforms.size() - 1; t >= 0; --t) {
         const JxlGpuTransform& tr = m->transforms[t];
         if (tr.kind == JXLGPU_TR_SQUEEZE) {
             const std::vector<JxlGpuSqueezeStep>& sp = m->steps[t];
+            SqueezePlan plan;
+            memset(&plan.chain, 0, sizeof(plan.chain));
             for (int i = (int)sp.size() - 1; i >= 0; --i) {
                 const JxlGpuSqueezeStep& st = sp[i];
                 const int begin = (int)st.begin_c, count = (int)st.num_c, end = begin + count;
                 const int from = st.in_place ? end : (int)l.size() - count;
                 std::vector<Grid> res(l.begin() + from, l.begin() + from + count);
                 l.erase(l.begin() + from, l.begin() + from + count);
-                for (int k = 0; k < count; ++k) {
-                    Grid& g = l[begin + k];
-                    const Grid& r = res[k];
-                    int out_loc = 0;
-                    while (out_loc == g.loc || out_loc == r.loc) ++out_loc;
-                    SqzArgs a;
-                    a.avg = ptr(g, g.loc, &a.avg_stride);
-                    a.res = ptr(r, r.loc, &a.res_stride);
-                    if (st.horizontal) g.w += r.w; else g.h += r.h;
-                    a.out = ptr(g, out_loc, &a.out_stride);
-                    a.width = g.w; a.height = g.h;
-                    g.loc = out_loc;
-                    if (i16) launch_squeeze<int16_t>(s, ctx->tune, st.horizontal, a, m->chk, m->chk_bytes, m->d_redo);
-                    else launch_squeeze<int32_t>(s, ctx->tune, st.horizontal, a, m->chk, m->chk_bytes, m->d_redo);
+                // the channels of a step are independent: up to three per launch
+                for (int k0 = 0; k0 < count; k0 += 3) {
+                    const int nk = std::min(3, count - k0);
+                    SqzArgs args[3];
+                    int slot[3];
+                    for (int k = 0; k < nk; ++k) {
+                        Grid& g = l[begin + k0 + k];
+                        const Grid& r = res[k0 + k];
+                        int out_loc = 0;
+                        while (out_loc == g.loc || out_loc == r.loc) ++out_loc;
+                        SqzArgs& a = args[k];
+                        a.avg = ptr(g, g.loc, &a.avg_stride);
+                        a.res = ptr(r, r.loc, &a.res_stride);
+                        if (st.horizontal) g.w += r.w; else g.h += r.h;
+                        a.out = ptr(g, out_loc, &a.out_stride);
+                        a.width = g.w; a.height = g.h;
+                        g.loc = out_loc;
+                        slot[k] = (begin + k0 + k) % 3;  // chain of the small levels this channel's steps join
+                    }
+                    if (i16) launch_squeeze_step<int16_t>(s, ctx->tune, st.horizontal, args, slot, nk, m->chk, m->chk_bytes, m->d_redo, plan);
+                    else launch_squeeze_step<int32_t>(s, ctx->tune, st.horizontal, args, slot, nk, m->chk, m->chk_bytes, m->d_redo, plan);
                     if (ctx->tune.debug_sync) {
+                        if (i16) flush_chain<int16_t>(s, plan); else flush_chain<int32_t>(s, plan);
                         hipError_t e = hipStreamSynchronize(s);
-                        fprintf(stderr, "squeeze %s ch%d %ux%u avg=%p(%u) res=%p(%u) out=%p(%u) -> %s\n", st.horizontal ? "H" : "V",
-                                begin + k, a.width, a.height, a.avg, a.avg_stride, a.res, a.res_stride, a.out, a.out_stride,
-                                hipGetErrorString(e));
+                        for (int k = 0; k < nk; ++k)
+                            fprintf(stderr, "squeeze %s ch%d %ux%u avg=%p(%u) res=%p(%u) out=%p(%u) -> %s\n", st.horizontal ? "H" : "V",
+                                    begin + k0 + k, args[k].width, args[k].height, args[k].avg, args[k].avg_stride, args[k].res,
+                                    args[k].res_stride, args[k].out, args[k].out_stride, hipGetErrorString(e));
                     }
                 }
             }
+            if (i16) flush_chain<int16_t>(s, plan); else flush_chain<int32_t>(s, plan);
         } else if (tr.kind == JXLGPU_TR_RCT) {
             RctArgs a;
+            for (int k = 0; k < 3; ++k) HIP_TRY(ctx, ensure_writable(l[tr.begin_c + k]));
             for (int k = 0; k < 3; ++k) a.p[k] = ptr(l[tr.begin_c + k], l[tr.begin_c + k].loc, &a.stride[k]);
             a.width = l[tr.begin_c].w; a.height = l[tr.begin_c].h; a.rct_type = tr.rct_type;
             dim3 grid(ceil_div(a.width, 256), a.height);
@@ -1269,6 +1498,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             Grid pal = l.front();
             l.erase(l.begin());
             Grid& leader = l[tr.begin_c];
+            HIP_TRY(ctx, ensure_writable(leader));
             PalArgs a;
             memset(&a, 0, sizeof(a));
             a.palette = ptr(pal, 0, &a.pal_stride);
@@ -1462,6 +1692,7 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
             size_t w = m->cw[c], h = m->ch[c];
             worst = std::max(worst, std::max((w / 32 + 1) * 2 * h, (h / 32 + 1) * 2 * w) * m->esz);
         }
+        worst = (worst + 15) / 16 * 16 * 3;  // three channels of a step share one launch
         m->chk_bytes = worst;
         if ((rc = malloc_dev(ctx, f, &m->chk, worst))) return rc;
     }
