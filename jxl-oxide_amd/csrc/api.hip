@@ -263,6 +263,10 @@ int upload_post_params(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuUpsampling&
         if (!src[i]) continue;
         std::vector<float> wq = expand_up_weights(src[i], ks[i]);
         TRY(dev_upload(ctx, f, &f->up_weights[i], wq));
+        if (i == 0) {
+            memcpy(f->up2_wq, wq.data(), sizeof(f->up2_wq));
+            f->have_up2 = true;
+        }
     }
     return JXLGPU_OK;
 }
@@ -775,9 +779,19 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
         const int log2f = up_factor == 2 ? 1 : up_factor == 4 ? 2 : 3;
         const int k = log2f == 3 ? 8 : (log2f == 1 ? 2 : 4);
         const float* kern = f->up_weights[k == 2 ? 0 : k == 4 ? 1 : 2];
-        for (int c = 0; c < 3; ++c) launch_upsample(s, cur[c], *cur_stride, W, H, f->up[c], W * k, k, kern);
-        for (int c = 0; c < 3; ++c) cur[c] = f->up[c];
-        *ow = W * k; *oh = H * k; *cur_stride = W * k;
+        // 2x (BASELINE config 5): one streaming pass for the three planes, colour transform fused
+        // when nothing (noise) sits between the two
+        const bool fuse = do_color && !do_noise;
+        if (k == 2 && f->have_up2 && !ctx->tune.no_fused &&
+            launch_upsample2_stream(s, cur, *cur_stride, W, H, f->up, W * k, f->up2_wq, fuse ? &f->color : nullptr)) {
+            for (int c = 0; c < 3; ++c) cur[c] = f->up[c];
+            *ow = W * k; *oh = H * k; *cur_stride = W * k;
+            if (fuse) return JXLGPU_OK;
+        } else {
+            for (int c = 0; c < 3; ++c) launch_upsample(s, cur[c], *cur_stride, W, H, f->up[c], W * k, k, kern);
+            for (int c = 0; c < 3; ++c) cur[c] = f->up[c];
+            *ow = W * k; *oh = H * k; *cur_stride = W * k;
+        }
     }
     if (do_noise) {
         // render.rs:207-222: after upsampling, on the frame's final size

@@ -305,6 +305,8 @@ struct jxlgpu_frame {
     uint32_t* ring_tiles = nullptr;      // outer ring of 32x32 tiles for the fused tile kernel
     uint32_t n_ring_tiles = 0;
     float* up_weights[3] = {};  // expanded 5x5 kernels per phase for 2x/4x/8x
+    float up2_wq[25] = {};      // host copy of the 2x kernel (kernel argument of the streaming form)
+    bool have_up2 = false;
     // result of the last render
     const float* result[3] = {};
     uint32_t result_stride = 0, result_w = 0, result_h = 0;
@@ -363,5 +365,8 @@ void launch_coeff_scatter(hipStream_t s, const uint32_t* pos, const void* val, b
                           uint32_t src_stride, uint32_t wr, uint32_t hr, uint32_t c, int32_t* dst, uint32_t* bad);
 void launch_color(hipStream_t s, const ColorArgs& c, float* const planes[3], uint32_t stride,
                   uint32_t width, uint32_t height);
+bool launch_upsample2_stream(hipStream_t s, const float* const in[3], uint32_t in_stride, uint32_t w, uint32_t h,
+                             float* const out[3], uint32_t out_stride, const float* weights_quarter_host,
+                             const ColorArgs* color);
 void launch_upsample(hipStream_t s, const float* in, uint32_t in_stride, uint32_t w, uint32_t h,
                      float* out, uint32_t out_stride, int k, const float* kernels);

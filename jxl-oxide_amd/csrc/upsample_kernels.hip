@@ -1,0 +1,166 @@
+// F3 + C1-C4 in one pass for 2x upsampling (BASELINE config 5): non-separable upsampling
+// (jxl-render/src/features/upsampling.rs:45-132) with the colour transform as its epilogue.
+//
+// The stage-at-a-time kernel (filter_kernels.hip) spends a thread per OUTPUT sample: 25 loads with
+// mirror arithmetic and 25 weight loads each, then a second full 8K pass for the colour transform.
+// Here a lane owns one INPUT column of all three channels and walks down the rows; the 5x5 window
+// lives in a register ring (the x-2..x+2 neighbours of a row are fetched once, with DPP lane
+// shifts, when the row enters the ring), the per-row min / max are cached, the 25 weights are
+// scalar registers, and the four output phases of an input sample are produced together and
+// converted to the output colour space before the only store.  The image border needs no special
+// case: lanes and rows outside the image load the mirrored sample (util.rs:423-454 == mirror() for
+// dimensions >= 2), exactly what the reference's padded copy holds.
+//
+// Arithmetic is the reference's: sum = 0; for iy, for ix: sum += w[ky][kx] * sample (mul, then add;
+// no contraction), clamp to [min, max] of the 25 samples.
+#include "common.h"
+#include "pixel_device.h"
+
+namespace {
+
+constexpr int UW = 60;   // output (input-resolution) columns per wave: 64 lanes - 2 halo lanes per side
+
+struct UpStreamArgs {
+    const float* in[3];
+    float* out[3];
+    uint32_t in_stride, out_stride;
+    int w, h;                 // input size
+    float wq[25];             // the one 5x5 kernel of K = 2 (weights_quarter[0])
+    ColorArgs color;
+    uint32_t do_color;
+    int rows_per_seg, strips, segs;
+};
+
+__device__ __forceinline__ float lane_m1(float v) {   // value held by lane - 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_p1(float v) {   // value held by lane + 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+struct UpState {
+    float R[5][3][5];     // rows r-2..r+2 (slot 4 = the newest), channel, column x-2..x+2
+    float mn[5][3], mx[5][3];
+};
+
+// One code body per kernel (the colour transform of the general op list is ~1200 instructions: the
+// row loop is NOT unrolled over ring phases and the two output rows of an input row share one copy
+// through a rolled loop, or the kernel would not fit the instruction cache): the ring rotates with
+// register moves, ~100 per row against the ~3000 of the sums and the colour transform.
+template <bool COLOR>
+__global__ __launch_bounds__(256) void upsample2_stream_kernel(UpStreamArgs a) {
+    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int strip = wave % a.strips, seg = wave / a.strips;
+    if (seg >= a.segs) return;
+    const int x = strip * UW - 2 + lane;
+    const int xl = mirror_idx(min(max(x, -a.w), 2 * a.w - 1), a.w);
+    const bool store_lane = lane >= 2 && lane < 2 + UW && x < a.w;
+    const uint32_t x_out_off = (uint32_t)(2 * max(x, 0)) * 4u;
+    const int y0 = seg * a.rows_per_seg, y1 = min(y0 + a.rows_per_seg, a.h);
+    UpState st;
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            st.mn[s][c] = st.mx[s][c] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) st.R[s][c][i] = 0.0f;
+        }
+    // rows y0-2 .. y1+1 enter the ring; output starts once row y0+2 is in (centre y0)
+#pragma unroll 1
+    for (int j = y0 - 2; j < y1 + 2; ++j) {
+        // ---- rotate, load row j (mirrored), fetch the x neighbours once
+        const int jm = mirror_idx(j, a.h);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st.mn[s][c] = st.mn[s + 1][c];
+                st.mx[s][c] = st.mx[s + 1][c];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) st.R[s][c][i] = st.R[s + 1][c][i];
+            }
+            const float v = (a.in[c] + (size_t)(uint32_t)jm * a.in_stride)[xl];
+            const float l1 = lane_m1(v), r1 = lane_p1(v);
+            const float l2 = lane_m1(l1), r2 = lane_p1(r1);
+            st.R[4][c][0] = l2; st.R[4][c][1] = l1; st.R[4][c][2] = v; st.R[4][c][3] = r1; st.R[4][c][4] = r2;
+            st.mn[4][c] = fminf(fminf(fminf(l2, l1), fminf(v, r1)), r2);
+            st.mx[4][c] = fmaxf(fmaxf(fmaxf(l2, l1), fmaxf(v, r1)), r2);
+        }
+        const int r = j - 2;
+        if (r < y0) continue;  // wave-uniform
+        float mn[3], mx[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            mn[c] = st.mn[0][c]; mx[c] = st.mx[0][c];
+#pragma unroll
+            for (int s = 1; s < 5; ++s) { mn[c] = fminf(mn[c], st.mn[s][c]); mx[c] = fmaxf(mx[c], st.mx[s][c]); }
+        }
+#pragma unroll 1
+        for (int ym = 0; ym < 2; ++ym) {
+            // this output row's weights: rows flipped for ym = 1 (flip_v = ym >= MAT_N); uniform loads
+            float wr[5][5];
+#pragma unroll
+            for (int iy = 0; iy < 5; ++iy)
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) wr[iy][kx] = a.wq[(ym ? 4 - iy : iy) * 5 + kx];
+            float o[2][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int xm = 0; xm < 2; ++xm) {
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int iy = 0; iy < 5; ++iy)
+#pragma unroll
+                        for (int ix = 0; ix < 5; ++ix) sum += wr[iy][xm ? 4 - ix : ix] * st.R[iy][c][ix];
+                    float v;
+                    if (!isfinite(mn[c])) v = __builtin_nanf("");
+                    else {
+                        v = sum;
+                        if (v < mn[c]) v = mn[c];
+                        if (v > mx[c]) v = mx[c];
+                    }
+                    o[xm][c] = v;
+                }
+            if constexpr (COLOR) {
+                color_pixel(a.color, o[0]);
+                color_pixel(a.color, o[1]);
+            }
+            if (store_lane) {
+                const size_t orow = (size_t)(uint32_t)(2 * r + ym) * a.out_stride;  // uniform
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(a.out[c] + orow) + x_out_off);
+                    *reinterpret_cast<float2*>(p) = make_float2(o[0][c], o[1][c]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// 2x upsampling of three planes (+ the colour transform when `color` is non-null) in one launch.
+// Returns false when the streaming form does not apply (tiny frames: the reference's padding has
+// its own behaviour below 2 samples, kept by the stage-at-a-time kernel).
+bool launch_upsample2_stream(hipStream_t s, const float* const in[3], uint32_t in_stride, uint32_t w, uint32_t h,
+                             float* const out[3], uint32_t out_stride, const float* weights_quarter_host,
+                             const ColorArgs* color) {
+    if (w < 8 || h < 8) return false;
+    UpStreamArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int c = 0; c < 3; ++c) { a.in[c] = in[c]; a.out[c] = out[c]; }
+    a.in_stride = in_stride; a.out_stride = out_stride;
+    a.w = (int)w; a.h = (int)h;
+    memcpy(a.wq, weights_quarter_host, sizeof(a.wq));
+    if (color) { a.color = *color; a.do_color = 1; }
+    a.rows_per_seg = 64;
+    a.strips = (int)ceil_div(w, UW);
+    a.segs = (int)ceil_div(h, (uint32_t)a.rows_per_seg);
+    const int waves = a.strips * a.segs;
+    if (color) upsample2_stream_kernel<true><<<(waves + 3) / 4, 256, 0, s>>>(a);
+    else upsample2_stream_kernel<false><<<(waves + 3) / 4, 256, 0, s>>>(a);
+    return true;
+}
