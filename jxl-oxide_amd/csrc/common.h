@@ -186,6 +186,9 @@ enum ProfGroup : int { PROF_LF = 0, PROF_TRANSFORM = 1, PROF_POST = 2, PROF_MODU
 struct Tuning {
     int stream_rows = 48;        // JXLGPU_STREAM_ROWS: rows per wave segment of post_stream_kernel
     int batch_stream_rows = 96;  // JXLGPU_BATCH_STREAM_ROWS: the same for batched launches (waves to spare)
+    int batch_chunk = 0;         // JXLGPU_BATCH_CHUNK: > 0: that many frames per launch, the chunks of a batch
+                                 // alternating between the context's two streams (measured: +1..3 %, the whole
+                                 // pipeline is VALU-issue bound; default 0 = one stream, <= 32 frames per launch)
     bool no_stream = false;      // JXLGPU_NO_STREAM: LDS tile kernel for the whole frame
     bool no_fused = false;       // JXLGPU_NO_FUSED: one kernel per post stage
     bool debug_sync = false;     // JXLGPU_DEBUG_SYNC: synchronise + report after every launch group
@@ -220,19 +223,21 @@ struct jxlgpu_ctx {
     int prof_group = -1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;
-    void prof_begin(int g) {
+    void prof_begin(int g, hipStream_t on = nullptr) {
         if (g != prof_group) return;
+        if (!on) on = stream;
         if (prof_used == prof_events.size()) {
             hipEvent_t a, b;
             (void)hipEventCreate(&a);
             (void)hipEventCreate(&b);
             prof_events.emplace_back(a, b);
         }
-        (void)hipEventRecord(prof_events[prof_used].first, stream);
+        (void)hipEventRecord(prof_events[prof_used].first, on);
     }
-    void prof_end(int g) {
+    void prof_end(int g, hipStream_t on = nullptr) {
         if (g != prof_group) return;
-        (void)hipEventRecord(prof_events[prof_used].second, stream);
+        if (!on) on = stream;
+        (void)hipEventRecord(prof_events[prof_used].second, on);
         ++prof_used;
     }
 };
