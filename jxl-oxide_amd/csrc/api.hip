@@ -1228,18 +1228,13 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
         for (uint32_t i = 0; i < n; ++i) TRY(jxlgpu_vardct_render(ctx, frames[i], stages, nullptr));
         return JXLGPU_OK;
     }
-    // Chunks of the batch alternate between the context's two streams: the V4-V8 launches of one
-    // chunk (HBM-bound) then overlap the post stage of the other (VALU-bound) on the device.
+    // One stream, <= 32 frames per launch, stage after stage.  Running the V1-V8 launches of chunk k+1
+    // on a second stream beside the post stage of chunk k was measured (round 2) and is slower: both
+    // stages are VALU-issue bound on this workload, so they only share the SIMDs.
     const uint32_t chunk = ctx->tune.batch_chunk > 0 ? std::min<uint32_t>((uint32_t)ctx->tune.batch_chunk, JXLGPU_MAX_BATCH)
                                                      : JXLGPU_MAX_BATCH;
-    const bool two_streams = ctx->tune.batch_chunk > 0 && n > chunk;
-    if (two_streams) {  // the side stream starts after whatever is already queued on the main one
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-    }
-    uint32_t chunk_idx = 0;
-    for (uint32_t i0 = 0; i0 < n; i0 += chunk, ++chunk_idx) {
-        hipStream_t s = (two_streams && (chunk_idx & 1)) ? ctx->stream2 : ctx->stream;
+    hipStream_t st = ctx->stream, sp = ctx->stream;
+    for (uint32_t i0 = 0; i0 < n; i0 += chunk) {
         const uint32_t m = std::min<uint32_t>(chunk, n - i0);
         FrameBatch b;
         memset(&b, 0, sizeof(b));
@@ -1255,34 +1250,25 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
             max_ring = std::max(max_ring, f->n_ring_tiles);
             any_smooth |= !f->desc.skip_adaptive_lf_smoothing;
         }
-        ctx->prof_begin(PROF_LF, s);
-        HIP_TRY(ctx, launch_lf_batch(s, b, m, max_w8, max_h8, any_smooth));
-        ctx->prof_end(PROF_LF, s);
-        ctx->prof_begin(PROF_TRANSFORM, s);
-        HIP_TRY(ctx, launch_transform_batch(s, b, m, max_wgs, max_special));
-        ctx->prof_end(PROF_TRANSFORM, s);
-        ctx->prof_begin(PROF_POST, s);
-        if (two_streams) {
-            // border rings (few, long tiles) first, on the same stream: the other chunk's work covers them
-            HIP_TRY(ctx, launch_post_batch(s, nullptr, b, m, max_stream, max_ring));
-        } else {
-            // one fork / join per launch: the border rings run beside the streaming kernel
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            HIP_TRY(ctx, launch_post_batch(s, ctx->stream2, b, m, max_stream, max_ring));
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-            HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
-        }
-        ctx->prof_end(PROF_POST, s);
+        ctx->prof_begin(PROF_LF, st);
+        HIP_TRY(ctx, launch_lf_batch(st, b, m, max_w8, max_h8, any_smooth));
+        ctx->prof_end(PROF_LF, st);
+        ctx->prof_begin(PROF_TRANSFORM, st);
+        HIP_TRY(ctx, launch_transform_batch(st, b, m, max_wgs, max_special));
+        ctx->prof_end(PROF_TRANSFORM, st);
+        ctx->prof_begin(PROF_POST, sp);
+        // one fork / join per launch: the border rings run beside the streaming kernel
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, sp));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        HIP_TRY(ctx, launch_post_batch(sp, ctx->stream2, b, m, max_stream, max_ring));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+        HIP_TRY(ctx, hipStreamWaitEvent(sp, ctx->ev_join, 0));
+        ctx->prof_end(PROF_POST, sp);
         for (uint32_t i = 0; i < m; ++i) {
             jxlgpu_frame* f = frames[i0 + i];
             for (int c = 0; c < 3; ++c) f->result[c] = f->buf_a[c];
             f->result_stride = f->wr; f->result_w = f->width; f->result_h = f->height;
         }
-    }
-    if (two_streams) {  // everything of the batch is ordered before whatever is queued on the main stream next
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     HIP_TRY(ctx, hipGetLastError());
     return JXLGPU_OK;

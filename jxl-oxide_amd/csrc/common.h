@@ -186,9 +186,7 @@ enum ProfGroup : int { PROF_LF = 0, PROF_TRANSFORM = 1, PROF_POST = 2, PROF_MODU
 struct Tuning {
     int stream_rows = 48;        // JXLGPU_STREAM_ROWS: rows per wave segment of post_stream_kernel
     int batch_stream_rows = 96;  // JXLGPU_BATCH_STREAM_ROWS: the same for batched launches (waves to spare)
-    int batch_chunk = 0;         // JXLGPU_BATCH_CHUNK: > 0: that many frames per launch, the chunks of a batch
-                                 // alternating between the context's two streams (measured: +1..3 %, the whole
-                                 // pipeline is VALU-issue bound; default 0 = one stream, <= 32 frames per launch)
+    int batch_chunk = 0;         // JXLGPU_BATCH_CHUNK: > 0: frames per launch of a batch (default: JXLGPU_MAX_BATCH)
     bool no_stream = false;      // JXLGPU_NO_STREAM: LDS tile kernel for the whole frame
     bool no_fused = false;       // JXLGPU_NO_FUSED: one kernel per post stage
     bool debug_sync = false;     // JXLGPU_DEBUG_SYNC: synchronise + report after every launch group
