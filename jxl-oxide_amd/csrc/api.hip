@@ -302,6 +302,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
         const int r = atoi(v);
         if (r >= 0 && r <= JXLGPU_MAX_BATCH) ctx->tune.batch_chunk = r;
     }
+    ctx->tune.no_pk = getenv("JXLGPU_NO_PK") != nullptr;
     ctx->tune.no_stream = getenv("JXLGPU_NO_STREAM") != nullptr;
     ctx->tune.no_fused = getenv("JXLGPU_NO_FUSED") != nullptr;
     ctx->tune.debug_sync = getenv("JXLGPU_DEBUG_SYNC") != nullptr;
@@ -1198,6 +1199,8 @@ static int ensure_dev_args(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     HIP_TRY(ctx, fused_prepare(ctx, f, in, f->wr, f->w8, f->buf_a, f->wr, true, 2, true, &h.post, &stream, &plain_srgb,
                                ctx->tune.batch_stream_rows));
     if (!stream || !plain_srgb) return JXLGPU_OK;
+    f->batch_pk = h.post.pk != 0;
+    if (f->batch_pk == ctx->tune.no_pk) return JXLGPU_OK;  // one kernel per batched launch: the odd frame renders alone
     h.post.tiles = f->ring_tiles;
     h.n_ring_tiles = f->n_ring_tiles;
     f->batch_stream_wgs = (uint32_t)(h.post.strips * h.post.segs + 3) / 4;
@@ -1260,7 +1263,7 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
         // one fork / join per launch: the border rings run beside the streaming kernel
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, sp));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        HIP_TRY(ctx, launch_post_batch(sp, ctx->stream2, b, m, max_stream, max_ring));
+        HIP_TRY(ctx, launch_post_batch(sp, ctx->stream2, b, m, max_stream, max_ring, !ctx->tune.no_pk));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
         HIP_TRY(ctx, hipStreamWaitEvent(sp, ctx->ev_join, 0));
         ctx->prof_end(PROF_POST, sp);

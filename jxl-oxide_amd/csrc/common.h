@@ -138,6 +138,7 @@ struct FusedArgs {
     const uint32_t* tiles;   // optional list of tiles (tx | ty << 16); null = full 2-D grid
     // streaming kernel geometry: it covers [sx0, sx1) x [sy0, sy1), strictly inside the image
     int sx0, sx1, sy0, sy1, rows_per_seg, strips, segs;
+    uint32_t pk;             // the geometry is the packed kernel's (strips of 120 columns, two per lane)
 };
 
 // Workgroups of one transform launch: class k owns workgroups [wg_begin[k], wg_begin[k + 1]).
@@ -187,6 +188,7 @@ struct Tuning {
     int stream_rows = 48;        // JXLGPU_STREAM_ROWS: rows per wave segment of post_stream_kernel
     int batch_stream_rows = 96;  // JXLGPU_BATCH_STREAM_ROWS: the same for batched launches (waves to spare)
     int batch_chunk = 0;         // JXLGPU_BATCH_CHUNK: > 0: frames per launch of a batch (default: JXLGPU_MAX_BATCH)
+    bool no_pk = false;          // JXLGPU_NO_PK: scalar streaming kernel (one column per lane)
     bool no_stream = false;      // JXLGPU_NO_STREAM: LDS tile kernel for the whole frame
     bool no_fused = false;       // JXLGPU_NO_FUSED: one kernel per post stage
     bool debug_sync = false;     // JXLGPU_DEBUG_SYNC: synchronise + report after every launch group
@@ -305,6 +307,7 @@ struct jxlgpu_frame {
     bool dev_args_ready = false;
     bool batch_ok = false;               // the frame qualifies for the batched default pipeline
     uint32_t batch_wgs[4] = {}, batch_stream_wgs = 0;
+    bool batch_pk = false;               // the batched post launch of this frame is the packed kernel
     uint32_t* ring_tiles = nullptr;      // outer ring of 32x32 tiles for the fused tile kernel
     uint32_t n_ring_tiles = 0;
     float* up_weights[3] = {};  // expanded 5x5 kernels per phase for 2x/4x/8x
@@ -341,7 +344,7 @@ hipError_t launch_lf_batch(hipStream_t s, const FrameBatch& b, uint32_t n, uint3
 hipError_t launch_transform_batch(hipStream_t s, const FrameBatch& b, uint32_t n, const uint32_t max_wgs[4],
                                   uint32_t max_special);
 hipError_t launch_post_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, uint32_t max_stream_wgs,
-                             uint32_t max_ring);
+                             uint32_t max_ring, bool pk);
 hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs& a, const uint4* entries,
                                   const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT],
                                   uint32_t num_cus, int wgs_per_cu);

@@ -495,6 +495,8 @@ __global__ __launch_bounds__(256) void post_stream_batch_kernel(FrameBatch b) {
     post_stream_body<JXLGPU_TF_SRGB, true, true>(a, srgb_lut);
 }
 
+#include "post_pk.inc"
+
 template <bool GAB, int ITERS>
 hipError_t launch_cfg(hipStream_t s, const FusedArgs& a, dim3 grid) {
     constexpr size_t lds_bytes = 2 * 3 * PostCfg<GAB, ITERS>::PLANE * sizeof(float);
@@ -576,7 +578,16 @@ hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in
     if (stream) {
         a.sx0 = T; a.sx1 = T * tx_hi; a.sy0 = T; a.sy1 = T * ty_hi;
         a.rows_per_seg = rows_per_seg > 0 ? rows_per_seg : (ctx ? ctx->tune.stream_rows : 48);
-        a.strips = (a.sx1 - a.sx0 + SW - 1) / SW;
+        // Packed kernel (two columns per lane): Gabor + EPF on the cell-tiled transform output, 8-byte
+        // aligned output rows, and the sign conditions under which 1 + d * s <= 1 (clamp == max(., 0)).
+        const JxlGpuFilterParams& fp = a.fp;
+        bool pk = gabor && in_tiled_w8 && !(ctx && ctx->tune.no_pk) && (out_stride & 1) == 0 &&
+                  fp.epf_channel_scale[0] >= 0 && fp.epf_channel_scale[1] >= 0 && fp.epf_channel_scale[2] >= 0 &&
+                  fp.epf_border_sad_mul >= 0 && fp.epf_pass2_sigma_scale >= 0;
+        for (int c = 0; c < 3; ++c) pk = pk && (reinterpret_cast<uintptr_t>(out[c]) & 7) == 0;
+        a.pk = pk ? 1u : 0u;
+        const int sw = pk ? PW : SW;
+        a.strips = (a.sx1 - a.sx0 + sw - 1) / sw;
         a.segs = (a.sy1 - a.sy0 + a.rows_per_seg - 1) / a.rows_per_seg;
     }
     // plain XYB -> sRGB (no gamut map / second matrix) gets a branch-free colour epilogue
@@ -606,7 +617,10 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
         if (gabor) post_stream_kernel<TF, TILED, true><<<sgrid, 256, 0, s>>>(a);      \
         else post_stream_kernel<TF, TILED, false><<<sgrid, 256, 0, s>>>(a);           \
     } while (0)
-    if (a.in_w8) {
+    if (a.pk) {
+        if (plain_srgb) post_pk_kernel<JXLGPU_TF_SRGB><<<sgrid, 256, 0, s>>>(a);
+        else post_pk_kernel<-1><<<sgrid, 256, 0, s>>>(a);
+    } else if (a.in_w8) {
         if (plain_srgb) STREAM(JXLGPU_TF_SRGB, true); else STREAM(-1, true);
     } else {
         if (plain_srgb) STREAM(JXLGPU_TF_SRGB, false); else STREAM(-1, false);
@@ -627,7 +641,7 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
 // Default pipeline of n frames: streaming kernel on `s`, border rings beside it on `side` (may be
 // null: same stream).  The caller forks / joins the two streams once per batch.
 hipError_t launch_post_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, uint32_t max_stream_wgs,
-                             uint32_t max_ring) {
+                             uint32_t max_ring, bool pk) {
     constexpr size_t lds_bytes = 2 * 3 * PostCfg<true, 2>::PLANE * sizeof(float);
     static std::once_flag once;
     std::call_once(once, [] {
@@ -635,6 +649,7 @@ hipError_t launch_post_batch(hipStream_t s, hipStream_t side, const FrameBatch& 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     });
     if (max_ring) post_ring_batch_kernel<<<dim3(max_ring, n), 256, lds_bytes, side ? side : s>>>(b);
-    if (max_stream_wgs) post_stream_batch_kernel<<<dim3(max_stream_wgs, n), 256, 0, s>>>(b);
+    if (max_stream_wgs && pk) post_pk_batch_kernel<<<dim3(max_stream_wgs, n), 256, 0, s>>>(b);
+    else if (max_stream_wgs) post_stream_batch_kernel<<<dim3(max_stream_wgs, n), 256, 0, s>>>(b);
     return hipGetLastError();
 }
