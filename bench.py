@@ -14,8 +14,8 @@ launch per stage for up to 32 frames).  Total work is fixed as N grows: "scaling
 Besides `value`, rank 0 reports in the same JSON line:
   roofline       HBM roofline of the dominant kernel group, HIP events on the library's own stream
                  inside the timed region (one bracket per batched launch);
-  roofline_valu  the same launches against the VALU issue ceiling (the post stage is bound by scalar
-                 f32 issue under bit-exact arithmetic, DESIGN.md §4);
+  roofline_valu  the same launches against the VALU issue ceiling (the post stage is bound by f32
+                 instruction issue under bit-exact arithmetic, DESIGN.md §4);
   verified       one frame per distinct workload downloaded after the timed region and compared
                  with the CPU oracle, bit for bit;
   gather_ms      the stitched-output step of config 4: u8 interleaved formatting on the device + ONE
@@ -43,8 +43,10 @@ sys.path.insert(0, ROOT)
 W4K, H4K = 3840, 2160
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GINSTR = 614.4    # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 f32 instruction (profiles/r01_pk_probe.txt)
-POST_VALU_PER_ROW = 399     # static VALU count of one row step of post_stream_kernel (tools/isa_stats.py)
-POST_ROWS_PER_SEG, POST_HALO_ROWS = 48, 8
+# static VALU count of one row step of the streaming post kernel and its strip width (tools/isa_blocks.sh):
+# packed kernel (two columns per lane, the default) / scalar kernel (JXLGPU_NO_PK)
+POST_VALU_PER_ROW, POST_STRIP = (354, 56) if os.environ.get("JXLGPU_NO_PK") else (424, 120)
+POST_ROWS_PER_SEG, POST_HALO_ROWS = int(os.environ.get("JXLGPU_BATCH_STREAM_ROWS", "96")), 8
 
 
 def main():
@@ -165,13 +167,15 @@ def main():
         roofline_valu = None
         if args.config == 2 and dominant == 2:
             segs = -(-(H4K - 64) // POST_ROWS_PER_SEG)
-            strips = -(-(W4K - 64) // 56)
+            strips = -(-(W4K - 64) // POST_STRIP)
             winstr = strips * segs * (POST_ROWS_PER_SEG + POST_HALO_ROWS) * POST_VALU_PER_ROW * frames_per_launch
             ach = winstr / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roofline_valu = {"bound": "valu", "achieved": round(ach, 1), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
                              "frac": round(ach / VALU_PEAK_GINSTR, 4),
-                             "note": "post_stream_kernel: scalar f32 in the reference's operation order (no FMA contraction, IEEE "
-                                     "division); 64/56 x 56/48 of the rows x lanes are halo recompute"}
+                             "note": "streaming post kernel, f32 in the reference's operation order (no FMA contraction, "
+                                     "correctly rounded division); a packed v_pk_*_f32 instruction counts once; halo rows "
+                                     "and columns are recomputed (%d/%d x %d/%d)" % (
+                                         POST_STRIP + 8, POST_STRIP, POST_ROWS_PER_SEG + POST_HALO_ROWS, POST_ROWS_PER_SEG)}
         verified = None
         if not args.no_verify:
             verified = job["verify"](ctx, frames, mine, wls, args.distinct)

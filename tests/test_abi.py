@@ -121,3 +121,15 @@ def test_c_caller_renders_on_the_gpu(tmp_path):
     exe = _build_c_caller(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)
+
+
+def test_shared_reciprocal_division_is_exact(tmp_path):
+    """tests/c/sdiv_check.c: the fma chain of div3_shared (csrc/post_pk.inc) equals IEEE division in its
+    guard range for every reciprocal estimate within 1 ulp — the CPU proof-by-test behind the packed post
+    kernel's normalisation."""
+    import subprocess
+    exe = str(tmp_path / "sdiv_check")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", os.path.join(ROOT, "tests", "c", "sdiv_check.c"), "-o", exe, "-lm"])
+    r = subprocess.run([exe, "3000000"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-500:]
+    assert "mismatches 0" in r.stdout

@@ -100,6 +100,67 @@ def test_tile_kernel_whole_frame_matches(gpu_ctx, oracle, monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize("size", [(520, 300), (1000, 264), (301, 299)])
+def test_packed_and_scalar_streaming_kernels_match(gpu_ctx, oracle, monkeypatch, size):
+    """The default post stage is the packed kernel (two columns per lane, post_pk.inc); JXLGPU_NO_PK
+    selects the scalar one.  Both must give the oracle's bits (several strips, a partial last strip,
+    an odd width)."""
+    from jxl_oxide_amd import runtime
+    wl = VardctWorkload(size[0], size[1], seed=76)
+    got, exp = _both(gpu_ctx, oracle, wl, S_ALL)
+    assert_ulp(got, exp, MAX_ULP, f"packed kernel {size}")
+    monkeypatch.setenv("JXLGPU_NO_PK", "1")
+    ctx = runtime.Context(0)
+    try:
+        got2, _ = _both(ctx, oracle, wl, S_ALL)
+        assert_ulp(got2, exp, MAX_ULP, f"scalar kernel {size}")
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("case", ["zero_x", "zero_all", "huge", "tiny"])
+@pytest.mark.parametrize("stages", [S_EPF, S_ALL])
+def test_packed_kernel_division_guard(gpu_ctx, oracle, case, stages):
+    """The packed kernel replaces sum_c / sum_w by a shared-reciprocal fma chain where every numerator
+    lies in [2^-100, 2^20]; anything else (zeros of either sign, huge or tiny samples) must take the
+    ordinary divisions.  S_EPF (no colour) keeps the sign of a zero visible in the output."""
+    wl = VardctWorkload(328, 232, seed=77, lf_i16=False)
+    if case in ("zero_x", "zero_all"):
+        chans = (0,) if case == "zero_x" else (0, 1, 2)
+        for c in chans:
+            wl.coeff[c, 64:200, 96:300] = 0
+        wl.xfy[:] = 0
+        wl.bfy[:] = 0
+        # lfq order is Y, X, B
+        for i in ((1,) if case == "zero_x" else (0, 1, 2)):
+            wl.lfq[i][8:25, 12:38] = 0
+    elif case == "huge":
+        wl.lfq[0][10:20, 14:30] = 2 ** 30
+        wl.lfq[2][12:22, 10:36] = -(2 ** 30)
+    else:
+        # samples far below 2^-100 after the dequantisation: all-zero LF and HF except single +-1 coefficients
+        # scaled down through the smallest multipliers the descriptor allows is not reachable; the
+        # closest the format gets is exact zeros next to ordinary samples
+        wl.coeff[:, 100:164, 100:228] = 0
+        for i in range(3):
+            wl.lfq[i][12:21, 12:29] = 0
+        wl.coeff[1, 120, 130] = 1
+    d = wl.desc()
+    ow, oh = wl.out_size(stages)
+    exp, _ = oracle.vardct_render(d, stages, ow, oh)
+    frame = gpu_ctx.vardct_upload(d)
+    try:
+        got = gpu_ctx.vardct_render(frame, stages)
+    finally:
+        frame.free()
+    assert got.shape == exp.shape
+    if case == "huge":
+        assert np.isfinite(exp).all()
+    # bit patterns, so that -0.0 vs +0.0 counts
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (
+        case, int((got.view(np.uint32) != exp.view(np.uint32)).sum()))
+
+
 @pytest.mark.parametrize("size", [(1, 1), (2, 3), (5, 4), (3, 40), (33, 2)])
 def test_tiny_images(gpu_ctx, oracle, size):
     w, h = size
