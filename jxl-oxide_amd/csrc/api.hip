@@ -288,6 +288,12 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     }
+#ifdef JXL_TR_PROFILE
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->tr_prof), 64 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemset(ctx->tr_prof, 0, 64 * sizeof(unsigned long long));
+    else
+        ctx->tr_prof = nullptr;
+#endif
     // environment -> per-context tuning, read once here (no process-global state afterwards)
     if (const char* mb = getenv("JXLGPU_POOL_MB")) ctx->pool_cap = (size_t)strtoull(mb, nullptr, 10) << 20;
     if (const char* v = getenv("JXLGPU_STREAM_ROWS")) {

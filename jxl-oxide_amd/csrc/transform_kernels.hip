@@ -443,7 +443,7 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
         }
         TR_STAMP(false);  // 7: column IDCT + stores issued
         TR_STAMP(true);   // 8: stores drained
-        TR_STAMP_FLUSH(H >= 64 || W >= 64 ? 3 : (H >= 32 || W >= 32 ? 2 : (H >= 16 || W >= 16 ? 1 : 0)));
+        TR_STAMP_FLUSH(C::MINWH >= 64 ? 3 : (C::MINWH >= 32 ? 2 : (C::MINWH >= 16 ? 1 : 0)));  // = the launch family
 #ifdef JXL_TR_PROFILE
         tr_n = 0;
         TR_STAMP(false);
