@@ -578,13 +578,13 @@ hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in
     if (stream) {
         a.sx0 = T; a.sx1 = T * tx_hi; a.sy0 = T; a.sy1 = T * ty_hi;
         a.rows_per_seg = rows_per_seg > 0 ? rows_per_seg : (ctx ? ctx->tune.stream_rows : 48);
-        // Packed kernel (two columns per lane): Gabor + EPF on the cell-tiled transform output, 8-byte
-        // aligned output rows, and the sign conditions under which 1 + d * s <= 1 (clamp == max(., 0)).
+        // Packed kernel (two columns per lane): 8-byte aligned input / output rows, and the sign conditions under which 1 + d * s <= 1 (clamp == max(., 0)).
         const JxlGpuFilterParams& fp = a.fp;
-        bool pk = gabor && in_tiled_w8 && !(ctx && ctx->tune.no_pk) && (out_stride & 1) == 0 &&
+        bool pk = !(ctx && ctx->tune.no_pk) && (out_stride & 1) == 0 && (in_tiled_w8 || (in_stride & 1) == 0) &&
                   fp.epf_channel_scale[0] >= 0 && fp.epf_channel_scale[1] >= 0 && fp.epf_channel_scale[2] >= 0 &&
                   fp.epf_border_sad_mul >= 0 && fp.epf_pass2_sigma_scale >= 0;
-        for (int c = 0; c < 3; ++c) pk = pk && (reinterpret_cast<uintptr_t>(out[c]) & 7) == 0;
+        for (int c = 0; c < 3; ++c)
+            pk = pk && (reinterpret_cast<uintptr_t>(out[c]) & 7) == 0 && (in_tiled_w8 || (reinterpret_cast<uintptr_t>(in[c]) & 7) == 0);
         a.pk = pk ? 1u : 0u;
         const int sw = pk ? PW : SW;
         a.strips = (a.sx1 - a.sx0 + sw - 1) / sw;
@@ -617,15 +617,22 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
         if (gabor) post_stream_kernel<TF, TILED, true><<<sgrid, 256, 0, s>>>(a);      \
         else post_stream_kernel<TF, TILED, false><<<sgrid, 256, 0, s>>>(a);           \
     } while (0)
-    if (a.pk) {
-        if (plain_srgb) post_pk_kernel<JXLGPU_TF_SRGB><<<sgrid, 256, 0, s>>>(a);
-        else post_pk_kernel<-1><<<sgrid, 256, 0, s>>>(a);
+#define STREAM_PK(TF, TILED)                                                        \
+    do {                                                                              \
+        if (gabor) post_pk_kernel<TF, TILED, true><<<sgrid, 256, 0, s>>>(a);          \
+        else post_pk_kernel<TF, TILED, false><<<sgrid, 256, 0, s>>>(a);               \
+    } while (0)
+    if (a.pk && a.in_w8) {
+        if (plain_srgb) STREAM_PK(JXLGPU_TF_SRGB, true); else STREAM_PK(-1, true);
+    } else if (a.pk) {
+        if (plain_srgb) STREAM_PK(JXLGPU_TF_SRGB, false); else STREAM_PK(-1, false);
     } else if (a.in_w8) {
         if (plain_srgb) STREAM(JXLGPU_TF_SRGB, true); else STREAM(-1, true);
     } else {
         if (plain_srgb) STREAM(JXLGPU_TF_SRGB, false); else STREAM(-1, false);
     }
 #undef STREAM
+#undef STREAM_PK
     if ((e = hipGetLastError()) != hipSuccess) return e;
     a.tiles = f->ring_tiles;
     // the border ring (a few hundred long-latency tiles) runs beside the streaming kernel
