@@ -194,7 +194,7 @@ struct Tuning {
     bool debug_sync = false;     // JXLGPU_DEBUG_SYNC: synchronise + report after every launch group
     int tr_wgs_per_cu[4] = {0, 0, 0, 0};  // JXLGPU_TR_WGS_PER_CU="a,b,c,d": persistent transform workgroups per CU
                                  // for the 8-, 16-, 32- and 64-px launch (0: one workgroup per item, no run-ahead)
-    int sqz_seg = 128;           // JXLGPU_SQZ_SEG: pairs per inverse-Squeeze segment
+    int sqz_seg = 64;            // JXLGPU_SQZ_SEG: pairs per inverse-Squeeze segment
     uint32_t sqz_runin = 1;      // JXLGPU_SQZ_RUNIN: 0 forces the Squeeze fix-up path (tests)
 };
 

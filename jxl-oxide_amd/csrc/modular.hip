@@ -223,8 +223,8 @@ __global__ __launch_bounds__(64) void squeeze_h_kernel(SqzArgs a) {
 // column is cut into segments: every segment starts OV pairs early from a guessed `prev`, and
 // records (a) the `prev` it had reached at its real start and (b) the `prev` it ends with.  A
 // check kernel then walks the chain of segments: segment 0 is exact by construction, segment s is
-// exact iff its (a) equals segment s-1's (b); if any link of a line fails, that line is redone
-// serially.  Bit-exactness never depends on the guess — only speed does.  This turns ~13 k long
+// exact iff its (a) equals segment s-1's (b); a segment whose link fails is redone serially from the
+// true state (squeeze_check3_kernel).  Bit-exactness never depends on the guess — only speed does.  This turns ~13 k long
 // chains (8K image) into ~400 k short ones, which is what fills 256 CUs.
 struct SegArgs {
     SqzArgs a;
@@ -341,24 +341,49 @@ __device__ __forceinline__ void squeeze_h_seg_body(const SegArgs& g, uint32_t y,
     S left = x == 0 ? avg : avgp[x - 1];  // guess: previous pair's average (exact at x == 0)
     Pack cur_a;
     cur_a.v = *reinterpret_cast<const V*>(avgp + x);  // segments are only used when avg_w >= 2N
-    for (; x + N <= x_e && x + 2 * N <= avg_w; x += N) {
-        if (x == x_s) chk[((size_t)seg * 2 + 0) * a.height + y] = left;
-        Pack r, nxt_a, o0, o1;
-        r.v = *reinterpret_cast<const V*>(resp + x);
-        nxt_a.v = *reinterpret_cast<const V*>(avgp + x + N);
+    auto vec_step = [&](const Pack& r, const Pack& nxt_a, uint32_t xx) __attribute__((always_inline)) {
+        Pack o0, o1;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            S next_avg = k + 1 < N ? cur_a.s[k + 1] : nxt_a.s[0];  // x+k+1 < avg_w holds in this loop
+            S next_avg = k + 1 < N ? cur_a.s[k + 1] : nxt_a.s[0];  // xx+k+1 < avg_w holds for every vector step
             S first, second;
             squeeze_pair<S>(r.s[k], next_avg, avg, left, first, second);
             if (2 * k < N) { o0.s[2 * k] = first; o0.s[2 * k + 1] = second; }
             else { o1.s[2 * k - N] = first; o1.s[2 * k + 1 - N] = second; }
         }
-        if (x >= x_s) {
-            *reinterpret_cast<V*>(outp + 2 * x) = o0.v;
-            *reinterpret_cast<V*>(outp + 2 * x + N) = o1.v;
+        if (xx >= x_s) {
+            *reinterpret_cast<V*>(outp + 2 * xx) = o0.v;
+            *reinterpret_cast<V*>(outp + 2 * xx + N) = o1.v;
         }
         cur_a.v = nxt_a.v;
+    };
+    // the run-in (one vector step), then whole 64-byte pieces of the row per step: a lane walks its
+    // own row, so every line it touches must be used up while it is still in the caches — with one
+    // 16-byte vector per step a line was fetched again for each of its 8 vectors on an 8K image
+    for (; x < x_s && x + 2 * N <= avg_w; x += N) {
+        Pack r, nxt_a;
+        r.v = *reinterpret_cast<const V*>(resp + x);
+        nxt_a.v = *reinterpret_cast<const V*>(avgp + x + N);
+        vec_step(r, nxt_a, x);
+    }
+    constexpr int VC = 4;  // vectors per step
+    for (; x + VC * N <= x_e && x + (VC + 1) * N <= avg_w; x += VC * N) {
+        if (x == x_s) chk[((size_t)seg * 2 + 0) * a.height + y] = left;
+        Pack r[VC], na[VC];
+#pragma unroll
+        for (int v = 0; v < VC; ++v) {
+            r[v].v = *reinterpret_cast<const V*>(resp + x + v * N);
+            na[v].v = *reinterpret_cast<const V*>(avgp + x + (v + 1) * N);
+        }
+#pragma unroll
+        for (int v = 0; v < VC; ++v) vec_step(r[v], na[v], x + v * N);
+    }
+    for (; x + N <= x_e && x + 2 * N <= avg_w; x += N) {
+        if (x == x_s) chk[((size_t)seg * 2 + 0) * a.height + y] = left;
+        Pack r, nxt_a;
+        r.v = *reinterpret_cast<const V*>(resp + x);
+        nxt_a.v = *reinterpret_cast<const V*>(avgp + x + N);
+        vec_step(r, nxt_a, x);
     }
     for (; x < x_e; ++x) {  // scalar tail (only the last segment gets here with x >= x_s)
         if (x == x_s) chk[((size_t)seg * 2 + 0) * a.height + y] = left;
@@ -524,6 +549,31 @@ __global__ __launch_bounds__(64) void squeeze_seg3_kernel(SegArgs3 g3) {
     else squeeze_v_seg_body<S>(g, i, blockIdx.y);
 }
 
+// One segment again, serially, from its true starting state (`prev` = what the segment before it
+// really ended with); returns the `prev` it ends with.  Pairs [p_s, p_e) of line i.
+template <typename S, bool HORIZONTAL>
+__device__ __forceinline__ S squeeze_redo_range(const SqzArgs& a, uint32_t i, uint32_t p_s, uint32_t p_e, S prev) {
+    const uint32_t len = HORIZONTAL ? a.width : a.height;
+    const uint32_t avg_n = (len + 1) / 2;
+    const size_t as = HORIZONTAL ? 1 : a.avg_stride, rs = HORIZONTAL ? 1 : a.res_stride, os = HORIZONTAL ? 1 : a.out_stride;
+    const S* avgp = (const S*)a.avg + (HORIZONTAL ? (size_t)i * a.avg_stride : (size_t)i);
+    const S* resp = (const S*)a.res + (HORIZONTAL ? (size_t)i * a.res_stride : (size_t)i);
+    S* outp = (S*)a.out + (HORIZONTAL ? (size_t)i * a.out_stride : (size_t)i);
+    S avg = avgp[(size_t)p_s * as];
+    for (uint32_t p = p_s; p < p_e; ++p) {
+        const S next_avg = (p + 1 < avg_n) ? avgp[(size_t)(p + 1) * as] : avg;
+        S first, second;
+        squeeze_pair<S>(resp[(size_t)p * rs], next_avg, avg, prev, first, second);
+        outp[(size_t)(2 * p) * os] = first;
+        outp[(size_t)(2 * p + 1) * os] = second;
+    }
+    return prev;
+}
+
+// Walk the chain of segments of every line.  Segment s is exact iff the `prev` it had reached at its
+// real start equals the `prev` the segment before it really ended with; a segment that is not is
+// redone alone from that true state (not the whole line: a redone segment nearly always ends with the
+// `prev` it ended with before, so the chain behind it stands), and the walk goes on with its new end.
 template <typename S, bool HORIZONTAL>
 __global__ __launch_bounds__(64) void squeeze_check3_kernel(SegArgs3 g3, int* redo_count) {
     const SegArgs& g = g3.g[blockIdx.y];
@@ -531,13 +581,17 @@ __global__ __launch_bounds__(64) void squeeze_check3_kernel(SegArgs3 g3, int* re
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= lines) return;
     const S* chk = (const S*)g.chk;
-    bool ok = true;
-    for (uint32_t s = 1; s < g.nseg; ++s)
-        ok &= chk[((size_t)s * 2 + 0) * lines + i] == chk[((size_t)(s - 1) * 2 + 1) * lines + i];
-    if (ok) return;
-    if (redo_count) atomicAdd(redo_count, 1);
-    if (HORIZONTAL) squeeze_h_line<S>(g.a, i);
-    else squeeze_v_line<S>(g.a, i);
+    const uint32_t pairs = (HORIZONTAL ? g.a.width : g.a.height) / 2;
+    S end_prev = chk[((size_t)0 * 2 + 1) * lines + i];
+    for (uint32_t s = 1; s < g.nseg; ++s) {
+        if (chk[((size_t)s * 2 + 0) * lines + i] == end_prev) {
+            end_prev = chk[((size_t)s * 2 + 1) * lines + i];
+            continue;
+        }
+        if (redo_count) atomicAdd(redo_count, 1);
+        const uint32_t p_s = s * g.seg_pairs, p_e = (s + 1 == g.nseg) ? pairs : p_s + g.seg_pairs;
+        end_prev = squeeze_redo_range<S, HORIZONTAL>(g.a, i, p_s, p_e, end_prev);
+    }
 }
 
 // The smallest levels of the pyramid (chains of a few dozen pairs, a few hundred lines) are pure
