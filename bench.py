@@ -166,16 +166,20 @@ def main():
         }
         roofline_valu = None
         if args.config == 2 and dominant == 2:
-            segs = -(-(H4K - 64) // POST_ROWS_PER_SEG)
-            strips = -(-(W4K - 64) // POST_STRIP)
-            winstr = strips * segs * (POST_ROWS_PER_SEG + POST_HALO_ROWS) * POST_VALU_PER_ROW * frames_per_launch
+            # the streaming kernel's region and segmentation, as fused_prepare() lays them out
+            iw, ih = (W4K - 4) // 8 * 8 - 16, (H4K - 4) // 8 * 8 - 16
+            nseg = max(1, (ih + POST_ROWS_PER_SEG // 2) // POST_ROWS_PER_SEG)
+            rows = (-(-ih // nseg) + 3) // 4 * 4
+            segs = -(-ih // rows)
+            strips = -(-iw // POST_STRIP)
+            winstr = strips * segs * (rows + POST_HALO_ROWS) * POST_VALU_PER_ROW * frames_per_launch
             ach = winstr / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roofline_valu = {"bound": "valu", "achieved": round(ach, 1), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
                              "frac": round(ach / VALU_PEAK_GINSTR, 4),
                              "note": "streaming post kernel, f32 in the reference's operation order (no FMA contraction, "
                                      "correctly rounded division); a packed v_pk_*_f32 instruction counts once; halo rows "
                                      "and columns are recomputed (%d/%d x %d/%d)" % (
-                                         POST_STRIP + 8, POST_STRIP, POST_ROWS_PER_SEG + POST_HALO_ROWS, POST_ROWS_PER_SEG)}
+                                         POST_STRIP + 8, POST_STRIP, rows + POST_HALO_ROWS, rows)}
         verified = None
         if not args.no_verify:
             verified = job["verify"](ctx, frames, mine, wls, args.distinct)

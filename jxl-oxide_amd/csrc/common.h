@@ -138,6 +138,7 @@ struct FusedArgs {
     const uint32_t* tiles;   // optional list of tiles (tx | ty << 16); null = full 2-D grid
     // streaming kernel geometry: it covers [sx0, sx1) x [sy0, sy1), strictly inside the image
     int sx0, sx1, sy0, sy1, rows_per_seg, strips, segs;
+    uint32_t n_ring_h;       // ring tile list: the first n_ring_h tiles are 32 x 16, the rest 16 x 32
     uint32_t pk;             // the geometry is the packed kernel's (strips of 120 columns, two per lane)
 };
 
@@ -308,8 +309,8 @@ struct jxlgpu_frame {
     bool batch_ok = false;               // the frame qualifies for the batched default pipeline
     uint32_t batch_wgs[4] = {}, batch_stream_wgs = 0;
     bool batch_pk = false;               // the batched post launch of this frame is the packed kernel
-    uint32_t* ring_tiles = nullptr;      // outer ring of 32x32 tiles for the fused tile kernel
-    uint32_t n_ring_tiles = 0;
+    uint32_t* ring_tiles = nullptr;      // border ring of the streaming post path: tile origins x0 | y0 << 16
+    uint32_t n_ring_tiles = 0, n_ring_h = 0;  // the first n_ring_h are 32 x 16 (top / bottom), the rest 16 x 32
     float* up_weights[3] = {};  // expanded 5x5 kernels per phase for 2x/4x/8x
     float up2_wq[25] = {};      // host copy of the 2x kernel (kernel argument of the streaming form)
     bool have_up2 = false;

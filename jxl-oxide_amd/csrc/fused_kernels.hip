@@ -20,16 +20,20 @@ namespace {
 
 constexpr int T = 32;  // output tile
 
-template <bool GAB, int ITERS>
+template <bool GAB, int ITERS, int TW = T, int TH = T>
 struct PostCfg {
     static constexpr int R_GAB = GAB ? 1 : 0;
     static constexpr int R_E0 = ITERS == 3 ? 3 : 0;
     static constexpr int R_E1 = ITERS >= 1 ? 2 : 0;
     static constexpr int R_E2 = ITERS >= 2 ? 1 : 0;
     static constexpr int HALO = R_GAB + R_E0 + R_E1 + R_E2;
-    static constexpr int LW = T + 2 * HALO;       // LDS plane width/height
-    static constexpr int PLANE = LW * LW;
+    static constexpr int LWX = TW + 2 * HALO, LWY = TH + 2 * HALO;  // LDS plane width / height
+    static constexpr int PLANE = LWX * LWY;
 };
+
+// Border ring of the streaming path: strips of kRingT pixels, tiles of 32 x 16 along the top / bottom
+// and 16 x 32 along the sides (same LDS plane size); the streaming kernels take everything inside.
+constexpr int kRingT = 16, kRingL = 32;
 
 template <bool TILED>
 __device__ __forceinline__ float load_in(const FusedArgs& a, int c, int x, int y) {
@@ -37,43 +41,44 @@ __device__ __forceinline__ float load_in(const FusedArgs& a, int c, int x, int y
     else return a.in[c][(size_t)y * a.in_stride + x];
 }
 
-// Refill the out-of-image cells of the square region [lo, LW-lo) of `buf` (3 planes) from their
+// Refill the out-of-image cells of the region [lo, LWX-lo) x [lo, LWY-lo) of `buf` (3 planes) from their
 // mirrored in-image cells.  (ox, oy) = image coordinate of LDS cell (0, 0).
-template <int LW>
+template <int LWX, int LWY>
 __device__ __forceinline__ void mirror_fill(float* buf, int lo, int ox, int oy, int width, int height, int t) {
-    const int n = LW - 2 * lo;
-    for (int i = t; i < n * n; i += 256) {
-        int ly = lo + i / n, lx = lo + i % n;
+    const int nx = LWX - 2 * lo, ny = LWY - 2 * lo;
+    for (int i = t; i < nx * ny; i += 256) {
+        int ly = lo + i / nx, lx = lo + i % nx;
         int x = ox + lx, y = oy + ly;
         if (x >= 0 && x < width && y >= 0 && y < height) continue;
         int sx = mirror_idx(x, width) - ox, sy = mirror_idx(y, height) - oy;
         // cells whose mirror source lies outside the region are beyond the reach of later stages
-        if (sx < lo || sx >= LW - lo || sy < lo || sy >= LW - lo) continue;
+        if (sx < lo || sx >= LWX - lo || sy < lo || sy >= LWY - lo) continue;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) buf[c * LW * LW + ly * LW + lx] = buf[c * LW * LW + sy * LW + sx];
+        for (int c = 0; c < 3; ++c) buf[c * LWX * LWY + ly * LWX + lx] = buf[c * LWX * LWY + sy * LWX + sx];
     }
 }
 
-template <int STEP, int LW>
+template <int STEP, int LWX, int LWY, int K>
 __device__ __forceinline__ void epf_stage(const float* src, float* dst, int lo, int ox, int oy, int width,
-                                          int height, const FusedArgs& a, int t, bool last, float (&res)[4][3]) {
-    const int n = LW - 2 * lo;
+                                          int height, const FusedArgs& a, int t, bool last, float (&res)[K][3]) {
+    constexpr int PLANE = LWX * LWY;
+    const int nx = LWX - 2 * lo, ny = LWY - 2 * lo;
     const float step_multiplier = STEP == 0 ? a.fp.epf_pass0_sigma_scale
                                 : STEP == 2 ? a.fp.epf_pass2_sigma_scale : 1.0f;
     int k = 0;
-    for (int i = t; i < n * n; i += 256, ++k) {
-        int ly = lo + i / n, lx = lo + i % n;
+    for (int i = t; i < nx * ny; i += 256, ++k) {
+        int ly = lo + i / nx, lx = lo + i % nx;
         int x = ox + lx, y = oy + ly;
         if (x < 0 || x >= width || y < 0 || y >= height) continue;
-        const float* p = src + ly * LW + lx;
+        const float* p = src + ly * LWX + lx;
         float o[3];
         float sigma_val = a.sigma[(size_t)(y >> 3) * a.sigma_stride + (x >> 3)];
         if (sigma_val < 0.3f) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) o[c] = p[c * LW * LW];
+            for (int c = 0; c < 3; ++c) o[c] = p[c * PLANE];
         } else {
             float sm = epf_step_mul(x, y, step_multiplier, a.fp.epf_border_sad_mul);
-            auto at = [&](int c, int dx, int dy) { return p[c * LW * LW + dy * LW + dx]; };
+            auto at = [&](int c, int dx, int dy) { return p[c * PLANE + dy * LWX + dx]; };
             epf_pixel<STEP>(at, sigma_val, sm, a.fp.epf_channel_scale, o);
         }
         if (last) {
@@ -81,32 +86,33 @@ __device__ __forceinline__ void epf_stage(const float* src, float* dst, int lo, 
             for (int c = 0; c < 3; ++c) res[k][c] = o[c];
         } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) dst[c * LW * LW + ly * LW + lx] = o[c];
+            for (int c = 0; c < 3; ++c) dst[c * PLANE + ly * LWX + lx] = o[c];
         }
     }
 }
 
-template <bool GAB, int ITERS, bool TILED>
-__device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds) {
-    using Cfg = PostCfg<GAB, ITERS>;
-    constexpr int LW = Cfg::LW, PLANE = Cfg::PLANE, HALO = Cfg::HALO;
+// TW x TH output tile; with a tile list (`a.tiles`) an entry is the tile's pixel origin x0 | y0 << 16.
+template <bool GAB, int ITERS, bool TILED, int TW = T, int TH = T>
+__device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds, uint32_t tile_index) {
+    using Cfg = PostCfg<GAB, ITERS, TW, TH>;
+    constexpr int LWX = Cfg::LWX, LWY = Cfg::LWY, PLANE = Cfg::PLANE, HALO = Cfg::HALO;
+    constexpr int K = (TW * TH + 255) / 256;  // output samples per lane
     float* bufA = lds;
     float* bufB = lds + 3 * PLANE;
     const int t = threadIdx.x;
-    int tile_x = blockIdx.x, tile_y = blockIdx.y;
+    int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
     if (a.tiles) {
-        uint32_t e = a.tiles[blockIdx.x];
-        tile_x = e & 0xffffu;
-        tile_y = e >> 16;
+        const uint32_t e = a.tiles[tile_index];
+        tx0 = e & 0xffffu;
+        ty0 = e >> 16;
     }
-    const int tx0 = tile_x * T, ty0 = tile_y * T;
     const int ox = tx0 - HALO, oy = ty0 - HALO;  // image coordinate of LDS cell (0,0)
     const int W = a.width, H = a.height;
-    const bool border = ox < 0 || oy < 0 || ox + LW > W || oy + LW > H;
+    const bool border = ox < 0 || oy < 0 || ox + LWX > W || oy + LWY > H;
 
     // ---- load tile + halo (mirrored at the image border), 3 channels
     for (int i = t; i < PLANE; i += 256) {
-        int ly = i / LW, lx = i % LW;
+        int ly = i / LWX, lx = i % LWX;
         int x = mirror_idx(ox + lx, W), y = mirror_idx(oy + ly, H);
 #pragma unroll
         for (int c = 0; c < 3; ++c) bufA[c * PLANE + i] = load_in<TILED>(a, c, x, y);
@@ -115,31 +121,31 @@ __device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds) 
 
     float* src = bufA;
     float* dst = bufB;
-    int lo = 0;  // the current stage's output region is [lo, LW - lo)^2
-    float res[4][3];
+    int lo = 0;  // the current stage's output region is [lo, LWX - lo) x [lo, LWY - lo)
+    float res[K][3];
 
     if constexpr (GAB) {
         lo += 1;
-        const int n = LW - 2 * lo;
+        const int nx = LWX - 2 * lo, ny = LWY - 2 * lo;
         constexpr bool last = ITERS == 0;
         int k = 0;
-        for (int i = t; i < n * n; i += 256, ++k) {
-            int ly = lo + i / n, lx = lo + i % n;
+        for (int i = t; i < nx * ny; i += 256, ++k) {
+            int ly = lo + i / nx, lx = lo + i % nx;
             int x = ox + lx, y = oy + ly;
             if (x < 0 || x >= W || y < 0 || y >= H) continue;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float* p = src + c * PLANE + ly * LW + lx;
-                auto at = [&](int dx, int dy) { return p[dy * LW + dx]; };
+                const float* p = src + c * PLANE + ly * LWX + lx;
+                auto at = [&](int dx, int dy) { return p[dy * LWX + dx]; };
                 float v = gabor_sample(at, x, y, W, H, a.fp.gab_weights[c][0], a.fp.gab_weights[c][1]);
                 if (last) res[k][c] = v;
-                else dst[c * PLANE + ly * LW + lx] = v;
+                else dst[c * PLANE + ly * LWX + lx] = v;
             }
         }
         if (!last) {
             __syncthreads();
             if (border) {
-                mirror_fill<LW>(dst, lo, ox, oy, W, H, t);
+                mirror_fill<LWX, LWY>(dst, lo, ox, oy, W, H, t);
                 __syncthreads();
             }
             float* tmp = src; src = dst; dst = tmp;
@@ -147,10 +153,10 @@ __device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds) 
     }
     if constexpr (ITERS == 3) {
         lo += 3;
-        epf_stage<0, LW>(src, dst, lo, ox, oy, W, H, a, t, false, res);
+        epf_stage<0, LWX, LWY, K>(src, dst, lo, ox, oy, W, H, a, t, false, res);
         __syncthreads();
         if (border) {
-            mirror_fill<LW>(dst, lo, ox, oy, W, H, t);
+            mirror_fill<LWX, LWY>(dst, lo, ox, oy, W, H, t);
             __syncthreads();
         }
         float* tmp = src; src = dst; dst = tmp;
@@ -158,11 +164,11 @@ __device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds) 
     if constexpr (ITERS >= 1) {
         lo += 2;
         constexpr bool last = ITERS == 1;
-        epf_stage<1, LW>(src, dst, lo, ox, oy, W, H, a, t, last, res);
+        epf_stage<1, LWX, LWY, K>(src, dst, lo, ox, oy, W, H, a, t, last, res);
         if (!last) {
             __syncthreads();
             if (border) {
-                mirror_fill<LW>(dst, lo, ox, oy, W, H, t);
+                mirror_fill<LWX, LWY>(dst, lo, ox, oy, W, H, t);
                 __syncthreads();
             }
             float* tmp = src; src = dst; dst = tmp;
@@ -170,21 +176,20 @@ __device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds) 
     }
     if constexpr (ITERS >= 2) {
         lo += 1;
-        epf_stage<2, LW>(src, dst, lo, ox, oy, W, H, a, t, true, res);
+        epf_stage<2, LWX, LWY, K>(src, dst, lo, ox, oy, W, H, a, t, true, res);
     }
     if constexpr (!GAB && ITERS == 0) {
         // colour only: straight from the staged tile
         int k = 0;
-        for (int i = t; i < T * T; i += 256, ++k)
+        for (int i = t; i < TW * TH; i += 256, ++k)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) res[k][c] = src[c * PLANE + (i / T) * LW + (i % T)];
+            for (int c = 0; c < 3; ++c) res[k][c] = src[c * PLANE + (i / TW) * LWX + (i % TW)];
     }
 
-    // ---- final region is the T x T tile: colour + store
-    static_assert(T * T == 4 * 256, "4 output samples per lane");
+    // ---- final region is the TW x TH tile: colour + store
     int k = 0;
-    for (int i = t; i < T * T; i += 256, ++k) {
-        int x = tx0 + i % T, y = ty0 + i / T;
+    for (int i = t; i < TW * TH; i += 256, ++k) {
+        int x = tx0 + i % TW, y = ty0 + i / TW;
         if (x >= W || y >= H) continue;
         float v[3] = {res[k][0], res[k][1], res[k][2]};
         if (a.do_color) color_pixel(a.color, v);
@@ -198,7 +203,20 @@ __device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds) 
 template <bool GAB, int ITERS, bool TILED>
 __global__ __launch_bounds__(256) void fused_post_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    fused_post_body<GAB, ITERS, TILED>(a, lds);
+    fused_post_body<GAB, ITERS, TILED>(a, lds, blockIdx.x);
+}
+
+// The border ring of the streaming path (EPF steps 1, 2): the first a.n_ring_h tiles of the list are
+// 32 x 16 (top / bottom strips), the rest 16 x 32 (left / right strips).
+template <bool GAB, bool TILED>
+__device__ __forceinline__ void ring_body(const FusedArgs& a, float* lds, uint32_t tile) {
+    if (tile < a.n_ring_h) fused_post_body<GAB, 2, TILED, kRingL, kRingT>(a, lds, tile);
+    else fused_post_body<GAB, 2, TILED, kRingT, kRingL>(a, lds, tile);
+}
+template <bool GAB, bool TILED>
+__global__ __launch_bounds__(256) void post_ring_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    ring_body<GAB, TILED>(a, lds, blockIdx.x);
 }
 
 // the border ring of n frames in one launch (blockIdx.y = frame; default pipeline only)
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(256) void post_ring_batch_kernel(FrameBatch b) {
     const FrameDevC fd = (FrameDevC)b.f[blockIdx.y];
     if (blockIdx.x >= fd->n_ring_tiles) return;
     const FusedArgs a = load_const(&fd->post);
-    fused_post_body<true, 2, true>(a, lds);
+    ring_body<true, true>(a, lds, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -550,18 +568,23 @@ hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in
     a.do_color = color ? 1u : 0u;
     a.tiles = nullptr;
     // EPF steps 1, 2 (with or without the Gabor-like stage in front) on a frame with an interior: the
-    // streaming kernel takes everything except the outer ring of tiles.
-    const int ntx = (int)ceil_div(f->width, T), nty = (int)ceil_div(f->height, T);
-    int tx_hi = ntx - 1, ty_hi = nty - 1;
-    while (tx_hi > 1 && T * tx_hi + SH > (int)f->width) --tx_hi;
-    while (ty_hi > 1 && T * ty_hi + SH > (int)f->height) --ty_hi;
+    // streaming kernel takes [sx0, sx1) x [sy0, sy1) — everything at least SH samples away from the
+    // border, cut to whole 8x8 cells — and the tile kernel the ring of 16-px strips around it.
+    const int W = (int)f->width, H = (int)f->height;
+    const int sx0 = kRingT, sy0 = kRingT, sx1 = (W - SH) / 8 * 8, sy1 = (H - SH) / 8 * 8;  // W - sx1 <= SH + 7 < kRingT
     const bool no_stream = ctx && ctx->tune.no_stream;
-    bool stream = epf_iters == 2 && tx_hi > 1 && ty_hi > 1 && !no_stream;
+    bool stream = epf_iters == 2 && W >= 64 && H >= 64 && W < 65536 && H < 65536 && !no_stream;
     if (stream && !f->ring_tiles) {
-        std::vector<uint32_t> ring;
-        for (int ty = 0; ty < nty; ++ty)
-            for (int tx = 0; tx < ntx; ++tx)
-                if (tx < 1 || tx >= tx_hi || ty < 1 || ty >= ty_hi) ring.push_back((uint32_t)tx | ((uint32_t)ty << 16));
+        std::vector<uint32_t> ring;  // pixel origins x0 | y0 << 16
+        for (int x0 = 0; x0 < W; x0 += kRingL) {  // top, bottom: 32 x 16 tiles (corners included)
+            ring.push_back((uint32_t)x0);
+            ring.push_back((uint32_t)x0 | ((uint32_t)sy1 << 16));
+        }
+        const uint32_t n_h = (uint32_t)ring.size();
+        for (int y0 = sy0; y0 < sy1; y0 += kRingL) {  // left, right: 16 x 32 tiles (the last pair may reach into
+            ring.push_back((uint32_t)y0 << 16);        // the bottom strip: the same samples, written twice)
+            ring.push_back((uint32_t)sx1 | ((uint32_t)y0 << 16));
+        }
         void* p = nullptr;
         if (ctx_dev_malloc(ctx, &p, ring.size() * 4) != hipSuccess) {
             (void)hipGetLastError();
@@ -572,12 +595,19 @@ hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in
             if (e != hipSuccess) return e;
             f->ring_tiles = static_cast<uint32_t*>(p);
             f->n_ring_tiles = (uint32_t)ring.size();
+            f->n_ring_h = n_h;
         }
     }
     *stream_out = stream;
     if (stream) {
-        a.sx0 = T; a.sx1 = T * tx_hi; a.sy0 = T; a.sy1 = T * ty_hi;
+        a.sx0 = sx0; a.sx1 = sx1; a.sy0 = sy0; a.sy1 = sy1;
+        a.n_ring_h = f->n_ring_h;
         a.rows_per_seg = rows_per_seg > 0 ? rows_per_seg : (ctx ? ctx->tune.stream_rows : 48);
+        {   // equal segments (a short last one would pay the 8 run-in rows for little output)
+            const int total = sy1 - sy0;
+            const int n = std::max(1, (total + a.rows_per_seg / 2) / a.rows_per_seg);
+            a.rows_per_seg = ((total + n - 1) / n + 3) / 4 * 4;
+        }
         // Packed kernel (two columns per lane): 8-byte aligned input / output rows, and the sign conditions under which 1 + d * s <= 1 (clamp == max(., 0)).
         const JxlGpuFilterParams& fp = a.fp;
         bool pk = !(ctx && ctx->tune.no_pk) && (out_stride & 1) == 0 && (in_tiled_w8 || (in_stride & 1) == 0) &&
@@ -636,25 +666,29 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
     if ((e = hipGetLastError()) != hipSuccess) return e;
     a.tiles = f->ring_tiles;
     // the border ring (a few hundred long-latency tiles) runs beside the streaming kernel
+    constexpr size_t ring_lds = 2 * 3 * PostCfg<true, 2, kRingL, kRingT>::PLANE * sizeof(float);
+    hipStream_t rs = side ? ctx->stream2 : s;
+    if (side && (e = hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0)) != hipSuccess) return e;
+    if (gabor) {
+        if (a.in_w8) post_ring_kernel<true, true><<<f->n_ring_tiles, 256, ring_lds, rs>>>(a);
+        else post_ring_kernel<true, false><<<f->n_ring_tiles, 256, ring_lds, rs>>>(a);
+    } else {
+        if (a.in_w8) post_ring_kernel<false, true><<<f->n_ring_tiles, 256, ring_lds, rs>>>(a);
+        else post_ring_kernel<false, false><<<f->n_ring_tiles, 256, ring_lds, rs>>>(a);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     if (side) {
-        if ((e = hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0)) != hipSuccess) return e;
-        if ((e = launch_tile_kernel(ctx->stream2, a, gabor, 2, dim3(f->n_ring_tiles))) != hipSuccess) return e;
         if ((e = hipEventRecord(ctx->ev_join, ctx->stream2)) != hipSuccess) return e;
         return hipStreamWaitEvent(s, ctx->ev_join, 0);
     }
-    return launch_tile_kernel(s, a, gabor, 2, dim3(f->n_ring_tiles));
+    return hipSuccess;
 }
 
 // Default pipeline of n frames: streaming kernel on `s`, border rings beside it on `side` (may be
 // null: same stream).  The caller forks / joins the two streams once per batch.
 hipError_t launch_post_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, uint32_t max_stream_wgs,
                              uint32_t max_ring, bool pk) {
-    constexpr size_t lds_bytes = 2 * 3 * PostCfg<true, 2>::PLANE * sizeof(float);
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&post_ring_batch_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    });
+    constexpr size_t lds_bytes = 2 * 3 * PostCfg<true, 2, kRingL, kRingT>::PLANE * sizeof(float);  // 23 KB
     if (max_ring) post_ring_batch_kernel<<<dim3(max_ring, n), 256, lds_bytes, side ? side : s>>>(b);
     if (max_stream_wgs && pk) post_pk_batch_kernel<<<dim3(max_stream_wgs, n), 256, 0, s>>>(b);
     else if (max_stream_wgs) post_stream_batch_kernel<<<dim3(max_stream_wgs, n), 256, 0, s>>>(b);
