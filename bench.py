@@ -285,9 +285,9 @@ def make_job(config, distinct):
             "render": lambda ctx, frames: ctx.vardct_render_batch(frames, stages),
             "groups": (1, 2),
             "group_names": {1: "transform: transform_items_batch_kernel<0..3> + transform_special_batch_kernel (V4-V8)",
-                            2: "post: post_stream_batch_kernel (+ post_ring_batch_kernel beside it): Gabor + EPF steps 1,2 + XYB->sRGB"},
+                            2: "post: post_pk_batch_kernel (+ post_ring_batch_kernel beside it): Gabor + EPF steps 1,2 + XYB->sRGB"},
             "alg_bytes": alg_bytes, "verify": verify,
-            "traffic": pmc_traffic({1: ("transform_",), 2: ("post_stream", "post_ring")}),
+            "traffic": pmc_traffic({1: ("transform_",), 2: ("post_pk", "post_stream", "post_ring")}),
         }
     if config == 5:
         from jxl_oxide_amd.synth import VardctWorkload
