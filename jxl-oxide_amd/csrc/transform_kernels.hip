@@ -1,6 +1,6 @@
 // V4-V8 on gfx950: HF dequantisation, chroma-from-luma, LF -> LLF injection and the inverse
 // variable-size DCT (jxl-render/src/vardct/mod.rs:442-682, transform_common.rs:11-75,
-// generic/{dct,transform}.rs), one WAVE per work item, no workgroup barriers.
+// generic/{dct,transform}.rs): one 192-thread workgroup (a wave per channel) per work item.
 //
 // Layout the kernels rely on: the i32 coefficients live in HBM as 8x8 cells,
 // channel-interleaved — cell (cx, cy) is 3 x 64 words {X, Y, B}, each 8 rows of 8 — so any
