@@ -251,7 +251,10 @@ int jxlgpu_profile_read(jxlgpu_ctx* ctx, double* total_ms, uint64_t* brackets);
 int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* desc, jxlgpu_frame** out_frame);
 /* Run the selected stages on the device.  `out` may be NULL (results stay in the frame's device
  * buffers, e.g. for benchmarking); otherwise the result of the last selected stage is written to
- * `out` (D2H copy for JXLGPU_MEM_HOST, followed by a stream synchronisation).                     */
+ * `out` (D2H copy for JXLGPU_MEM_HOST, followed by a stream synchronisation).  A `stages` mask
+ * without JXLGPU_STAGE_TRANSFORM produces the LF planes only (jxlgpu_frame_download_lf reads
+ * them): passing `out` with it is JXLGPU_ERR_INVALID_ARG.  Frames (after upsampling) taller than
+ * 65535 rows are rejected at upload with JXLGPU_ERR_UNSUPPORTED.                                    */
 int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* frame, uint32_t stages, const JxlGpuOut* out);
 /* Batch variant: `n` uploaded frames, one launch per stage for all of them — what the
  * reference's callers do with a parallel loop over keyframes (jxl-oxide-cli/src/decode.rs:293-304).
@@ -299,7 +302,9 @@ typedef struct {
     uint32_t width, height;
 } JxlGpuBlendRect;
 /* `base` (base_w x base_h, stride base_stride) and `new_plane` are device pointers, e.g. from
- * jxlgpu_frame_result_plane.  Asynchronous on the ctx stream.                                       */
+ * jxlgpu_frame_result_plane.  Runs on the ctx stream and returns after it has finished (the copy
+ * of the rectangle list on the device is released before the call returns).  A rectangle taller
+ * than 65535 rows is rejected (JXLGPU_ERR_UNSUPPORTED).                                             */
 int jxlgpu_blend_rects(jxlgpu_ctx* ctx, float* base, uint32_t base_stride, uint32_t base_w, uint32_t base_h,
                        const float* new_plane, uint32_t new_stride, uint32_t new_w, uint32_t new_h,
                        const JxlGpuBlendRect* rects, uint32_t num_rects);

@@ -437,6 +437,8 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     if (d->filter.epf_iters > 3) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "epf_iters > 3");
     const uint32_t upf = d->upsampling.factor ? d->upsampling.factor : 1;
     if (upf != 1 && upf != 2 && upf != 4 && upf != 8) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "bad upsampling factor");
+    // several per-row kernels launch one grid row per image row (HIP: grid.y <= 65535)
+    if ((uint64_t)d->height * upf > 65535u) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "output taller than 65535 rows");
     if (d->coeff_format > JXLGPU_COEFF_SPARSE || d->coeff_sample_type > JXLGPU_SAMPLE_I16)
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "bad coeff_format / coeff_sample_type");
     for (int c = 0; c < 3; ++c) {
@@ -928,6 +930,7 @@ int upload_subsampled(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_frame**
         return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "sparse coefficient transport on a chroma-subsampled frame");
     if (d->width == 0 || d->height == 0 || d->width > (1u << 18) || d->height > (1u << 18))
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "bad frame size");
+    if (d->height > 65535u) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "output taller than 65535 rows");
     if (!d->lf_groups) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "no LF groups");
     // ChannelShift::from_jpeg_upsampling, param.rs:105-122
     bool has_h = false, has_v = false;
@@ -1148,6 +1151,7 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
     if (!(stages & JXLGPU_STAGE_TRANSFORM)) {
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipStreamSynchronize(s));
+        if (out) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "an LF-only render has no pixel output: use jxlgpu_frame_download_lf");
         return JXLGPU_OK;
     }
 

@@ -99,6 +99,7 @@ extern "C" int jxlgpu_blend_rects(jxlgpu_ctx* ctx, float* base, uint32_t base_st
         if (r.base_alpha && r.base_alpha_stride < base_w) return bad("base_alpha_stride < width");
         max_w = std::max(max_w, r.width); max_h = std::max(max_h, r.height);
     }
+    if (max_h > 65535u) { ctx->last_error = "blend rectangle taller than 65535 rows"; return JXLGPU_ERR_UNSUPPORTED; }
     if (num_rects == 0 || max_w == 0 || max_h == 0) return JXLGPU_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     void* d_rects = nullptr;

@@ -1754,6 +1754,9 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
     // geometry of the colour image for the float tail
     f->width = d->channels[0].width;
     f->height = d->channels[0].height;
+    // several per-row kernels launch one grid row per image row (HIP: grid.y <= 65535)
+    if ((uint64_t)f->height * (d->upsampling.factor ? d->upsampling.factor : 1) > 65535u)
+        return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "output taller than 65535 rows");
     f->w8 = ceil_div(f->width, 8); f->h8 = ceil_div(f->height, 8);
     f->wr = f->w8 * 8; f->hr = f->h8 * 8;
     f->desc.filter = d->filter;

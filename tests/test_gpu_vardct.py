@@ -301,6 +301,20 @@ def test_error_codes(gpu_ctx):
     with pytest.raises(Exception) as e:
         gpu_ctx.vardct_upload(d)
     assert e.value.code == abi.ERR_INVALID_ARG
+    # an LF-only render has no pixel output to copy
+    frame = gpu_ctx.vardct_upload(wl.desc())
+    try:
+        with pytest.raises(Exception) as e:
+            gpu_ctx.vardct_render(frame, abi.STAGE_LF)
+        assert e.value.code == abi.ERR_INVALID_ARG
+    finally:
+        frame.free()
+    # per-row kernels use one grid row per image row: outputs taller than 65535 rows are refused at upload
+    d = wl.desc()
+    d.height = 70000
+    with pytest.raises(Exception) as e:
+        gpu_ctx.vardct_upload(d)
+    assert e.value.code == abi.ERR_UNSUPPORTED
 
 
 @pytest.mark.parametrize("fmt", [abi.FMT_F32, abi.FMT_U16, abi.FMT_U8])
