@@ -218,6 +218,7 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
     using C = RCfg<W, H>;
     constexpr int BW = C::BW, BH = C::BH, NBI = C::NBI, RP = C::RP, CP = C::CP, S = C::S, BS = C::BS;
     constexpr int TYPE = type_of<W, H>();
+    constexpr bool PAR_LLF = BW >= 4 && BH >= 4;  // LF -> LLF forward DCT spread over lanes (32 / 64-px shapes)
     float* lut = lds;
     float* T = lds + kLutWords + wave * C::WAVE_WORDS;
     float* llf = T + C::T_WORDS;
@@ -266,7 +267,7 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
             g.ccx[q] = pos & 0xffffu;
             g.ccy[q] = pos >> 16;
         }
-        g.lpos = ent[min(lane, nv - 1)].x;
+        g.lpos = ent[min(PAR_LLF ? lane / BH : lane, nv - 1)].x;  // the varblock whose LF samples this lane loads
     };
     auto issue_loads = [&](const Geo<RP, CP>& g, Pre<RP, W, BW, BH>& pr) __attribute__((always_inline)) {
 #pragma unroll
@@ -279,7 +280,13 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
             pr.k1[p] = kmap[(py >> 6) * a.w64 + ((px0 + W - 1) >> 6)];
             pr.split[p] = 64 - (int)(px0 & 63u);
         }
-        if (lane < NBI) {
+        if constexpr (PAR_LLF) {
+            if (lane < NBI * BH) {  // lane = (varblock, LF row): one row of BW samples
+                const size_t cell = (size_t)((g.lpos >> 16) + (uint32_t)(lane % BH)) * a.w8 + (g.lpos & 0xffffu);
+#pragma unroll
+                for (int x = 0; x < BW; ++x) pr.lfv[0][x] = lfp[cell + x];
+            }
+        } else if (lane < NBI) {
             const size_t cell = (size_t)(g.lpos >> 16) * a.w8 + (g.lpos & 0xffffu);
 #pragma unroll
             for (int y = 0; y < BH; ++y)
@@ -319,7 +326,34 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
         // ---- V6 first half: LF -> lowest-frequency coefficients of this channel
         //      (transform_common.rs:40-66: copy the BW x BH LF samples, forward DCT, divide by the
         //      scale_f products); one lane per varblock, parked in LDS for the row lanes.
-        if (lane < NBI) {
+        if constexpr (PAR_LLF) {
+            // >= 4 x 4 LF samples: the generic branch of fdct2d_small (rows, then columns, independent 1-D
+            // transforms) spread over lanes — BH row lanes, the wave's llf patch as the transposition
+            // buffer, BW column lanes — instead of one lane doing BH + BW transforms and BW * BH divisions
+            // (measured: ~7 k of the ~36 k cycles of a 64 x 64 item)
+            if (lane < NBI * BH) {
+                float r[BW];
+#pragma unroll
+                for (int x = 0; x < BW; ++x) r[x] = pr.lfv[0][x];
+                fdct<BW>(r, sl);
+                float* dst = llf + lane * BW;  // [varblock][y][x]
+#pragma unroll
+                for (int x = 0; x < BW; ++x) dst[x] = r[x];
+            }
+            wave_lds_sync();
+            if (lane < NBI * BW) {
+                const int blk = lane / BW, x = lane % BW;
+                float* colp = llf + blk * (BW * BH) + x;
+                float col[BH];
+#pragma unroll
+                for (int y = 0; y < BH; ++y) col[y] = colp[y * BW];
+                fdct<BH>(col, sl);
+                constexpr int sy = 5 - __builtin_ctz(BH), sx = 5 - __builtin_ctz(BW);
+                const float fx = kScaleF[x << sx];
+#pragma unroll
+                for (int y = 0; y < BH; ++y) colp[y * BW] = col[y] / (kScaleF[y << sy] * fx);
+            }
+        } else if (lane < NBI) {
             float v[BH][BW];
 #pragma unroll
             for (int y = 0; y < BH; ++y)
