@@ -349,7 +349,9 @@ __device__ __forceinline__ void run_class(const TransformArgs& a, const uint4* _
                 for (int y = 0; y < BH; ++y) col[y] = colp[y * BW];
                 fdct<BH>(col, sl);
                 constexpr int sy = 5 - __builtin_ctz(BH), sx = 5 - __builtin_ctz(BW);
-                const float fx = kScaleF[x << sx];
+                float fx = kScaleF[0];  // kScaleF[x << sx] through selects on immediates: a table lookup here is a
+#pragma unroll                  // global load whose latency nothing hides
+                for (int i = 1; i < BW; ++i) fx = x == i ? kScaleF[i << sx] : fx;
 #pragma unroll
                 for (int y = 0; y < BH; ++y) colp[y * BW] = col[y] / (kScaleF[y << sy] * fx);
             }
