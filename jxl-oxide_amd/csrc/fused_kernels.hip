@@ -23,9 +23,12 @@ constexpr int T = 32;  // output tile
 template <bool GAB, int ITERS, int TW = T, int TH = T>
 struct PostCfg {
     static constexpr int R_GAB = GAB ? 1 : 0;
-    static constexpr int R_E0 = ITERS == 3 ? 3 : 0;
-    static constexpr int R_E1 = ITERS >= 1 ? 2 : 0;
-    static constexpr int R_E2 = ITERS >= 2 ? 1 : 0;
+    // ITERS: 0-3 = the frame's epf_iters (3: steps 0, 1, 2; 2: steps 1, 2; 1: step 1);
+    //        4 = step 0 alone (first pass of the split iters-3 path, launch_fused_post)
+    static constexpr bool HAS_E0 = ITERS == 3 || ITERS == 4, HAS_E1 = ITERS >= 1 && ITERS <= 3, HAS_E2 = ITERS == 2 || ITERS == 3;
+    static constexpr int R_E0 = HAS_E0 ? 3 : 0;
+    static constexpr int R_E1 = HAS_E1 ? 2 : 0;
+    static constexpr int R_E2 = HAS_E2 ? 1 : 0;
     static constexpr int HALO = R_GAB + R_E0 + R_E1 + R_E2;
     static constexpr int LWX = TW + 2 * HALO, LWY = TH + 2 * HALO;  // LDS plane width / height
     static constexpr int PLANE = LWX * LWY;
@@ -151,17 +154,20 @@ __device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds, 
             float* tmp = src; src = dst; dst = tmp;
         }
     }
-    if constexpr (ITERS == 3) {
+    if constexpr (Cfg::HAS_E0) {
         lo += 3;
-        epf_stage<0, LWX, LWY, K>(src, dst, lo, ox, oy, W, H, a, t, false, res);
-        __syncthreads();
-        if (border) {
-            mirror_fill<LWX, LWY>(dst, lo, ox, oy, W, H, t);
+        constexpr bool last = ITERS == 4;
+        epf_stage<0, LWX, LWY, K>(src, dst, lo, ox, oy, W, H, a, t, last, res);
+        if (!last) {
             __syncthreads();
+            if (border) {
+                mirror_fill<LWX, LWY>(dst, lo, ox, oy, W, H, t);
+                __syncthreads();
+            }
+            float* tmp = src; src = dst; dst = tmp;
         }
-        float* tmp = src; src = dst; dst = tmp;
     }
-    if constexpr (ITERS >= 1) {
+    if constexpr (Cfg::HAS_E1) {
         lo += 2;
         constexpr bool last = ITERS == 1;
         epf_stage<1, LWX, LWY, K>(src, dst, lo, ox, oy, W, H, a, t, last, res);
@@ -174,7 +180,7 @@ __device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds, 
             float* tmp = src; src = dst; dst = tmp;
         }
     }
-    if constexpr (ITERS >= 2) {
+    if constexpr (Cfg::HAS_E2) {
         lo += 1;
         epf_stage<2, LWX, LWY, K>(src, dst, lo, ox, oy, W, H, a, t, true, res);
     }
@@ -532,15 +538,17 @@ hipError_t launch_cfg(hipStream_t s, const FusedArgs& a, dim3 grid) {
 }
 
 hipError_t launch_tile_kernel(hipStream_t s, const FusedArgs& a, bool gabor, int epf_iters, dim3 grid) {
-    switch ((gabor ? 4 : 0) + epf_iters) {
+    switch ((gabor ? 5 : 0) + epf_iters) {
         case 0: return launch_cfg<false, 0>(s, a, grid);
         case 1: return launch_cfg<false, 1>(s, a, grid);
         case 2: return launch_cfg<false, 2>(s, a, grid);
         case 3: return launch_cfg<false, 3>(s, a, grid);
-        case 4: return launch_cfg<true, 0>(s, a, grid);
-        case 5: return launch_cfg<true, 1>(s, a, grid);
-        case 6: return launch_cfg<true, 2>(s, a, grid);
-        default: return launch_cfg<true, 3>(s, a, grid);
+        case 4: return launch_cfg<false, 4>(s, a, grid);
+        case 5: return launch_cfg<true, 0>(s, a, grid);
+        case 6: return launch_cfg<true, 1>(s, a, grid);
+        case 7: return launch_cfg<true, 2>(s, a, grid);
+        case 8: return launch_cfg<true, 3>(s, a, grid);
+        default: return launch_cfg<true, 4>(s, a, grid);
     }
 }
 
@@ -634,8 +642,23 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
                              bool color, jxlgpu_ctx* ctx) {
     FusedArgs a;
     bool stream = false, plain_srgb = false;
-    hipError_t e = fused_prepare(ctx, f, in, in_stride, in_tiled_w8, out, out_stride, gabor, epf_iters, color, &a, &stream,
-                                 &plain_srgb, 0);
+    hipError_t e;
+    // epf_iters == 3 on a frame the streaming kernels can take: step 0 (+ the Gabor-like stage) through
+    // the tile kernel into the frame's spare plane set, then steps 1, 2 (+ colour) through the streaming
+    // path — every stage still mirrors its own input at the border.  The all-in-one tile kernel pays
+    // a 7-sample halo (46 x 46 cells per 32 x 32 outputs) for three stages.
+    if (epf_iters == 3 && in_tiled_w8 && f->buf_b[0] && f->width >= 64 && f->height >= 64 && f->width < 65536 &&
+        f->height < 65536 && !(ctx && ctx->tune.no_stream)) {
+        float* const* tmp = out[0] == f->buf_a[0] ? f->buf_b : f->buf_a;
+        e = fused_prepare(ctx, f, in, in_stride, in_tiled_w8, tmp, f->wr, gabor, 4, false, &a, &stream, &plain_srgb, 0);
+        if (e != hipSuccess) return e;
+        e = launch_tile_kernel(s, a, gabor, 4, dim3(ceil_div(f->width, T), ceil_div(f->height, T)));
+        if (e != hipSuccess) return e;
+        const float* const in2[3] = {tmp[0], tmp[1], tmp[2]};
+        return launch_fused_post(s, f, in2, f->wr, 0u, out, out_stride, false, 2, color, ctx);
+    }
+    e = fused_prepare(ctx, f, in, in_stride, in_tiled_w8, out, out_stride, gabor, epf_iters, color, &a, &stream,
+                      &plain_srgb, 0);
     if (e != hipSuccess) return e;
     if (!stream) return launch_tile_kernel(s, a, gabor, epf_iters, dim3(ceil_div(f->width, T), ceil_div(f->height, T)));
     const int waves = a.strips * a.segs;
