@@ -260,9 +260,11 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* frame, uint32_t stages, 
  * reference's callers do with a parallel loop over keyframes (jxl-oxide-cli/src/decode.rs:293-304).
  * Asynchronous, like a render with out == NULL: after jxlgpu_synchronize the results are on the
  * device (jxlgpu_frame_result_plane / jxlgpu_frame_download_result / jxlgpu_frame_format_output).
- * Frames of different sizes may be mixed.  Frames or stage masks outside the batched default
- * pipeline (all stages; Gabor + EPF iters 2; no upsampling / noise; plain XYB -> sRGB; no varblock
- * >= 128 px; no chroma subsampling) are rendered one by one by the same call: same results.        */
+ * Frames of different sizes may be mixed.  V1-V8 share launches unless a frame has a varblock
+ * >= 128 px, chroma subsampling or LF-only groups; the post stage shares launches for the default
+ * pipeline (all stages; Gabor + EPF iters 2; no upsampling / noise; plain XYB -> sRGB) and follows
+ * frame by frame for anything else.  Whatever does not qualify is rendered one by one by the same
+ * call: same results.                                                                              */
 int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uint32_t n, uint32_t stages);
 /* Copy the result of the frame's last render to `out` (planar f32; host or device memory). */
 int jxlgpu_frame_download_result(jxlgpu_ctx* ctx, jxlgpu_frame* frame, const JxlGpuOut* out);

@@ -1187,10 +1187,12 @@ static int ensure_dev_args(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     f->batch_ok = false;
     const JxlGpuVardctDesc& d = f->desc;
     const uint32_t upf = d.upsampling.factor ? d.upsampling.factor : 1;
+    f->batch_tr_ok = false;
+    // V1-V8 of any single-geometry frame made of <= 64-px varblocks can share launches ...
     if (f->kind_of_frame != 0 || !f->subs.empty() || !f->buf_a[0] || f->list_count[CLS_BIG] || f->nometa_count) return JXLGPU_OK;
-    if (!d.filter.gab_enabled || d.filter.epf_iters != 2 || upf != 1 || d.noise.enabled || !d.color.enabled || d.color.ycbcr)
-        return JXLGPU_OK;
-    if (!fused_post_supported(ctx, f, true, 2)) return JXLGPU_OK;
+    // ... the post stage only for the default pipeline (Gabor + EPF iters 2 + plain XYB -> sRGB, no upsampling / noise)
+    const bool post_default = d.filter.gab_enabled && d.filter.epf_iters == 2 && upf == 1 && !d.noise.enabled &&
+                              d.color.enabled && !d.color.ycbcr && fused_post_supported(ctx, f, true, 2);
     FrameDev h;
     memset(&h, 0, sizeof(h));
     fill_lf_args(f, &h.lf, &h.smooth);
@@ -1203,41 +1205,53 @@ static int ensure_dev_args(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     h.entries = f->entries;
     h.special_first = f->class_first[CLS_SPECIAL8];
     h.special_count = f->list_count[CLS_SPECIAL8];
-    const float* in[3] = {f->pix_t, nullptr, nullptr};
-    bool stream = false, plain_srgb = false;
-    // batched launches have waves to spare: taller wave segments (less halo-row recompute)
-    HIP_TRY(ctx, fused_prepare(ctx, f, in, f->wr, f->w8, f->buf_a, f->wr, true, 2, true, &h.post, &stream, &plain_srgb,
-                               ctx->tune.batch_stream_rows));
-    if (!stream || !plain_srgb) return JXLGPU_OK;
-    f->batch_pk = h.post.pk != 0;
-    if (f->batch_pk == ctx->tune.no_pk) return JXLGPU_OK;  // one kernel per batched launch: the odd frame renders alone
-    h.post.tiles = f->ring_tiles;
-    h.n_ring_tiles = f->n_ring_tiles;
-    f->batch_stream_wgs = (uint32_t)(h.post.strips * h.post.segs + 3) / 4;
+    bool post_ok = false;
+    if (post_default) {
+        const float* in[3] = {f->pix_t, nullptr, nullptr};
+        bool stream = false, plain_srgb = false;
+        // batched launches have waves to spare: taller wave segments (less halo-row recompute)
+        HIP_TRY(ctx, fused_prepare(ctx, f, in, f->wr, f->w8, f->buf_a, f->wr, true, 2, true, &h.post, &stream, &plain_srgb,
+                                   ctx->tune.batch_stream_rows));
+        f->batch_pk = h.post.pk != 0;
+        // one kernel per batched launch: a frame that needs the other streaming kernel renders its post stage alone
+        post_ok = stream && plain_srgb && f->batch_pk != ctx->tune.no_pk;
+        if (post_ok) {
+            h.post.tiles = f->ring_tiles;
+            h.n_ring_tiles = f->n_ring_tiles;
+            f->batch_stream_wgs = (uint32_t)(h.post.strips * h.post.segs + 3) / 4;
+        }
+    }
     TRY(dev_alloc(ctx, f, &f->dev_args, 1));
     HIP_TRY(ctx, hipMemcpy(f->dev_args, &h, sizeof(h), hipMemcpyHostToDevice));
-    f->batch_ok = true;
+    f->batch_tr_ok = true;
+    f->batch_ok = post_ok;
     return JXLGPU_OK;
 }
 
 // N frames, one launch per stage (SURVEY §8b "batch variants taking N descs"; the caller pattern is
 // jxl-oxide-cli/src/decode.rs:293-304, keyframes rendered in a parallel loop).  Asynchronous like a
 // render without an output descriptor: results stay on the device (jxlgpu_frame_result_plane,
-// jxlgpu_frame_format_output) after jxlgpu_synchronize.  Frames that do not qualify for the batched
-// default pipeline (other filter settings, upsampling, noise, >= 128-px varblocks, chroma
-// subsampling, ...) or a `stages` mask without the full pipeline are rendered one by one.
+// jxlgpu_frame_format_output) after jxlgpu_synchronize.  V1-V8 share launches unless a frame has
+// >= 128-px varblocks, chroma subsampling or LF-only groups; the post stage shares launches for the
+// default pipeline (Gabor + EPF iters 2 + plain XYB -> sRGB) and follows frame by frame otherwise
+// (other filter settings, upsampling, noise, other colour chains).
 int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uint32_t n, uint32_t stages) {
     if (!ctx || (!frames && n)) return JXLGPU_ERR_INVALID_ARG;
     for (uint32_t i = 0; i < n; ++i)
         if (!frames[i] || frames[i]->kind_of_frame != 0) return JXLGPU_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const uint32_t need = JXLGPU_STAGE_LF | JXLGPU_STAGE_TRANSFORM | JXLGPU_STAGE_GABOR | JXLGPU_STAGE_EPF | JXLGPU_STAGE_COLOR;
+    const uint32_t need_tr = JXLGPU_STAGE_LF | JXLGPU_STAGE_TRANSFORM;
+    const uint32_t need = need_tr | JXLGPU_STAGE_GABOR | JXLGPU_STAGE_EPF | JXLGPU_STAGE_COLOR;
+    // V1-V8 share launches whenever every frame's transform qualifies; the post stage as well when every
+    // frame runs the default pipeline, otherwise it follows frame by frame on the transformed batch
+    bool batched_tr = (stages & need_tr) == need_tr && n > 0;
     bool batched = (stages & need) == need;
-    for (uint32_t i = 0; i < n && batched; ++i) {
+    for (uint32_t i = 0; i < n && batched_tr; ++i) {
         TRY(ensure_dev_args(ctx, frames[i]));
-        batched = frames[i]->batch_ok;
+        batched_tr = frames[i]->batch_tr_ok;
+        batched = batched && frames[i]->batch_ok;
     }
-    if (!batched) {
+    if (!batched_tr) {
         for (uint32_t i = 0; i < n; ++i) TRY(jxlgpu_vardct_render(ctx, frames[i], stages, nullptr));
         return JXLGPU_OK;
     }
@@ -1269,6 +1283,19 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
         ctx->prof_begin(PROF_TRANSFORM, st);
         HIP_TRY(ctx, launch_transform_batch(st, b, m, max_wgs, max_special));
         ctx->prof_end(PROF_TRANSFORM, st);
+        if (!batched) {
+            for (uint32_t i = 0; i < m; ++i) {
+                jxlgpu_frame* f = frames[i0 + i];
+                float* cur[3] = {nullptr, nullptr, nullptr};  // the input of the post stages is the tiled f->pix_t
+                uint32_t stride = f->wr, ow = f->width, oh = f->height;
+                ctx->prof_begin(PROF_POST);
+                TRY(run_post_stages(ctx, f, stages, f->desc.filter, f->desc.upsampling.factor ? f->desc.upsampling.factor : 1,
+                                    cur, &stride, &ow, &oh, true));
+                ctx->prof_end(PROF_POST);
+                TRY(finish_render(ctx, f, cur, stride, ow, oh, nullptr));
+            }
+            continue;
+        }
         ctx->prof_begin(PROF_POST, sp);
         // one fork / join per launch: the border rings run beside the streaming kernel
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, sp));

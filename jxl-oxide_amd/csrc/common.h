@@ -306,7 +306,8 @@ struct jxlgpu_frame {
     float* deq_lut = nullptr;            // quant_bias_numerator / k, k < 256 (dequant_one_lut)
     FrameDev* dev_args = nullptr;        // device copy of the default pipeline's arguments (batched launches)
     bool dev_args_ready = false;
-    bool batch_ok = false;               // the frame qualifies for the batched default pipeline
+    bool batch_ok = false;               // the frame qualifies for the batched default pipeline (V1-V8 and post)
+    bool batch_tr_ok = false;            // V1-V8 of the frame can share launches (any post pipeline)
     uint32_t batch_wgs[4] = {}, batch_stream_wgs = 0;
     bool batch_pk = false;               // the batched post launch of this frame is the packed kernel
     uint32_t* ring_tiles = nullptr;      // border ring of the streaming post path: tile origins x0 | y0 << 16

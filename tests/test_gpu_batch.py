@@ -71,3 +71,24 @@ def test_batch_with_frames_outside_the_default_pipeline(gpu_ctx):
     finally:
         for f in frames:
             f.free()
+
+
+def test_batch_with_non_default_post_pipelines(gpu_ctx, oracle):
+    """Frames whose post stage is not the default pipeline (EPF iters 3 + 2x upsampling + PQ, no Gabor,
+    iters 1) still share the V1-V8 launches of a batch; their post stages follow frame by frame."""
+    from jxl_oxide_amd.synth import VardctWorkload
+    wls = [VardctWorkload(264, 200, seed=90, epf_iters=3, upsampling=2, intensity_target=4000.0, hdr_pq=True),
+           VardctWorkload(328, 136, seed=91, epf_iters=1, gabor=False),
+           VardctWorkload(200, 264, seed=92)]
+    frames = [gpu_ctx.vardct_upload(wl.desc()) for wl in wls]
+    try:
+        gpu_ctx.vardct_render_batch(frames, abi.STAGE_ALL)
+        gpu_ctx.synchronize()
+        for wl, f in zip(wls, frames):
+            ow, oh = wl.out_size(abi.STAGE_ALL)
+            exp, _ = oracle.vardct_render(wl.desc(), abi.STAGE_ALL, ow, oh)
+            got = gpu_ctx.download_result(f, abi.STAGE_ALL)
+            assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (wl.width, wl.height)
+    finally:
+        for f in frames:
+            f.free()
