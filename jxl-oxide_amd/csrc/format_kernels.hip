@@ -46,6 +46,32 @@ __global__ __launch_bounds__(256) void format_kernel(FormatArgs a) {
     }
 }
 
+// u8, orientation 1, width a multiple of 4, 16-byte aligned rows: four pixels per lane — three 16-byte
+// loads, 12 bytes out as three dwords (the one-pixel form writes single bytes: a quarter of a dword
+// per store).  Same conversion per sample.
+__global__ __launch_bounds__(256) void format_u8_x4_kernel(FormatArgs a) {
+    const uint32_t x4 = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x4 * 4 >= a.ow) return;
+    const size_t gi = (size_t)y * a.in_stride + x4 * 4;
+    float v[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float4 t = *reinterpret_cast<const float4*>(a.in[c] + gi);
+        v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
+    }
+    uint32_t b[12];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float t = clampf(v[c][p] * 255.0f + 0.5f, 0.0f, 255.0f);
+            b[p * 3 + c] = t != t ? 0u : (uint32_t)(uint8_t)t;
+        }
+    uint32_t* o = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a.out) + ((size_t)y * a.ow + x4 * 4) * 3);
+#pragma unroll
+    for (int w = 0; w < 3; ++w) o[w] = b[4 * w] | (b[4 * w + 1] << 8) | (b[4 * w + 2] << 16) | (b[4 * w + 3] << 24);
+}
+
 }  // namespace
 
 extern "C" int jxlgpu_frame_format_output(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuFormatDesc* fmt, void* out,
@@ -79,7 +105,11 @@ extern "C" int jxlgpu_frame_format_output(jxlgpu_ctx* ctx, jxlgpu_frame* f, cons
     for (int c = 0; c < 3; ++c) a.in[c] = f->result[c];
     a.out = dst; a.in_stride = f->result_stride; a.ow = ow; a.oh = oh; a.orientation = fmt->orientation;
     dim3 grid(ceil_div(ow, 256), oh);
-    if (fmt->sample_format == JXLGPU_FMT_F32) format_kernel<JXLGPU_FMT_F32><<<grid, 256, 0, ctx->stream>>>(a);
+    const bool x4 = fmt->sample_format == JXLGPU_FMT_U8 && fmt->orientation == 1 && (ow & 3) == 0 && (a.in_stride & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(dst) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.in[0]) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.in[1]) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.in[2]) & 15) == 0;
+    if (x4) format_u8_x4_kernel<<<dim3(ceil_div(ow / 4, 256), oh), 256, 0, ctx->stream>>>(a);
+    else if (fmt->sample_format == JXLGPU_FMT_F32) format_kernel<JXLGPU_FMT_F32><<<grid, 256, 0, ctx->stream>>>(a);
     else if (fmt->sample_format == JXLGPU_FMT_U16) format_kernel<JXLGPU_FMT_U16><<<grid, 256, 0, ctx->stream>>>(a);
     else format_kernel<JXLGPU_FMT_U8><<<grid, 256, 0, ctx->stream>>>(a);
     HIP_TRY(ctx, hipGetLastError());

@@ -320,16 +320,17 @@ def test_error_codes(gpu_ctx):
 @pytest.mark.parametrize("fmt", [abi.FMT_F32, abi.FMT_U16, abi.FMT_U8])
 def test_device_output_formatting(gpu_ctx, oracle, fmt):
     """interleave + orientation + u8/u16 conversion on the device."""
-    wl = VardctWorkload(136, 72, seed=21)
-    d = wl.desc()
-    planes, _ = oracle.vardct_render(d, S_ALL, wl.width, wl.height)
-    frame = gpu_ctx.vardct_upload(d)
-    try:
-        gpu_ctx.vardct_render(frame, S_ALL, to_host=False)
-        for o in range(1, 9):
-            got = gpu_ctx.format_output(frame, fmt, o)
-            exp = oracle.format_output(planes, fmt, o)
-            assert got.shape == exp.shape
-            assert np.array_equal(got.view(np.uint8), exp.view(np.uint8)), f"fmt {fmt} orientation {o}"
-    finally:
-        frame.free()
+    for size in ((136, 72), (134, 70)):  # a multiple of 4 (four-pixel u8 kernel) and not
+        wl = VardctWorkload(size[0], size[1], seed=21)
+        d = wl.desc()
+        planes, _ = oracle.vardct_render(d, S_ALL, wl.width, wl.height)
+        frame = gpu_ctx.vardct_upload(d)
+        try:
+            gpu_ctx.vardct_render(frame, S_ALL, to_host=False)
+            for o in range(1, 9):
+                got = gpu_ctx.format_output(frame, fmt, o)
+                exp = oracle.format_output(planes, fmt, o)
+                assert got.shape == exp.shape
+                assert np.array_equal(got.view(np.uint8), exp.view(np.uint8)), f"{size} fmt {fmt} orientation {o}"
+        finally:
+            frame.free()
