@@ -309,6 +309,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
         if (r >= 0 && r <= JXLGPU_MAX_BATCH) ctx->tune.batch_chunk = r;
     }
     ctx->tune.no_pk = getenv("JXLGPU_NO_PK") != nullptr;
+    if (const char* e = getenv("JXLGPU_TR_SIDE_MAX")) ctx->tune.tr_side_max = atoi(e);
     ctx->tune.no_stream = getenv("JXLGPU_NO_STREAM") != nullptr;
     ctx->tune.no_fused = getenv("JXLGPU_NO_FUSED") != nullptr;
     ctx->tune.debug_sync = getenv("JXLGPU_DEBUG_SYNC") != nullptr;
@@ -1281,7 +1282,15 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
         HIP_TRY(ctx, launch_lf_batch(st, b, m, max_w8, max_h8, any_smooth));
         ctx->prof_end(PROF_LF, st);
         ctx->prof_begin(PROF_TRANSFORM, st);
-        HIP_TRY(ctx, launch_transform_batch(st, b, m, max_wgs, max_special));
+        if ((int)m <= ctx->tune.tr_side_max) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            HIP_TRY(ctx, launch_transform_batch(st, ctx->stream2, b, m, max_wgs, max_special));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+        } else {
+            HIP_TRY(ctx, launch_transform_batch(st, nullptr, b, m, max_wgs, max_special));
+        }
         ctx->prof_end(PROF_TRANSFORM, st);
         if (!batched) {
             for (uint32_t i = 0; i < m; ++i) {

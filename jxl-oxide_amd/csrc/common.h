@@ -189,6 +189,8 @@ struct Tuning {
     int stream_rows = 48;        // JXLGPU_STREAM_ROWS: rows per wave segment of post_stream_kernel
     int batch_stream_rows = 96;  // JXLGPU_BATCH_STREAM_ROWS: the same for batched launches (waves to spare)
     int batch_chunk = 0;         // JXLGPU_BATCH_CHUNK: > 0: frames per launch of a batch (default: JXLGPU_MAX_BATCH)
+    int tr_side_max = 16;        // JXLGPU_TR_SIDE_MAX: launches of <= this many frames run the big-shape transforms on the side stream
+                                 // (short launches: their tails overlap; +2.7 % at 8 frames per launch, nothing at 32)
     bool no_pk = false;          // JXLGPU_NO_PK: scalar streaming kernel (one column per lane)
     bool no_stream = false;      // JXLGPU_NO_STREAM: LDS tile kernel for the whole frame
     bool no_fused = false;       // JXLGPU_NO_FUSED: one kernel per post stage
@@ -343,7 +345,7 @@ void launch_transform_class(hipStream_t s, int cls, const TransformArgs& a, cons
 void build_class_table(int family, const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT],
                        uint32_t num_cus, int wgs_per_cu, ClassTable* ct);
 hipError_t launch_lf_batch(hipStream_t s, const FrameBatch& b, uint32_t n, uint32_t max_w8, uint32_t max_h8, bool any_smooth);
-hipError_t launch_transform_batch(hipStream_t s, const FrameBatch& b, uint32_t n, const uint32_t max_wgs[4],
+hipError_t launch_transform_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, const uint32_t max_wgs[4],
                                   uint32_t max_special);
 hipError_t launch_post_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, uint32_t max_stream_wgs,
                              uint32_t max_ring, bool pk);

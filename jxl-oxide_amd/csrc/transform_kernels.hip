@@ -1024,19 +1024,23 @@ hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs
 }
 
 // All four families + the special 8x8 family of n frames: long work items first, the bulk last.
-hipError_t launch_transform_batch(hipStream_t s, const FrameBatch& b, uint32_t n, const uint32_t max_wgs[4],
+// `side` (optional): the 64 / 32-px families and the special one run there beside the 16 / 8-px families
+// on `s` (disjoint varblocks; the caller forks / joins the streams) — for small batches, whose launches
+// are short enough for their tails to show.
+hipError_t launch_transform_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, const uint32_t max_wgs[4],
                                   uint32_t max_special) {
-#define LAUNCHB(F)                                                                                          \
+    if (!side) side = s;
+#define LAUNCHB(F, ST)                                                                                       \
     if (max_wgs[F]) {                                                                                       \
         set_lds_attr<F>();                                                                                  \
-        transform_items_batch_kernel<F><<<dim3(max_wgs[F], n), 192, FamCfg<F>::WORDS * sizeof(float), s>>>(b); \
+        transform_items_batch_kernel<F><<<dim3(max_wgs[F], n), 192, FamCfg<F>::WORDS * sizeof(float), ST>>>(b); \
     }
-    LAUNCHB(3)
-    LAUNCHB(2)
+    LAUNCHB(3, side)
+    LAUNCHB(2, side)
     if (max_special)
-        transform_special_batch_kernel<<<dim3(ceil_div(max_special, kSpecialPerWave), n), 64, 0, s>>>(b);
-    LAUNCHB(1)
-    LAUNCHB(0)
+        transform_special_batch_kernel<<<dim3(ceil_div(max_special, kSpecialPerWave), n), 64, 0, side>>>(b);
+    LAUNCHB(1, s)
+    LAUNCHB(0, s)
 #undef LAUNCHB
     return hipGetLastError();
 }
