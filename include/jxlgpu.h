@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 12u
+#define JXLGPU_ABI_VERSION 13u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -159,6 +159,24 @@ typedef struct {
 
 #define JXLGPU_COEFF_DENSE 0u
 #define JXLGPU_COEFF_SPARSE 1u
+#define JXLGPU_COEFF_GROUPED 2u
+
+/* One pass group's HF coefficients exactly as the decode loop of `write_hf_coeff` produces them
+ * (jxl-vardct/src/hf_coeff.rs:97-254), before they would be stored into the coefficient grid:
+ * for every `BlockInfo::Data` cell of the group in raster order (:97-106), for c in [Y, X, B]
+ * (:138-140): the `non_zeros` count read at :188 and then that many (dx, dy, coeff) triples, where
+ * (dx, dy) is the coefficient's position inside the varblock after the need_transpose swap
+ * (:236-241) and coeff = unpack_signed(ucoeff) << coeff_shift (:235).  The device transform
+ * consumes these lists directly (no dense coefficient plane is ever built): the shim replaces the
+ * store at hf_coeff.rs:243 by a push.  Single-pass frames with |coeff| < 32768 only (what a
+ * non-progressive stream is); anything else uses JXLGPU_COEFF_SPARSE / _DENSE.                 */
+typedef struct {
+    uint32_t num_varblocks;   /* BlockInfo::Data cells of the group                               */
+    uint32_t num_nz;          /* entries in `nz` = sum of nz_count                                */
+    const uint16_t* nz_count; /* 3 per varblock, in the order decoded: [Y, X, B]                  */
+    const uint32_t* nz;       /* dx | dy << 8 | (uint32_t)(uint16_t)coeff << 16, varblock after    */
+                              /* varblock, Y then X then B, in coefficient (decode) order         */
+} JxlGpuHfGroup;
 
 typedef struct {
     uint32_t abi;                 /* = JXLGPU_ABI_VERSION                                         */
@@ -178,7 +196,9 @@ typedef struct {
      *   JXLGPU_COEFF_DENSE : coeff[c] = the plane, elements of `coeff_sample_type` (i32 is the
      *                        reference's own framebuffer; i16 halves the H2D volume and is valid
      *                        whenever every |coefficient| < 32768).
-     *   JXLGPU_COEFF_SPARSE: the non-zero stores of hf_coeff.rs:234 as lists.  coeff[c] = values
+     *   JXLGPU_COEFF_GROUPED: see JxlGpuHfGroup above — the preferred transport (4 bytes per
+ *                        non-zero coefficient across PCIe, no device-side layout pass).
+ *   JXLGPU_COEFF_SPARSE: the non-zero stores of hf_coeff.rs:234 as lists.  coeff[c] = values
      *                        (`coeff_sample_type`), sparse_pos[c][i] = y * coeff_stride + x,
      *                        sparse_count[c] entries; entries accumulate (`+=`, as the passes of a
      *                        progressive frame do), everything not listed is 0.                  */
@@ -188,6 +208,12 @@ typedef struct {
     uint32_t coeff_sample_type;   /* JXLGPU_SAMPLE_I32 / JXLGPU_SAMPLE_I16                         */
     const uint32_t* sparse_pos[3];
     uint64_t sparse_count[3];
+    /* JXLGPU_COEFF_GROUPED: one entry per pass group, raster order over the frame's
+     * ceil(width / group_dim) x ceil(height / group_dim) groups; `coeff`, `coeff_stride`,
+     * `coeff_sample_type` and the sparse fields are ignored.  Not offered for chroma-subsampled
+     * frames (jpeg_upsampling != 0).                                                             */
+    uint32_t num_hf_groups;
+    const JxlGpuHfGroup* hf_groups;
     uint32_t num_lf_groups;       /* frame_header.num_lf_groups(), raster order                    */
     const JxlGpuLfGroup* lf_groups;
     /* Quantizer / LfChannelDequantization / LfChannelCorrelation (jxl-vardct/src/lf.rs:11-34) */

@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -23,7 +23,7 @@ SAMPLE_I16 = 1
 
 TF_LINEAR, TF_SRGB, TF_PQ, TF_BT709, TF_GAMMA, TF_HLG = range(6)
 GAMUT_NONE, GAMUT_MAP, GAMUT_CLIP = range(3)
-COEFF_DENSE, COEFF_SPARSE = range(2)
+COEFF_DENSE, COEFF_SPARSE, COEFF_GROUPED = range(3)
 
 STAGE_LF = 0x01
 STAGE_TRANSFORM = 0x02
@@ -153,6 +153,15 @@ class LfGroup(C.Structure):
     ]
 
 
+class HfGroup(C.Structure):
+    _fields_ = [
+        ("num_varblocks", C.c_uint32),
+        ("num_nz", C.c_uint32),
+        ("nz_count", C.POINTER(C.c_uint16)),
+        ("nz", C.POINTER(C.c_uint32)),
+    ]
+
+
 class VardctDesc(C.Structure):
     _fields_ = [
         ("abi", C.c_uint32),
@@ -167,6 +176,8 @@ class VardctDesc(C.Structure):
         ("coeff_sample_type", C.c_uint32),
         ("sparse_pos", C.POINTER(C.c_uint32) * 3),
         ("sparse_count", C.c_uint64 * 3),
+        ("num_hf_groups", C.c_uint32),
+        ("hf_groups", C.POINTER(HfGroup)),
         ("num_lf_groups", C.c_uint32),
         ("lf_groups", C.POINTER(LfGroup)),
         ("global_scale", C.c_uint32),

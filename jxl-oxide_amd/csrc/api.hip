@@ -135,6 +135,7 @@ struct Scratch {
     ~Scratch() {
         if (ptrs.empty()) return;
         (void)hipStreamSynchronize(ctx->stream);  // error paths may leave kernels reading these
+        (void)hipStreamSynchronize(ctx->stream2);
         for (void* p : ptrs) ctx_dev_release(ctx, p);
     }
     int alloc(jxlgpu_ctx* c, void** out, size_t bytes) {
@@ -312,6 +313,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     if (const char* e = getenv("JXLGPU_TR_SIDE_MAX")) ctx->tune.tr_side_max = atoi(e);
     ctx->tune.no_stream = getenv("JXLGPU_NO_STREAM") != nullptr;
     ctx->tune.no_fused = getenv("JXLGPU_NO_FUSED") != nullptr;
+    ctx->tune.no_sparse_tr = getenv("JXLGPU_NO_SPARSE_TR") != nullptr;
     ctx->tune.debug_sync = getenv("JXLGPU_DEBUG_SYNC") != nullptr;
     if (const char* v = getenv("JXLGPU_TR_WGS_PER_CU")) {
         int t[4];
@@ -405,6 +407,9 @@ void jxlgpu_frame_free(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
+        // the side stream too: an error return between a fork and its join (batched render) leaves
+        // kernels there that the main stream never waited for
+        (void)hipStreamSynchronize(ctx->stream2);
     }
     for (auto& sub : f->subs) jxlgpu_frame_free(ctx, sub.child);
     for (void* p : f->allocs) {
@@ -440,8 +445,10 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     if (upf != 1 && upf != 2 && upf != 4 && upf != 8) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "bad upsampling factor");
     // several per-row kernels launch one grid row per image row (HIP: grid.y <= 65535)
     if ((uint64_t)d->height * upf > 65535u) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "output taller than 65535 rows");
-    if (d->coeff_format > JXLGPU_COEFF_SPARSE || d->coeff_sample_type > JXLGPU_SAMPLE_I16)
+    if (d->coeff_format > JXLGPU_COEFF_GROUPED ||
+        (d->coeff_format != JXLGPU_COEFF_GROUPED && d->coeff_sample_type > JXLGPU_SAMPLE_I16))
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "bad coeff_format / coeff_sample_type");
+    const bool grouped = d->coeff_format == JXLGPU_COEFF_GROUPED;
     for (int c = 0; c < 3; ++c) {
         if (d->coeff_format == JXLGPU_COEFF_DENSE && !d->coeff[c])
             return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null coefficient plane");
@@ -472,7 +479,7 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     f->num_lf_groups = f->lf_groups_per_row * lf_rows;
     if (d->num_lf_groups != f->num_lf_groups || !d->lf_groups)
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "num_lf_groups does not match the frame size");
-    if (d->coeff_stride < f->wr) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "coeff_stride < width_rounded");
+    if (!grouped && d->coeff_stride < f->wr) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "coeff_stride < width_rounded");
     if ((uint64_t)f->wr * f->hr * 3 >= (1ull << 30))  // kernels address the tiled planes with 32-bit word offsets
         return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "frame larger than 357 megapixels");
 
@@ -539,14 +546,25 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     }
 
     // ---- varblock work lists, one per shape class, ordered by 256x256 group then raster
-    std::vector<uint4> lists[CLS_COUNT];
+    struct VbEntry { uint4 e; uint32_t cyx; };   // cyx: non-zero counts Y | X << 16 (grouped transport)
+    std::vector<VbEntry> lists[CLS_COUNT];
     std::vector<uint32_t> nometa;
     const uint32_t gcells = d->group_dim / 8;
     const uint32_t groups_x = ceil_div(d->width, d->group_dim), groups_y = ceil_div(d->height, d->group_dim);
+    if (grouped && (d->num_hf_groups != groups_x * groups_y || !d->hf_groups))
+        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "num_hf_groups does not match the frame size");
+    uint64_t nz_total = 0;  // list words in front of the current group
     for (uint32_t gy = 0; gy < groups_y; ++gy)
         for (uint32_t gx = 0; gx < groups_x; ++gx) {
             const uint32_t lfg = (gy * gcells / f->lfg_cells_y) * f->lf_groups_per_row + gx * gcells / f->lfg_cells_x;
+            const JxlGpuHfGroup* hg = grouped ? &d->hf_groups[gy * groups_x + gx] : nullptr;
+            if (hg && ((hg->num_varblocks && !hg->nz_count) || (hg->num_nz && !hg->nz)))
+                return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null list pointers in an HF group");
+            uint32_t vb_k = 0;      // varblocks of this group seen so far (decode order)
+            uint64_t nz_k = 0;      // their list words
             if (!has_meta[lfg]) {
+                if (hg && (hg->num_varblocks || hg->num_nz))
+                    return fail(ctx, JXLGPU_ERR_INVALID_ARG, "HF lists for a group without HfMetadata");
                 nometa.push_back(gy * groups_x + gx);
                 continue;
             }
@@ -561,8 +579,27 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
                     if (hf_mul[(size_t)y * f->w8 + x] <= 0) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "non-positive HfMul");
                     if (!d->dequant[t][0] || !d->dequant[t][1] || !d->dequant[t][2])
                         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "missing dequant matrix for a used transform");
-                    lists[class_of(t)].push_back(make_uint4(x | (y << 16), t, (uint32_t)hf_mul[(size_t)y * f->w8 + x], 0));
+                    VbEntry v{make_uint4(x | (y << 16), t, (uint32_t)hf_mul[(size_t)y * f->w8 + x], 0), 0};
+                    if (hg) {
+                        if (vb_k >= hg->num_varblocks) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "fewer nz_count entries than varblocks in a group");
+                        const uint16_t* cnt = hg->nz_count + 3 * (size_t)vb_k;  // decode order: Y, X, B
+                        const uint32_t max_nz = 63u * bw * bh;                 // hf_coeff.rs:193
+                        if (cnt[0] > max_nz || cnt[1] > max_nz || cnt[2] > max_nz)
+                            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "non_zeros too large");
+                        v.e.w = (uint32_t)(nz_total + nz_k);
+                        v.e.y |= (uint32_t)cnt[2] << 16;
+                        v.cyx = (uint32_t)cnt[0] | (uint32_t)cnt[1] << 16;
+                        nz_k += (uint64_t)cnt[0] + cnt[1] + cnt[2];
+                        ++vb_k;
+                    }
+                    lists[class_of(t)].push_back(v);
                 }
+            if (hg) {
+                if (vb_k != hg->num_varblocks || nz_k != hg->num_nz)
+                    return fail(ctx, JXLGPU_ERR_INVALID_ARG, "HF group lists do not match the block map");
+                nz_total += nz_k;
+                if (nz_total >= (1ull << 32)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "more than 2^32 non-zero coefficients");
+            }
         }
 
     // ---- dequant matrices (only the types that appear), flat, 16-byte aligned offsets
@@ -589,11 +626,22 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     TRY(tmp.alloc(ctx, &d_bad_v, 4));
     uint32_t* d_bad = static_cast<uint32_t*>(d_bad_v);
     HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
-    TRY(dev_alloc(ctx, f, &f->coeff, npix * 3));
+    // grouped lists feed the transform kernels directly; dense cells are built from them only for frames
+    // with >= 128-px varblocks (global-memory path) or on request (JXLGPU_NO_SPARSE_TR)
+    f->sparse_tr = grouped && !ctx->tune.no_sparse_tr && lists[CLS_BIG].empty();
+    if (!f->sparse_tr) TRY(dev_alloc(ctx, f, &f->coeff, npix * 3));
     TRY(dev_alloc(ctx, f, &f->pix_t, npix * 3));
-    if (d->coeff_format == JXLGPU_COEFF_SPARSE) HIP_TRY(ctx, hipMemsetAsync(f->coeff, 0, npix * 12, ctx->stream));
+    if (d->coeff_format != JXLGPU_COEFF_DENSE && f->coeff) HIP_TRY(ctx, hipMemsetAsync(f->coeff, 0, npix * 12, ctx->stream));
+    if (grouped) {
+        std::vector<uint32_t> words;
+        words.reserve((size_t)nz_total);
+        for (uint32_t g = 0; g < d->num_hf_groups; ++g)
+            words.insert(words.end(), d->hf_groups[g].nz, d->hf_groups[g].nz + d->hf_groups[g].num_nz);
+        TRY(dev_upload(ctx, f, &f->nz, words));
+        f->nz_total = nz_total;
+    }
     for (int c = 0; c < 3; ++c) {
-        TRY(upload_coeff_plane(ctx, f, d, c, tmp, d_bad));
+        if (!grouped) TRY(upload_coeff_plane(ctx, f, d, c, tmp, d_bad));
         uint8_t* p = nullptr;
         TRY(dev_upload(ctx, f, &p, lfq_host[c]));
         f->lfq[c] = p;
@@ -622,14 +670,22 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
         // one entry array, classes concatenated; the special 8x8 family sorted by transform type so
         // that the per-lane dispatch of transform_special_kernel is (nearly) wave-uniform
         std::stable_sort(lists[CLS_SPECIAL8].begin(), lists[CLS_SPECIAL8].end(),
-                         [](const uint4& a, const uint4& b) { return a.y < b.y; });
+                         [](const VbEntry& a, const VbEntry& b) { return (a.e.y & 0xffffu) < (b.e.y & 0xffffu); });
         std::vector<uint4> entries;
+        std::vector<uint32_t> cyx;
         for (int cls = 0; cls < CLS_COUNT; ++cls) {
             f->class_first[cls] = (uint32_t)entries.size();
             f->list_count[cls] = (uint32_t)lists[cls].size();
-            entries.insert(entries.end(), lists[cls].begin(), lists[cls].end());
+            for (const VbEntry& v : lists[cls]) {
+                entries.push_back(v.e);
+                if (grouped) cyx.push_back(v.cyx);
+            }
         }
         TRY(dev_upload(ctx, f, &f->entries, entries));
+        if (grouped) {
+            TRY(dev_upload(ctx, f, &f->nzc, cyx));
+            if (!f->sparse_tr) launch_grouped_to_dense(ctx->stream, f->entries, f->nzc, (uint32_t)entries.size(), f->nz, f->w8, f->coeff);
+        }
     }
     f->nometa_count = (uint32_t)nometa.size();
     if (!nometa.empty()) TRY(dev_upload(ctx, f, &f->nometa_groups, nometa));
@@ -685,6 +741,7 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     // pointers inside the descriptor copy are dead from here on
     for (int c = 0; c < 3; ++c) f->desc.coeff[c] = nullptr;
     f->desc.lf_groups = nullptr;
+    f->desc.hf_groups = nullptr;
     memset(f->desc.dequant, 0, sizeof(f->desc.dequant));
     guard.armed = false;
     *out_frame = f;
@@ -928,7 +985,7 @@ int upload_subsampled(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_frame**
     if ((d->upsampling.factor ? d->upsampling.factor : 1) != 1)
         return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "chroma-subsampled frame with non-separable upsampling");
     if (d->coeff_format != JXLGPU_COEFF_DENSE)
-        return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "sparse coefficient transport on a chroma-subsampled frame");
+        return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "sparse / grouped coefficient transport on a chroma-subsampled frame");
     if (d->width == 0 || d->height == 0 || d->width > (1u << 18) || d->height > (1u << 18))
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "bad frame size");
     if (d->height > 65535u) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "output taller than 65535 rows");
@@ -1102,6 +1159,7 @@ static void fill_transform_args(jxlgpu_ctx* ctx, const jxlgpu_frame* f, Transfor
     ta.quant_bias_numerator = d.quant_bias_numerator;
     ta.big_tmp = f->big_tmp;
     ta.deq_lut = f->deq_lut;
+    ta.nz = f->nz;
 #ifdef JXL_TR_PROFILE
     ta.prof = ctx->tr_prof;
 #else
@@ -1161,10 +1219,17 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
     fill_transform_args(ctx, f, &ta);
     ctx->prof_begin(PROF_TRANSFORM);
     // few, long work items first (64-px, 32-px shapes, the special 8x8 family), the bulk last
-    for (int fam : {3, 2}) HIP_TRY(ctx, launch_transform_items(s, fam, ta, f->entries, f->class_first, f->list_count, ctx->num_cus, ctx->tune.tr_wgs_per_cu[fam]));
-    launch_transform_class(s, CLS_SPECIAL8, ta, f->entries + f->class_first[CLS_SPECIAL8], f->list_count[CLS_SPECIAL8]);
-    for (int fam : {1, 0}) HIP_TRY(ctx, launch_transform_items(s, fam, ta, f->entries, f->class_first, f->list_count, ctx->num_cus, ctx->tune.tr_wgs_per_cu[fam]));
-    launch_transform_class(s, CLS_BIG, ta, f->entries + f->class_first[CLS_BIG], f->list_count[CLS_BIG]);
+    if (f->sparse_tr) {
+        for (int fam : {3, 2}) HIP_TRY(ctx, launch_transform_items_sparse(s, fam, ta, f->entries, f->nzc, f->class_first, f->list_count, ctx->num_cus));
+        launch_transform_special_sparse(s, ta, f->entries + f->class_first[CLS_SPECIAL8], f->nzc + f->class_first[CLS_SPECIAL8],
+                                        f->list_count[CLS_SPECIAL8]);
+        for (int fam : {1, 0}) HIP_TRY(ctx, launch_transform_items_sparse(s, fam, ta, f->entries, f->nzc, f->class_first, f->list_count, ctx->num_cus));
+    } else {
+        for (int fam : {3, 2}) HIP_TRY(ctx, launch_transform_items(s, fam, ta, f->entries, f->class_first, f->list_count, ctx->num_cus, ctx->tune.tr_wgs_per_cu[fam]));
+        launch_transform_class(s, CLS_SPECIAL8, ta, f->entries + f->class_first[CLS_SPECIAL8], f->list_count[CLS_SPECIAL8]);
+        for (int fam : {1, 0}) HIP_TRY(ctx, launch_transform_items(s, fam, ta, f->entries, f->class_first, f->list_count, ctx->num_cus, ctx->tune.tr_wgs_per_cu[fam]));
+        launch_transform_class(s, CLS_BIG, ta, f->entries + f->class_first[CLS_BIG], f->list_count[CLS_BIG]);
+    }
     launch_nometa_groups(s, ta, f->nometa_groups, f->nometa_count, f->group_dim, ceil_div(f->width, f->group_dim));
     ctx->prof_end(PROF_TRANSFORM);
 
@@ -1184,13 +1249,15 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
 // per frame whether it qualifies.
 static int ensure_dev_args(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     if (f->dev_args_ready) return JXLGPU_OK;
-    f->dev_args_ready = true;
     f->batch_ok = false;
     const JxlGpuVardctDesc& d = f->desc;
     const uint32_t upf = d.upsampling.factor ? d.upsampling.factor : 1;
     f->batch_tr_ok = false;
     // V1-V8 of any single-geometry frame made of <= 64-px varblocks can share launches ...
-    if (f->kind_of_frame != 0 || !f->subs.empty() || !f->buf_a[0] || f->list_count[CLS_BIG] || f->nometa_count) return JXLGPU_OK;
+    if (f->kind_of_frame != 0 || !f->subs.empty() || !f->buf_a[0] || f->list_count[CLS_BIG] || f->nometa_count) {
+        f->dev_args_ready = true;
+        return JXLGPU_OK;
+    }
     // ... the post stage only for the default pipeline (Gabor + EPF iters 2 + plain XYB -> sRGB, no upsampling / noise)
     const bool post_default = d.filter.gab_enabled && d.filter.epf_iters == 2 && upf == 1 && !d.noise.enabled &&
                               d.color.enabled && !d.color.ycbcr && fused_post_supported(ctx, f, true, 2);
@@ -1204,6 +1271,7 @@ static int ensure_dev_args(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
         f->batch_wgs[fam] = h.ct[fam].wg_begin[h.ct[fam].n_classes];
     }
     h.entries = f->entries;
+    h.nzc = f->nzc;
     h.special_first = f->class_first[CLS_SPECIAL8];
     h.special_count = f->list_count[CLS_SPECIAL8];
     bool post_ok = false;
@@ -1222,8 +1290,11 @@ static int ensure_dev_args(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             f->batch_stream_wgs = (uint32_t)(h.post.strips * h.post.segs + 3) / 4;
         }
     }
-    TRY(dev_alloc(ctx, f, &f->dev_args, 1));
+    if (!f->dev_args) TRY(dev_alloc(ctx, f, &f->dev_args, 1));
     HIP_TRY(ctx, hipMemcpy(f->dev_args, &h, sizeof(h), hipMemcpyHostToDevice));
+    // only now: a failure above (allocation, copy) is reported and retried by the next call instead of
+    // silently demoting the frame to one-by-one rendering for good
+    f->dev_args_ready = true;
     f->batch_tr_ok = true;
     f->batch_ok = post_ok;
     return JXLGPU_OK;
@@ -1249,9 +1320,11 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
     bool batched = (stages & need) == need;
     for (uint32_t i = 0; i < n && batched_tr; ++i) {
         TRY(ensure_dev_args(ctx, frames[i]));
-        batched_tr = frames[i]->batch_tr_ok;
+        // one kernel per launch: list-fed and dense frames do not share one
+        batched_tr = frames[i]->batch_tr_ok && frames[i]->sparse_tr == frames[0]->sparse_tr;
         batched = batched && frames[i]->batch_ok;
     }
+    const bool sparse_tr = n > 0 && frames[0]->sparse_tr;
     if (!batched_tr) {
         for (uint32_t i = 0; i < n; ++i) TRY(jxlgpu_vardct_render(ctx, frames[i], stages, nullptr));
         return JXLGPU_OK;
@@ -1285,11 +1358,13 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
         if ((int)m <= ctx->tune.tr_side_max) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            HIP_TRY(ctx, launch_transform_batch(st, ctx->stream2, b, m, max_wgs, max_special));
+            HIP_TRY(ctx, sparse_tr ? launch_transform_batch_sparse(st, ctx->stream2, b, m, max_wgs, max_special)
+                                   : launch_transform_batch(st, ctx->stream2, b, m, max_wgs, max_special));
             HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
             HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
         } else {
-            HIP_TRY(ctx, launch_transform_batch(st, nullptr, b, m, max_wgs, max_special));
+            HIP_TRY(ctx, sparse_tr ? launch_transform_batch_sparse(st, nullptr, b, m, max_wgs, max_special)
+                                   : launch_transform_batch(st, nullptr, b, m, max_wgs, max_special));
         }
         ctx->prof_end(PROF_TRANSFORM, st);
         if (!batched) {

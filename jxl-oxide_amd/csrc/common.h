@@ -65,6 +65,7 @@ struct TransformArgs {
     float quant_bias_numerator;
     float* big_tmp;            // 6 row-major planes of pstride x (h8*8): working storage of the >=128 path
     const float* deq_lut;      // 256 x quant_bias_numerator / k (k >= 2), or nullptr: divide
+    const uint32_t* nz;        // JXLGPU_COEFF_GROUPED: every group's (dx | dy << 8 | coeff << 16) words; `coeff` is null then
 #ifdef JXL_TR_PROFILE
     unsigned long long* prof;  // tools only (make PROF=1): per-phase s_memtime sums, 4 families x 16 slots
 #endif
@@ -162,6 +163,7 @@ struct FrameDev {
     TransformArgs tr;
     ClassTable ct[4];
     const uint4* entries;
+    const uint32_t* nzc;     // list-fed frames: per entry, non-zero counts Y | X << 16 (B: entry.y >> 16; first word: entry.w)
     uint32_t special_first, special_count;
     FusedArgs post;
     uint32_t n_ring_tiles;
@@ -194,6 +196,7 @@ struct Tuning {
     bool no_pk = false;          // JXLGPU_NO_PK: scalar streaming kernel (one column per lane)
     bool no_stream = false;      // JXLGPU_NO_STREAM: LDS tile kernel for the whole frame
     bool no_fused = false;       // JXLGPU_NO_FUSED: one kernel per post stage
+    bool no_sparse_tr = false;   // JXLGPU_NO_SPARSE_TR: grouped lists are expanded to dense cells first (dense kernels)
     bool debug_sync = false;     // JXLGPU_DEBUG_SYNC: synchronise + report after every launch group
     int tr_wgs_per_cu[4] = {0, 0, 0, 0};  // JXLGPU_TR_WGS_PER_CU="a,b,c,d": persistent transform workgroups per CU
                                  // for the 8-, 16-, 32- and 64-px launch (0: one workgroup per item, no run-ahead)
@@ -280,6 +283,12 @@ struct jxlgpu_frame {
     float* up[3] = {};          // upsampled planes
     float* up_tmp[3] = {};
     uint4* entries = nullptr;            // all varblocks, classes concatenated
+    // JXLGPU_COEFF_GROUPED: the decoder's non-zero lists, consumed by the list-fed transform kernels
+    // (transform_sparse.hip); `coeff` stays null unless the frame falls back to the dense kernels
+    uint32_t* nz = nullptr;              // all groups' list words
+    uint32_t* nzc = nullptr;             // per entry: count Y | count X << 16
+    uint64_t nz_total = 0;
+    bool sparse_tr = false;              // V4-V8 run the list-fed kernels
     uint32_t class_first[CLS_COUNT] = {};
     uint32_t list_count[CLS_COUNT] = {};
     bool has_no_meta_groups = false;
@@ -352,6 +361,18 @@ hipError_t launch_post_batch(hipStream_t s, hipStream_t side, const FrameBatch& 
 hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs& a, const uint4* entries,
                                   const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT],
                                   uint32_t num_cus, int wgs_per_cu);
+// transform_sparse.hip: the same launches for list-fed frames (JXLGPU_COEFF_GROUPED)
+hipError_t launch_transform_items_sparse(hipStream_t s, int family, const TransformArgs& a, const uint4* entries,
+                                         const uint32_t* nzc, const uint32_t class_first[CLS_COUNT],
+                                         const uint32_t list_count[CLS_COUNT], uint32_t num_cus);
+void launch_transform_special_sparse(hipStream_t s, const TransformArgs& a, const uint4* entries, const uint32_t* nzc,
+                                     uint32_t count);
+hipError_t launch_transform_batch_sparse(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n,
+                                         const uint32_t max_wgs[4], uint32_t max_special);
+// grouped lists -> dense cell-tiled coefficients (fallback for frames with >= 128-px varblocks; `coeff` zeroed first)
+void launch_grouped_to_dense(hipStream_t s, const uint4* entries, const uint32_t* nzc, uint32_t n_entries,
+                             const uint32_t* nz, uint32_t w8, int32_t* coeff);
+int transform_items_nbi(int cls);
 void launch_nometa_groups(hipStream_t s, const TransformArgs& a, const uint32_t* groups,
                           uint32_t count, uint32_t group_dim, uint32_t groups_per_row);
 void launch_gabor(hipStream_t s, const FilterArgs& a);

@@ -308,6 +308,12 @@ class VardctWorkload:
                     plane = np.ascontiguousarray(plane.astype(np.int16))
                     keep_c.append(plane)
                 d.coeff[c] = plane.ctypes.data
+        elif coeff_transport == "grouped":
+            d.coeff_format = abi.COEFF_GROUPED
+            hf_groups, arrays = self.grouped_lists()
+            keep_c += [hf_groups, arrays]
+            d.num_hf_groups = len(hf_groups)
+            d.hf_groups = C.cast(hf_groups, C.POINTER(abi.HfGroup))
         else:
             d.coeff_format = abi.COEFF_SPARSE
             for c in range(3):
@@ -386,6 +392,56 @@ class VardctWorkload:
             d.upsampling.up8_weight = self.up_w[2].ctypes.data_as(abi.f32p)
         self._keep = [groups, keep, keep_c]
         return d
+
+    def grouped_lists(self):
+        """JXLGPU_COEFF_GROUPED: per 256x256 pass group, the `non_zeros` counts and the
+        (dx, dy, coeff) triples in the order `write_hf_coeff` decodes them (hf_coeff.rs:97-254):
+        Data cells of the group in raster order, channels Y, X, B.  The order of the triples inside
+        one (varblock, channel) — the coefficient order of the pass in a real stream — is shuffled."""
+        gc = self.group_dim // 8
+        h8, w8 = self.kind.shape
+        groups_x, groups_y = -(-self.width // self.group_dim), -(-self.height // self.group_dim)
+        ys, xs = np.nonzero(self.kind <= 26)
+        gid = (ys // gc) * groups_x + xs // gc
+        order = np.lexsort((xs, ys, gid))          # group, then raster inside the group
+        ys, xs, gid = ys[order], xs[order], gid[order]
+        nvb = ys.size
+        owner = np.full((h8, w8), -1, dtype=np.int64)  # cell -> index of its varblock in decode order
+        for k in np.unique(self.kind[ys, xs]):
+            bw, bh = DCT_SELECT_SIZE[int(k)]
+            sel = np.flatnonzero(self.kind[ys, xs] == k)
+            for dy in range(bh):
+                for dx in range(bw):
+                    owner[ys[sel] + dy, xs[sel] + dx] = sel
+        counts = np.zeros((nvb, 3), dtype=np.int64)
+        ent_vb, ent_slot, ent_word = [], [], []
+        for slot, c in enumerate((1, 0, 2)):       # decoded Y, X, B (hf_coeff.rs:138-140)
+            py, px = np.nonzero(self.coeff[c])
+            vb = owner[py // 8, px // 8]
+            assert (vb >= 0).all()
+            val = self.coeff[c][py, px]
+            assert np.abs(val).max(initial=0) < 32768
+            dx, dy = px - xs[vb] * 8, py - ys[vb] * 8
+            counts[:, slot] = np.bincount(vb, minlength=nvb)
+            ent_vb.append(vb)
+            ent_slot.append(np.full(vb.size, slot))
+            ent_word.append((dx | (dy << 8) | ((val.astype(np.int64) & 0xFFFF) << 16)).astype(np.uint32))
+        ent_vb, ent_slot, ent_word = map(np.concatenate, (ent_vb, ent_slot, ent_word))
+        shuffle = np.random.default_rng(SEED_BASE ^ 0x6E7A).random(ent_vb.size)
+        o = np.lexsort((shuffle, ent_slot, ent_vb))
+        words = np.ascontiguousarray(ent_word[o])
+        counts16 = np.ascontiguousarray(counts.astype(np.uint16).reshape(-1))
+        n_groups = groups_x * groups_y
+        vb_first = np.searchsorted(gid, np.arange(n_groups + 1))      # varblock range of every group
+        nz_first = np.concatenate([[0], np.cumsum(counts.sum(axis=1))])[vb_first]
+        hf = (abi.HfGroup * n_groups)()
+        u16p, u32p = C.POINTER(C.c_uint16), C.POINTER(C.c_uint32)
+        for g in range(n_groups):
+            hf[g].num_varblocks = int(vb_first[g + 1] - vb_first[g])
+            hf[g].num_nz = int(nz_first[g + 1] - nz_first[g])
+            hf[g].nz_count = C.cast(counts16.ctypes.data + 6 * int(vb_first[g]), u16p)
+            hf[g].nz = C.cast(words.ctypes.data + 4 * int(nz_first[g]), u32p)
+        return hf, (counts16, words)
 
     def out_size(self, stages):
         f = self.up_factor if (stages & abi.STAGE_UPSAMPLE) else 1

@@ -60,7 +60,8 @@ def test_field_offsets_match_the_compiler():
     import tempfile
     pairs = [("JxlGpuFormatDesc", abi.FormatDesc), ("JxlGpuFilterParams", abi.FilterParams),
              ("JxlGpuColorParams", abi.ColorParams), ("JxlGpuUpsampling", abi.Upsampling),
-             ("JxlGpuNoiseParams", abi.NoiseParams), ("JxlGpuLfGroup", abi.LfGroup), ("JxlGpuVardctDesc", abi.VardctDesc),
+             ("JxlGpuNoiseParams", abi.NoiseParams), ("JxlGpuLfGroup", abi.LfGroup), ("JxlGpuHfGroup", abi.HfGroup),
+             ("JxlGpuVardctDesc", abi.VardctDesc),
              ("JxlGpuOut", abi.Out), ("JxlGpuBlendRect", abi.BlendRect), ("JxlGpuSqueezeStep", abi.SqueezeStep),
              ("JxlGpuTransform", abi.Transform), ("JxlGpuModularChannel", abi.ModularChannel),
              ("JxlGpuModularDesc", abi.ModularDesc)]
