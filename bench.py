@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5))
     ap.add_argument("--frames", type=int, default=None, help="frames in the whole job (default 64; 8 for configs 3 / 5)")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic frames in the job")
+    ap.add_argument("--transport", default="grouped", choices=("grouped", "dense_i32", "sparse_i16"),
+                    help="coefficient transport of the resident input (VarDCT configs): the decoder's per-varblock "
+                         "non-zero lists (default; consumed by the transform kernels directly) or dense planes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="per CPU-baseline configuration")
     ap.add_argument("--no-verify", action="store_true")
@@ -87,7 +90,7 @@ def main():
 
     n_total = args.frames or (64 if args.config == 2 else 8)
     mine = list(shard.frame_shard(n_total, rank, world))
-    job = make_job(args.config, args.distinct)
+    job = make_job(args.config, args.distinct, args.transport)
     wls = {d: job["make"](d) for d in sorted({i % args.distinct for i in mine})}  # untimed
     frames = [job["upload"](ctx, wls[i % args.distinct]) for i in mine]            # own device copy each; untimed
     mp_per_frame = job["out_w"] * job["out_h"] / 1e6
@@ -231,7 +234,7 @@ def main():
 
 
 # ------------------------------------------------------------------------------------------------
-def make_job(config, distinct):
+def make_job(config, distinct, transport="grouped"):
     import numpy as np
     from jxl_oxide_amd import abi
 
@@ -281,7 +284,7 @@ def make_job(config, distinct):
             "workload": f"{W4K}x{H4K} VarDCT d1 XYB, Gabor + EPF iters 2, XYB->sRGB f32 planar (BASELINE config 2 frames, config 4 batch of 64)",
             "out_w": W4K, "out_h": H4K,
             "make": lambda d: VardctWorkload(W4K, H4K, seed=2000 + d),
-            "upload": lambda ctx, wl: ctx.vardct_upload(wl.desc()),
+            "upload": lambda ctx, wl: ctx.vardct_upload(wl.desc(coeff_transport=transport)),
             "render": lambda ctx, frames: ctx.vardct_render_batch(frames, stages),
             "groups": (1, 2),
             "group_names": {1: "transform: transform_items_batch_kernel<0..3> + transform_special_batch_kernel (V4-V8)",
@@ -311,7 +314,7 @@ def make_job(config, distinct):
             "workload": "coded 3840x2160 VarDCT, Gabor + EPF iters 3, 2x non-separable upsampling -> 7680x4320, intensity target 4000, Rec.2100 PQ (BASELINE config 5)",
             "out_w": 2 * W4K, "out_h": 2 * H4K,
             "make": lambda d: VardctWorkload(W4K, H4K, seed=5000 + d, epf_iters=3, upsampling=2, intensity_target=4000.0, hdr_pq=True),
-            "upload": lambda ctx, wl: ctx.vardct_upload(wl.desc()),
+            "upload": lambda ctx, wl: ctx.vardct_upload(wl.desc(coeff_transport=transport)),
             "render": render, "groups": (1, 2),
             "group_names": {1: "transform: V4-V8", 2: "post: fused_post_kernel<true,4> (Gabor + EPF step 0) + post_pk_kernel (steps 1, 2) + upsample2_stream_kernel (2x + PQ)"},
             "alg_bytes": lambda f, g: W4K * H4K * 12 + 4 * W4K * H4K * 12,  # 12 B per coded px in, 12 B per output px out

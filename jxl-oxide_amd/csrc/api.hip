@@ -628,7 +628,16 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
     // grouped lists feed the transform kernels directly; dense cells are built from them only for frames
     // with >= 128-px varblocks (global-memory path) or on request (JXLGPU_NO_SPARSE_TR)
-    f->sparse_tr = grouped && !ctx->tune.no_sparse_tr && lists[CLS_BIG].empty();
+    // ... and only if a zero coefficient dequantises to +0.0 (the list-fed kernels never touch the zeros):
+    // 0 * quant_bias * matrix * mul has that value when the factors are finite and not negative — true of
+    // every conforming stream (the reference rejects weights <= 0 or >= 1e8, jxl-vardct/src/dequant.rs:191-196, 391-396)
+    bool zero_stays_zero = true;
+    auto nonneg_finite = [](float v) { uint32_t u; memcpy(&u, &v, 4); return (u >> 31) == 0 && (u & 0x7f800000u) != 0x7f800000u; };
+    for (int c = 0; c < 3; ++c) zero_stays_zero &= nonneg_finite(d->quant_bias[c]);
+    if (grouped)
+        for (float v : deq)
+            if (!nonneg_finite(v)) { zero_stays_zero = false; break; }
+    f->sparse_tr = grouped && !ctx->tune.no_sparse_tr && lists[CLS_BIG].empty() && zero_stays_zero;
     if (!f->sparse_tr) TRY(dev_alloc(ctx, f, &f->coeff, npix * 3));
     TRY(dev_alloc(ctx, f, &f->pix_t, npix * 3));
     if (d->coeff_format != JXLGPU_COEFF_DENSE && f->coeff) HIP_TRY(ctx, hipMemsetAsync(f->coeff, 0, npix * 12, ctx->stream));

@@ -16,19 +16,17 @@ namespace {
 
 __global__ __launch_bounds__(64) void transform_special_sparse_kernel(TransformArgs a, const uint4* __restrict__ entries,
                                                                       const uint32_t* __restrict__ nzc, uint32_t count) {
-    __shared__ float lut[kLutWords];
     __shared__ __attribute__((aligned(16))) int tile[kSpecialTileWords];
-    special_body<true>(a, entries, nzc, count, lut, tile);
+    special_body<true>(a, entries, nzc, count, nullptr, tile);
 }
 
 __global__ __launch_bounds__(64) void transform_special_sparse_batch_kernel(FrameBatch b) {
-    __shared__ float lut[kLutWords];
     __shared__ __attribute__((aligned(16))) int tile[kSpecialTileWords];
     const FrameDevC fd = (FrameDevC)b.f[blockIdx.y];
     const uint32_t count = fd->special_count;
     if (blockIdx.x * kSpecialPerWave >= count) return;
     const TransformArgs a = load_transform_args(fd);
-    special_body<true>(a, fd->entries + fd->special_first, fd->nzc + fd->special_first, count, lut, tile);
+    special_body<true>(a, fd->entries + fd->special_first, fd->nzc + fd->special_first, count, nullptr, tile);
 }
 
 // Fallback: expand the lists into the dense cell-tiled coefficients (zeroed by the caller).  One wave

@@ -27,9 +27,9 @@ def use_native(on=True):
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB) or any(
-            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
-            for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))):
+    deps = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))]
+    deps.append(os.path.join(_HERE, "..", "include", "jxlgpu.h"))  # the shared POD descriptors
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(f) > os.path.getmtime(_LIB) for f in deps):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB
 

@@ -141,3 +141,19 @@ def test_malformed_lists_are_rejected_or_ignored(gpu_ctx, oracle):
     finally:
         f.free()
     del keep
+
+
+def test_negative_quant_bias_takes_the_dense_kernels(gpu_ctx, oracle):
+    """A zero coefficient times a negative quant_bias is -0.0, which the list-fed kernels (zeros never
+    touched) would not produce: such a frame is expanded to dense cells at upload.  Same result as the oracle."""
+    wl = VardctWorkload(264, 200, seed=21)
+    d0 = wl.desc()
+    d0.quant_bias[0] = -0.9
+    exp, _ = oracle.vardct_render(d0, S_TR, wl.width, wl.height)
+    d = wl.desc(coeff_transport="grouped")
+    d.quant_bias[0] = -0.9
+    f = gpu_ctx.vardct_upload(d)
+    try:
+        _same(gpu_ctx.vardct_render(f, S_TR), exp, "negative quant_bias")
+    finally:
+        f.free()
