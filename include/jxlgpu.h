@@ -403,12 +403,15 @@ typedef struct {
      *     sample = residual * multiplier + offset + predict(neighbours)      (decode_one, :878-890)
      * 0xFFFFFFFF = the channel buffers already hold reconstructed samples; 0..13 = they hold the
      * residuals (`unpack_signed` tokens) of that Predictor (jxl-modular/src/predictor.rs:26-41),
-     * applied per group_dim x group_dim tile with a fresh PredictorState per tile.  6 =
+     * applied with a fresh PredictorState per (group, channel) subgrid exactly as the reference
+     * carves them (prepare_groups, jxl-modular/src/image.rs:209-340): every TRANSFORMED channel —
+     * each Squeeze sub-channel, each palette table — on its own tile grid: the leading meta / small
+     * channels whole (GlobalModular), the others in (group_dim >> hshift) x (group_dim >> vshift)
+     * pass-group tiles, or LF-group tiles once both shifts reach 3.  The channel buffers and the meta
+     * channels hold the residuals of those transformed channels, carved as described above.  6 =
      * SelfCorrecting with `wp_params`.  MA trees with more than one leaf choose the entropy-coding
-     * context from the neighbours, so they stay with the entropy decoder on the host.
-     * Restriction: only with transform chains made of RCT (or none).  With Squeeze or Palette the
-     * reference predicts every carved sub-channel and meta channel separately, on its own tile grid
-     * (group_dim >> shift, image.rs:209-371); that combination returns JXLGPU_ERR_UNSUPPORTED.     */
+     * context from the neighbours, so they stay with the entropy decoder on the host.  All channels
+     * have ChannelShift 0 (no extra-channel upsampling shifts).                                     */
     uint32_t residual_predictor;
     int32_t residual_multiplier; /* MaTreeLeafClustered.multiplier (1 for a default leaf)            */
     int32_t residual_offset;     /* MaTreeLeafClustered.offset                                       */

@@ -732,10 +732,12 @@ __global__ __launch_bounds__(256) void palette_kernel(PalArgs g) {
 // workgroup: lane r owns row r and trails row r-1 by one column (wavefront), samples staged in LDS.
 template <typename S>
 __global__ __launch_bounds__(256) void gradient_kernel(void* buf, uint32_t stride, uint32_t width, uint32_t height,
-                                                       uint32_t group_dim) {
+                                                       uint32_t tile_w, uint32_t tile_h) {
     S* base = (S*)buf;
-    const uint32_t x0 = blockIdx.x * group_dim, y0 = blockIdx.y * group_dim;
-    const uint32_t gw = min(group_dim, width - x0), gh = min(group_dim, height - y0);
+    // into_groups_with_fixed_count (jxl-grid/src/mutable_subgrid.rs:480-515): tiles past the channel are empty
+    const uint32_t x0 = min(blockIdx.x * tile_w, width), y0 = min(blockIdx.y * tile_h, height);
+    const uint32_t gw = min(tile_w, width - x0), gh = min(tile_h, height - y0);
+    if (gw == 0 || gh == 0) return;
     S* g = base + (size_t)y0 * stride + x0;
     const uint32_t r = threadIdx.x;  // group_dim <= 256 rows
     // wavefront: at step s lane r handles column s - r.  Rows of the previous lane are read back
@@ -777,9 +779,10 @@ __global__ __launch_bounds__(256) void gradient_kernel(void* buf, uint32_t strid
 // PredictorState / Properties::record (predictor.rs:540-577) and SelfCorrectingPredictor
 // (predictor.rs:312-441) statement by statement; its two error rows live in LDS and are
 // overwritten in place exactly like the reference's `true_err_row` / `subpred_err_row`.
+constexpr uint32_t kPredMaxTileW = 1024;  // the self-correcting predictor's error rows live in LDS
 struct PredArgs {
     void* buf;
-    uint32_t stride, width, height, group_dim, predictor;
+    uint32_t stride, width, height, tile_w, tile_h, predictor;
     int32_t mul, off;
     int32_t wp[11];
 };
@@ -788,20 +791,24 @@ __device__ __forceinline__ uint32_t div_lookup_dev(uint32_t i) { return i == 0 ?
 
 template <typename S>
 __global__ __launch_bounds__(256) void predict_kernel(PredArgs a) {
-    __shared__ int32_t s_true_err[256];
-    __shared__ uint32_t s_sub_err[4][256];
+    __shared__ int32_t s_true_err[kPredMaxTileW];
+    __shared__ uint32_t s_sub_err[4][kPredMaxTileW];
     S* base = (S*)a.buf;
-    const uint32_t x0 = blockIdx.x * a.group_dim, y0 = blockIdx.y * a.group_dim;
-    const uint32_t gw = min(a.group_dim, a.width - x0), gh = min(a.group_dim, a.height - y0);
+    // one (group, channel) subgrid per workgroup: into_groups_with_fixed_count, mutable_subgrid.rs:480-515
+    const uint32_t x0 = min(blockIdx.x * a.tile_w, a.width), y0 = min(blockIdx.y * a.tile_h, a.height);
+    const uint32_t gw = min(a.tile_w, a.width - x0), gh = min(a.tile_h, a.height - y0);
+    if (gw == 0 || gh == 0) return;  // workgroup-uniform
     const uint32_t r = threadIdx.x;
     S* row = base + (size_t)(y0 + r) * a.stride + x0;
     const S* prev = row - a.stride;
     const S* prev2 = prev - a.stride;
     const bool active = r < gh;
     const bool sc_on = a.predictor == 6;
-    s_true_err[r] = 0;
+    for (uint32_t i = r; i < kPredMaxTileW; i += 256) {
+        s_true_err[i] = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s_sub_err[i][r] = 0;
+        for (int k = 0; k < 4; ++k) s_sub_err[k][i] = 0;
+    }
     __syncthreads();
 
     // PredictorState registers
@@ -1250,6 +1257,10 @@ struct Grid {
     uint32_t x0, y0, w, h;
     int loc;                 // which working copy holds the data (channel buffers only)
     std::vector<int> members;  // palette: buffers of the merged member channels
+    // ModularChannelInfo (jxl-modular/src/lib.rs:157-191): shifts accumulated by Squeeze (-1: unshiftable meta
+    // channel) and the size of the untransformed channel, which fixes the number of groups
+    int hshift = 0, vshift = 0;
+    uint32_t orig_w = 0, orig_h = 0;
 };
 
 struct ModularState {
@@ -1259,6 +1270,7 @@ struct ModularState {
     std::vector<void*> orig;                  // uploaded buffers (never modified)
     std::vector<void*> work[4];               // three working copies; [3] aliases `orig` (read-only location)
     std::vector<void*> meta;
+    std::vector<void*> meta_work;             // writable copies (the predictor pass runs on the palette tables too)
     std::vector<uint32_t> mw, mh;
     std::vector<JxlGpuTransform> transforms;
     std::vector<std::vector<JxlGpuSqueezeStep>> explicit_steps;  // per transform (empty = default)
@@ -1398,35 +1410,21 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     // the in-place passes (predictor, RCT, palette) need a writable copy first.
     m->work[3] = m->orig;
     const bool predict = m->desc.residual_predictor <= 13;
-    if (predict)
+    if (predict) {
         for (uint32_t c = 0; c < nch; ++c)
             HIP_TRY(ctx, hipMemcpyAsync(m->work[0][c], m->orig[c], (size_t)m->cw[c] * m->ch[c] * esz, hipMemcpyDeviceToDevice, s));
-
-    if (m->desc.residual_predictor <= 13) {
-        const uint32_t gd = m->desc.group_dim ? m->desc.group_dim : 256;
-        // decode_single_node's dispatch (image.rs:733-777)
-        const bool simple_grad = m->desc.residual_predictor == 5 && m->desc.residual_offset == 0 && m->desc.residual_multiplier == 1;
-        for (uint32_t c = 0; c < nch; ++c) {
-            dim3 grid(ceil_div(m->cw[c], gd), ceil_div(m->ch[c], gd));
-            if (simple_grad) {
-                if (i16) gradient_kernel<int16_t><<<grid, 256, 0, s>>>(m->work[0][c], m->cw[c], m->cw[c], m->ch[c], gd);
-                else gradient_kernel<int32_t><<<grid, 256, 0, s>>>(m->work[0][c], m->cw[c], m->cw[c], m->ch[c], gd);
-            } else {
-                PredArgs pa;
-                pa.buf = m->work[0][c]; pa.stride = m->cw[c]; pa.width = m->cw[c]; pa.height = m->ch[c];
-                pa.group_dim = gd; pa.predictor = m->desc.residual_predictor;
-                pa.mul = m->desc.residual_multiplier; pa.off = m->desc.residual_offset;
-                for (int i = 0; i < 11; ++i) pa.wp[i] = m->desc.wp_params[i];
-                if (i16) predict_kernel<int16_t><<<grid, 256, 0, s>>>(pa);
-                else predict_kernel<int32_t><<<grid, 256, 0, s>>>(pa);
-            }
-        }
+        for (size_t c = 0; c < m->meta.size(); ++c)
+            HIP_TRY(ctx, hipMemcpyAsync(m->meta_work[c], m->meta[c], (size_t)m->mw[c] * m->mh[c] * esz, hipMemcpyDeviceToDevice, s));
     }
 
     // forward bookkeeping (transform_channel_info): which rectangle is which transformed channel
     std::vector<Grid> l;
     int nb_meta = 0;
-    for (uint32_t c = 0; c < nch; ++c) l.push_back(Grid{(int)c, 0, 0, m->cw[c], m->ch[c], predict ? 0 : 3, {}});
+    for (uint32_t c = 0; c < nch; ++c) {
+        Grid g{(int)c, 0, 0, m->cw[c], m->ch[c], predict ? 0 : 3, {}};
+        g.orig_w = m->cw[c]; g.orig_h = m->ch[c];
+        l.push_back(g);
+    }
     int meta_next = 0;
     m->steps.assign(m->transforms.size(), {});
     for (size_t t = 0; t < m->transforms.size(); ++t) {
@@ -1447,7 +1445,10 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 l[begin].members.push_back(l[begin + 1].buf);
                 l.erase(l.begin() + begin + 1);
             }
-            l.insert(l.begin(), Grid{~meta_next, 0, 0, tr.nb_colours, tr.num_c, 0, {}});
+            Grid pal{~meta_next, 0, 0, tr.nb_colours, tr.num_c, 0, {}};
+            pal.hshift = pal.vshift = -1;  // ModularChannelInfo::new_unshiftable, transform.rs:236
+            pal.orig_w = tr.nb_colours; pal.orig_h = tr.num_c;
+            l.insert(l.begin(), pal);
             ++meta_next;
         } else if (tr.kind == JXLGPU_TR_SQUEEZE) {
             std::vector<JxlGpuSqueezeStep>& sp = m->steps[t];
@@ -1465,8 +1466,14 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     Grid& g = l[i];
                     if (g.w == 0 || g.h == 0 || g.buf < 0) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "cannot squeeze this channel");
                     Grid r = g;
-                    if (st.horizontal) { uint32_t len = g.w; g.w = (len + 1) / 2; r.w = len / 2; r.x0 = g.x0 + g.w; }
-                    else { uint32_t len = g.h; g.h = (len + 1) / 2; r.h = len / 2; r.y0 = g.y0 + g.h; }
+                    if (g.hshift > 30 || g.vshift > 30) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "channel squeezed too much");
+                    if (st.horizontal) {
+                        uint32_t len = g.w; g.w = (len + 1) / 2; r.w = len / 2; r.x0 = g.x0 + g.w;
+                        if (g.hshift >= 0) { ++g.hshift; ++r.hshift; }  // transform.rs:398-401
+                    } else {
+                        uint32_t len = g.h; g.h = (len + 1) / 2; r.h = len / 2; r.y0 = g.y0 + g.h;
+                        if (g.vshift >= 0) { ++g.vshift; ++r.vshift; }
+                    }
                     res.push_back(r);
                 }
                 l.insert(st.in_place ? l.begin() + end : l.end(), res.begin(), res.end());
@@ -1482,8 +1489,60 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             return (char*)m->work[loc][g.buf] + ((size_t)g.y0 * *stride + g.x0) * esz;
         }
         *stride = m->mw[~g.buf];
-        return (char*)m->meta[~g.buf];
+        return (char*)(predict ? m->meta_work[~g.buf] : m->meta[~g.buf]);
     };
+
+    // ---- M4: residuals -> samples, one (group, channel) subgrid at a time, BEFORE the inverse transforms.
+    // The reference decodes every transformed channel on its own tile grid (prepare_groups,
+    // jxl-modular/src/image.rs:209-340): the leading meta channels and the leading channels that fit one
+    // group are whole-channel streams of GlobalModular (:224-228 skip_while); of the rest, channels with
+    // hshift < 3 or vshift < 3 are cut into (group_dim >> hshift) x (group_dim >> vshift) pass-group tiles,
+    // the others into LF-group tiles of (8 group_dim >> shift); the tile COUNT comes from the untransformed
+    // size (:279-284, :300-305).  Every tile starts a fresh PredictorState (decode_single_node, :716-777).
+    if (predict) {
+        const uint32_t gd = m->desc.group_dim ? m->desc.group_dim : 256;
+        // decode_single_node's dispatch (image.rs:733-777)
+        const bool simple_grad = m->desc.residual_predictor == 5 && m->desc.residual_offset == 0 && m->desc.residual_multiplier == 1;
+        bool global_phase = true;
+        for (size_t i = 0; i < l.size(); ++i) {
+            const Grid& g = l[i];
+            if (g.w == 0 || g.h == 0) continue;
+            uint32_t tw, th, ncols, nrows;
+            if (global_phase && ((int)i < nb_meta || (g.w <= gd && g.h <= gd))) {
+                tw = g.w; th = g.h; ncols = nrows = 1;
+            } else {
+                global_phase = false;
+                if (g.hshift < 0 || g.vshift < 0) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "unshiftable channel among the grouped channels");
+                if (g.hshift < 3 || g.vshift < 3) {
+                    tw = gd >> g.hshift; th = gd >> g.vshift;
+                    ncols = ceil_div(g.orig_w, gd); nrows = ceil_div(g.orig_h, gd);
+                } else {
+                    tw = gd >> (g.hshift - 3); th = gd >> (g.vshift - 3);
+                    ncols = ceil_div(g.orig_w, gd * 8); nrows = ceil_div(g.orig_h, gd * 8);
+                }
+                if (g.hshift > 31 || g.vshift > 31 || tw == 0 || th == 0)
+                    return fail(ctx, JXLGPU_ERR_INVALID_ARG, "channel shift too large after transform");  // image.rs:265-273
+            }
+            if (th > 256 || (m->desc.residual_predictor == 6 && tw > kPredMaxTileW))
+                return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tile larger than 256 rows (or 1024 columns with the self-correcting predictor)");
+            if (nrows > 65535) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "too many group rows");
+            uint32_t stride = 0;
+            void* base = ptr(g, 0, &stride);
+            const dim3 grid(ncols, nrows);
+            if (simple_grad) {
+                if (i16) gradient_kernel<int16_t><<<grid, 256, 0, s>>>(base, stride, g.w, g.h, tw, th);
+                else gradient_kernel<int32_t><<<grid, 256, 0, s>>>(base, stride, g.w, g.h, tw, th);
+            } else {
+                PredArgs pa;
+                pa.buf = base; pa.stride = stride; pa.width = g.w; pa.height = g.h;
+                pa.tile_w = tw; pa.tile_h = th; pa.predictor = m->desc.residual_predictor;
+                pa.mul = m->desc.residual_multiplier; pa.off = m->desc.residual_offset;
+                for (int k = 0; k < 11; ++k) pa.wp[k] = m->desc.wp_params[k];
+                if (i16) predict_kernel<int16_t><<<grid, 256, 0, s>>>(pa);
+                else predict_kernel<int32_t><<<grid, 256, 0, s>>>(pa);
+            }
+        }
+    }
 
     // in-place passes: move a rectangle that still lives in the read-only upload into working copy 0
     auto ensure_writable = [&](Grid& g) -> hipError_t {
@@ -1660,18 +1719,10 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
         if (!d->meta_channels[c].data || !d->meta_channels[c].width || !d->meta_channels[c].height)
             return fail(ctx, JXLGPU_ERR_INVALID_ARG, "empty meta channel");
     {
-        // The separable predictor pass (M4) runs on whole top-level channel buffers in group_dim
-        // tiles.  With Squeeze or Palette in the chain the reference predicts every carved
-        // sub-channel / meta channel on its own tile grid (group_dim >> shift,
-        // jxl-modular/src/image.rs:209-371): not the same image, so that combination stays on the
-        // caller's CPU path instead of silently decoding something else.
         uint32_t meta_used = 0;
         for (uint32_t t = 0; t < d->num_transforms; ++t) {
             const JxlGpuTransform& tr = d->transforms[t];
             if (tr.kind > JXLGPU_TR_SQUEEZE) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "unknown transform kind");
-            if (d->residual_predictor <= 13 && (tr.kind == JXLGPU_TR_SQUEEZE || tr.kind == JXLGPU_TR_PALETTE))
-                return fail(ctx, JXLGPU_ERR_UNSUPPORTED,
-                            "residual_predictor together with Squeeze / Palette (the reference predicts each carved sub-channel separately)");
             if (tr.kind == JXLGPU_TR_PALETTE) {
                 if (meta_used >= d->num_meta_channels) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "Palette transform without its meta channel");
                 const JxlGpuModularChannel& mc = d->meta_channels[meta_used++];
@@ -1727,6 +1778,10 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
         m->meta.push_back(p);
         m->mw.push_back(ch.width);
         m->mh.push_back(ch.height);
+        if (d->residual_predictor <= 13) {  // the predictor pass rewrites the palette table: it needs a copy of its own
+            if ((rc = malloc_dev(ctx, f, &p, bytes))) return rc;
+            m->meta_work.push_back(p);
+        }
     }
     for (uint32_t t = 0; t < d->num_transforms; ++t) {
         m->transforms.push_back(d->transforms[t]);

@@ -58,8 +58,13 @@ def forward_squeeze_rows(v):
 
 
 class _Grid:
-    def __init__(self, buf, x0, y0, w, h):
+    """A transformed channel: a sub-rectangle of buffer `buf` (>= 0) or meta table ~buf, with the shifts
+    Squeeze has accumulated (-1: an unshiftable meta channel) and the size of the untransformed channel."""
+    def __init__(self, buf, x0, y0, w, h, hshift=0, vshift=0, orig_w=None, orig_h=None):
         self.buf, self.x0, self.y0, self.w, self.h = buf, x0, y0, w, h
+        self.hshift, self.vshift = hshift, vshift
+        self.orig_w = w if orig_w is None else orig_w
+        self.orig_h = h if orig_h is None else orig_h
 
 
 def default_squeeze_params(grids):
@@ -95,7 +100,8 @@ def forward_squeeze(bufs, grids, steps, quant=None):
                     res = quant(level, res)
                 view[:, :aw] = avg
                 view[:, aw:] = res
-                r = _Grid(g.buf, g.x0 + aw, g.y0, g.w - aw, g.h)
+                g.hshift += 1
+                r = _Grid(g.buf, g.x0 + aw, g.y0, g.w - aw, g.h, g.hshift, g.vshift, g.orig_w, g.orig_h)
                 g.w = aw
             else:
                 avg, res = forward_squeeze_rows(view.T.copy())
@@ -104,7 +110,8 @@ def forward_squeeze(bufs, grids, steps, quant=None):
                     res = quant(level, res)
                 view[:ah, :] = avg.T
                 view[ah:, :] = res.T
-                r = _Grid(g.buf, g.x0, g.y0 + ah, g.w, g.h - ah)
+                g.vshift += 1
+                r = _Grid(g.buf, g.x0, g.y0 + ah, g.w, g.h - ah, g.hshift, g.vshift, g.orig_w, g.orig_h)
                 g.h = ah
             residuals.append(r)
         at = end if in_place else len(grids)
@@ -141,6 +148,80 @@ def forward_rct(a, b, c, rct_type):
     else:
         bb = e
     return aa, bb, cc
+
+
+def channel_tiles(grids, nb_meta, group_dim):
+    """For every transformed channel (in order) the list of its (x0, y0, w, h) decode units, as the
+    format carves them (18181-1 clause on GlobalModular / ModularLfGroup / ModularGroup): the leading
+    meta channels and the leading channels no larger than one group are coded whole in the global
+    section; once a channel is larger than group_dim in either direction, it and every later channel
+    is coded per group — in group_dim-sized groups scaled by the channel's shifts when min(hshift,
+    vshift) < 3, in 8 x group_dim LF groups otherwise — with as many groups as the UNTRANSFORMED
+    channel has.  Written from that rule, not from oracle/ or csrc/."""
+    out = []
+    grouped = False
+    for i, g in enumerate(grids):
+        if not grouped and (i < nb_meta or (g.w <= group_dim and g.h <= group_dim)):
+            out.append([(0, 0, g.w, g.h)] if g.w and g.h else [])
+            continue
+        grouped = True
+        assert g.hshift >= 0 and g.vshift >= 0
+        dim = group_dim if min(g.hshift, g.vshift) < 3 else group_dim * 8
+        tw, th = dim >> g.hshift, dim >> g.vshift
+        assert tw > 0 and th > 0
+        ncols, nrows = -(-g.orig_w // dim), -(-g.orig_h // dim)
+        tiles = []
+        for gy in range(nrows):
+            for gx in range(ncols):
+                x0, y0 = gx * tw, gy * th
+                if x0 < g.w and y0 < g.h:
+                    tiles.append((x0, y0, min(tw, g.w - x0), min(th, g.h - y0)))
+        out.append(tiles)
+    return out
+
+
+_wp_lib = None
+
+
+def _wp_forward_lib():
+    """synth_wp.c (the encoder-side weighted predictor, a C transcription of weighted_residuals) built
+    on demand next to this file."""
+    global _wp_lib
+    if _wp_lib is None:
+        import os
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        src, so = os.path.join(here, "synth_wp.c"), os.path.join(here, "_synth_wp.so")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["gcc", "-O2", "-fwrapv", "-shared", "-fPIC", src, "-o", so])
+        _wp_lib = C.CDLL(so)
+        _wp_lib.synth_wp_residuals_tile.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                                   C.POINTER(C.c_int32)]
+    return _wp_lib
+
+
+def tile_residuals(t, predictor, offset=0, wp=None, fast_wp=True):
+    """Residuals of ONE decode unit `t` (2-D int64) for a single-leaf tree with `predictor`."""
+    if predictor == 6:
+        wp = DEFAULT_WP if wp is None else wp
+        if not fast_wp:
+            return weighted_residuals(t, max(t.shape), wp) - offset
+        t = np.ascontiguousarray(t, dtype=np.int64)
+        out = np.zeros_like(t)
+        h, w = t.shape
+        _wp_forward_lib().synth_wp_residuals_tile(t.ctypes.data, w, w, h, out.ctypes.data, w, (C.c_int32 * 11)(*wp))
+        return out - offset
+    return predictor_residuals(t, max(t.shape), predictor, offset)
+
+
+def residuals_in_place(bufs, metas, grids, nb_meta, group_dim, predictor, offset=0, wp=None):
+    """Replaces the samples of every transformed channel by its residuals, decode unit by decode unit."""
+    for g, tiles in zip(grids, channel_tiles(grids, nb_meta, group_dim)):
+        arr = bufs[g.buf] if g.buf >= 0 else metas[~g.buf]
+        view = arr[g.y0:g.y0 + g.h, g.x0:g.x0 + g.w]
+        src = view.copy()
+        for (x0, y0, w, h) in tiles:
+            view[y0:y0 + h, x0:x0 + w] = tile_residuals(src[y0:y0 + h, x0:x0 + w].astype(np.int64), predictor, offset, wp)
 
 
 def gradient_residuals(img, group_dim):
@@ -350,7 +431,10 @@ class ModularWorkload:
     transforms, exercises wrapping)."""
 
     def __init__(self, width, height, kind="squeeze", seed=0, i16=True, lossy=True, rct_type=None,
-                 xyb=True, epf_iters=0, gabor=False, bit_depth=8, predictor=5, pred_offset=0):
+                 xyb=True, epf_iters=0, gabor=False, bit_depth=8, predictor=5, pred_offset=0, residual=None):
+        """`residual` (kinds 'squeeze', 'palette'): a Predictor id — the buffers then hold the RESIDUALS of
+        that predictor (single-leaf MA tree) for every transformed channel, computed decode unit by decode
+        unit (channel_tiles) from the transformed samples; None: they hold the samples themselves."""
         rng = np.random.default_rng(SEED_BASE + 0x100 + seed)
         self.width, self.height, self.kind = width, height, kind
         self.dtype = np.int16 if i16 else np.int32
@@ -416,6 +500,9 @@ class ModularWorkload:
                 return _trunc_div(res, q) * 1  # quantised residuals (dequantised form is what is coded)
             forward_squeeze(bufs, grids, steps, quant)
             self.transforms.append(("squeeze", None))
+            if residual is not None:
+                residuals_in_place(bufs, [], grids, 0, 256, residual, pred_offset)
+                self.residual_predictor, self.residual_offset = residual, pred_offset
             self.buffers = [b.astype(self.dtype) for b in bufs]
         elif kind == "palette":
             ncol = 37
@@ -423,6 +510,12 @@ class ModularWorkload:
             idx = rng.integers(0, ncol, size=(H, W)).astype(np.int64)
             self.expected = [pal[c][idx].astype(self.dtype) for c in range(3)]
             self.transforms.append(("palette", 0, 3, ncol))
+            if residual is not None:
+                # transformed channel list: [palette table (meta, unshiftable), index channel]
+                grids = [_Grid(~0, 0, 0, ncol, 3, -1, -1), _Grid(0, 0, 0, W, H)]
+                bufs, metas = [idx], [pal]
+                residuals_in_place(bufs, metas, grids, 1, 256, residual, pred_offset)
+                self.residual_predictor, self.residual_offset = residual, pred_offset
             self.meta.append(pal.astype(self.dtype))
             self.buffers = [idx.astype(self.dtype), np.zeros((H, W), self.dtype), np.zeros((H, W), self.dtype)]
         elif kind == "palette_delta":

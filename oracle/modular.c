@@ -182,6 +182,7 @@ typedef struct {
     int32_t hshift, vshift;
     int nmembers;            /* palette: merged member grids                                 */
     int members[8];
+    uint32_t orig_w, orig_h; /* ModularChannelInfo.original_width / height (lib.rs:157-191)  */
 } Grid;
 
 typedef struct {
@@ -307,34 +308,13 @@ int jxl_oracle_modular_inverse(const JxlGpuModularDesc* d, void* const* out) {
         w.meta[c] = malloc(n);
         memcpy(w.meta[c], d->meta_channels[c].data, n);
     }
-    /* M4: separable predictor application (single-leaf tree), per group_dim x group_dim tile.
-     * decode_single_node's dispatch (image.rs:733-777): Gradient with offset 0 / multiplier 1 takes
-     * decode_simple_grad, everything else decode_one with a fresh PredictorState (predict.c). */
-    if (d->residual_predictor <= 13) {
-        uint32_t gd = d->group_dim ? d->group_dim : 256;
-        const int simple_grad = d->residual_predictor == 5 && d->residual_offset == 0 && d->residual_multiplier == 1;
-        for (uint32_t c = 0; c < d->num_channels; ++c) {
-            uint32_t W = d->channels[c].width, H = d->channels[c].height;
-            long ngx = (W + gd - 1) / gd, ngy = (H + gd - 1) / gd;
-#pragma omp parallel for schedule(dynamic)
-            for (long g = 0; g < ngx * ngy; ++g) {
-                uint32_t x0 = (uint32_t)(g % ngx) * gd, y0 = (uint32_t)(g / ngx) * gd;
-                uint32_t gw = W - x0 < gd ? W - x0 : gd, gh = H - y0 < gd ? H - y0 : gd;
-                if (!simple_grad)
-                    orc_predict_apply((char*)w.bufs[c] + ((size_t)y0 * W + x0) * esz, W, gw, gh, (int)esz,
-                                      d->residual_predictor, d->residual_multiplier, d->residual_offset, d->wp_params);
-                else if (esz == 2) gradient_apply_i16((int16_t*)w.bufs[c] + (size_t)y0 * W + x0, W, gw, gh);
-                else gradient_apply_i32((int32_t*)w.bufs[c] + (size_t)y0 * W + x0, W, gw, gh);
-            }
-        }
-    } else if (d->residual_predictor != 0xFFFFFFFFu) {
-        return JXLGPU_ERR_INVALID_ARG;
-    }
+    if (d->residual_predictor > 13 && d->residual_predictor != 0xFFFFFFFFu) return JXLGPU_ERR_INVALID_ARG;
 
     /* forward bookkeeping: which sub-rectangle is which transformed channel */
     GridList l = {NULL, 0, 0, 0};
     for (uint32_t c = 0; c < d->num_channels; ++c) {
         Grid g = {(int)c, 0, 0, d->channels[c].width, d->channels[c].height, 0, 0, 0, {0}};
+        g.orig_w = g.w; g.orig_h = g.h;
         gl_insert(&l, l.n, g);
     }
     JxlGpuSqueezeStep** steps = (JxlGpuSqueezeStep**)calloc(d->num_transforms + 1, sizeof(void*));
@@ -356,7 +336,8 @@ int jxl_oracle_modular_inverse(const JxlGpuModularDesc* d, void* const* out) {
             /* keep member buffers addressable: store their buffer ids */
             leader = &l.g[begin];
             for (int i = 0; i < leader->nmembers; ++i) leader->members[i] = members[i].buf;
-            Grid pal = {~meta_next, 0, 0, tr->nb_colours, tr->num_c, -1, -1, 0, {0}};
+            Grid pal = {~meta_next, 0, 0, tr->nb_colours, tr->num_c, -1, -1, 0, {0}};  /* new_unshiftable */
+            pal.orig_w = pal.w; pal.orig_h = pal.h;
             meta_next++;
             gl_insert(&l, 0, pal);
         } else if (tr->kind == JXLGPU_TR_SQUEEZE) {
@@ -369,6 +350,57 @@ int jxl_oracle_modular_inverse(const JxlGpuModularDesc* d, void* const* out) {
             for (int i = 0; i < n && rc == 0; ++i)
                 if (squeeze_forward_step(&l, &sp[i])) rc = JXLGPU_ERR_INVALID_ARG;
         } else rc = JXLGPU_ERR_INVALID_ARG;
+    }
+
+    /* M4: separable predictor application (single-leaf MA tree): residuals -> samples, one (group, channel)
+     * subgrid at a time with a fresh PredictorState, on the TRANSFORMED channel list, before the inverse
+     * transforms.  prepare_groups (image.rs:209-340): the leading meta channels and the leading channels
+     * that fit one group are decoded whole by GlobalModular (skip_while, :224-228); every later channel is
+     * cut with into_groups_with_fixed_count (jxl-grid mutable_subgrid.rs:480-515) into pass-group tiles
+     * (group_dim >> hshift) x (group_dim >> vshift) when hshift < 3 or vshift < 3 (:258-285), else into
+     * LF-group tiles (group_dim >> (shift - 3)) (:286-306); the tile count comes from original_width /
+     * original_height.  decode_single_node's dispatch (image.rs:733-777): Gradient with offset 0 and
+     * multiplier 1 takes decode_simple_grad, everything else decode_one (predict.c).                    */
+    if (d->residual_predictor <= 13 && rc == 0) {
+        const uint32_t gd = d->group_dim ? d->group_dim : 256;
+        const int simple_grad = d->residual_predictor == 5 && d->residual_offset == 0 && d->residual_multiplier == 1;
+        int global_phase = 1;
+        for (int i = 0; i < l.n && rc == 0; ++i) {
+            const Grid* g = &l.g[i];
+            if (g->w == 0 || g->h == 0) continue;
+            uint32_t tw, th, ncols, nrows;
+            if (global_phase && (i < l.nb_meta || (g->w <= gd && g->h <= gd))) {
+                tw = g->w; th = g->h; ncols = nrows = 1;
+            } else {
+                global_phase = 0;
+                if (g->hshift < 0 || g->vshift < 0) { rc = JXLGPU_ERR_INVALID_ARG; break; }  /* assert!, image.rs:243 */
+                if (g->hshift < 3 || g->vshift < 3) {
+                    tw = gd >> g->hshift; th = gd >> g->vshift;
+                    ncols = (g->orig_w + gd - 1) / gd; nrows = (g->orig_h + gd - 1) / gd;
+                } else {
+                    tw = gd >> (g->hshift - 3); th = gd >> (g->vshift - 3);
+                    ncols = (g->orig_w + gd * 8 - 1) / (gd * 8); nrows = (g->orig_h + gd * 8 - 1) / (gd * 8);
+                }
+                if (g->hshift > 31 || g->vshift > 31 || tw == 0 || th == 0) { rc = JXLGPU_ERR_INVALID_ARG; break; }  /* InvalidSqueezeParams */
+            }
+            size_t stride;
+            char* base = (char*)grid_ptr(&w, g, &stride, esz);
+            const uint32_t W = g->w, H = g->h;
+#pragma omp parallel for schedule(dynamic)
+            for (long t = 0; t < (long)ncols * nrows; ++t) {
+                uint32_t x0 = (uint32_t)(t % ncols) * tw, y0 = (uint32_t)(t / ncols) * th;
+                if (x0 > W) x0 = W;
+                if (y0 > H) y0 = H;
+                const uint32_t gw = W - x0 < tw ? W - x0 : tw, gh = H - y0 < th ? H - y0 : th;
+                if (gw == 0 || gh == 0) continue;
+                char* p = base + ((size_t)y0 * stride + x0) * esz;
+                if (!simple_grad)
+                    orc_predict_apply(p, stride, gw, gh, (int)esz, d->residual_predictor, d->residual_multiplier,
+                                      d->residual_offset, d->wp_params);
+                else if (esz == 2) gradient_apply_i16((int16_t*)p, stride, gw, gh);
+                else gradient_apply_i32((int32_t*)p, stride, gw, gh);
+            }
+        }
     }
 
     /* inverse, last transform first */

@@ -61,12 +61,14 @@ def test_config5_hdr_upsampled(gpu_ctx, oracle):
 
 @pytest.fixture(scope="module")
 def modular_8k():
-    return ModularWorkload(7680, 4320, kind="squeeze", lossy=True, i16=True, epf_iters=2, seed=3)
+    # BASELINE config 3 as worded: lossy Squeeze AND self-correcting-predictor residuals (single-leaf tree) on
+    # every carved sub-channel
+    return ModularWorkload(7680, 4320, kind="squeeze", lossy=True, i16=True, epf_iters=2, seed=3, residual=6)
 
 
 def test_config3_8k_squeeze_inverse_bit_exact(gpu_ctx, oracle, modular_8k):
-    """7680x4320 Modular, lossy Squeeze (default 22-step schedule), 16-bit buffers: the integer
-    reconstruction must be bit-identical."""
+    """7680x4320 Modular, lossy Squeeze (default 22-step schedule) + self-correcting predictor residuals on
+    the 67 carved sub-channels, 16-bit buffers: the integer reconstruction must be bit-identical."""
     wl = modular_8k
     d = wl.desc()
     exp = oracle.modular_inverse(d, wl.shapes(), wl.dtype)

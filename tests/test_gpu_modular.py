@@ -209,15 +209,10 @@ print("FIXUP_OK")
 
 
 def test_upload_rejects_what_the_device_path_would_get_wrong(gpu_ctx):
-    """Descriptor validation of jxlgpu_modular_upload: predictor + Squeeze / Palette is
-    UNSUPPORTED (the reference predicts each carved sub-channel separately); malformed upsampling /
-    EPF / meta-channel parameters are INVALID_ARG instead of out-of-bounds device accesses."""
+    """Descriptor validation of jxlgpu_modular_upload: malformed upsampling / EPF / meta-channel
+    parameters are INVALID_ARG instead of out-of-bounds device accesses.  (Predictor + Squeeze / Palette,
+    refused until round 2, is implemented: test_predictor_on_transformed_channels.)"""
     from jxl_oxide_amd.runtime import JxlGpuError
-    wl = ModularWorkload(64, 48, kind="squeeze", lossy=False, xyb=False, seed=1)
-    wl.residual_predictor = 5
-    with pytest.raises(JxlGpuError) as e:
-        gpu_ctx.modular_upload(wl.desc())
-    assert e.value.code == abi.ERR_UNSUPPORTED
     wl = ModularWorkload(64, 48, kind="squeeze", lossy=False, xyb=False, seed=1)
     d = wl.desc()
     d.upsampling.factor = 3
@@ -243,3 +238,40 @@ def test_all_rct_codes(gpu_ctx, oracle):
         got = _inverse_both(gpu_ctx, oracle, wl)
         for c in range(3):
             assert np.array_equal(got[c], wl.expected[c]), rct_type
+
+
+@pytest.mark.parametrize("case", [
+    dict(kind="squeeze", lossy=False, xyb=False, residual=5),
+    dict(kind="squeeze", lossy=False, xyb=False, residual=6),
+    dict(kind="squeeze", lossy=False, xyb=False, residual=13, pred_offset=3),
+    dict(kind="squeeze", lossy=False, xyb=False, residual=6, i16=False, rct_type=6),
+    dict(kind="squeeze", lossy=True, residual=6),
+    dict(kind="palette", residual=6),
+    dict(kind="palette", residual=4, i16=False),
+])
+@pytest.mark.parametrize("size", [(300, 200), (1100, 720), (257, 600), (40, 9)])
+def test_predictor_on_transformed_channels(gpu_ctx, oracle, case, size):
+    """M4 per carved sub-channel (prepare_groups, image.rs:209-340): predictor residuals of every Squeeze
+    sub-channel / palette table on its own tile grid, then the inverse transforms — HIP vs oracle, and vs
+    the original image where the chain is lossless (residuals from the independent numpy forward)."""
+    w, h = size
+    wl = ModularWorkload(w, h, seed=3, **case)
+    got = _inverse_both(gpu_ctx, oracle, wl)
+    if wl.expected is not None:
+        for c in range(3):
+            assert np.array_equal(got[c], wl.expected[c]), f"channel {c} differs from the original image"
+
+
+def test_predictor_squeeze_render_tail(gpu_ctx, oracle):
+    """BASELINE config 3 in small: lossy Squeeze + self-correcting predictor residuals, XYB dequantisation,
+    EPF, XYB -> sRGB."""
+    wl = ModularWorkload(520, 300, kind="squeeze", lossy=True, i16=True, epf_iters=2, seed=9, residual=6)
+    d = wl.desc()
+    stages = abi.STAGE_ALL | abi.STAGE_MODULAR_TO_FLOAT
+    exp = oracle.modular_render(d, stages, wl.width, wl.height)
+    f = gpu_ctx.modular_upload(d)
+    try:
+        got = gpu_ctx.modular_render(f, stages)
+    finally:
+        f.free()
+    assert_ulp(got, exp, 1, "lossy Squeeze + WP residuals render")

@@ -108,3 +108,67 @@ def test_palette_with_delta_entries(oracle, d_pred, i16):
     exp = palette_delta_reference(wl.index_plane, wl.palette, 29, 4, d_pred, 8, 16 if i16 else 32)
     for c in range(3):
         assert np.array_equal(got[c].astype(np.int64), exp[c]), f"channel {c}"
+
+
+# ---- M4 on transformed channels: the predictor runs per carved sub-channel / palette
+# table on its own tile grid (prepare_groups, jxl-modular/src/image.rs:209-340).  The residuals come from
+# synth_modular: forward Squeeze / palette, the tile geometry (channel_tiles) and the forward predictors are
+# all written independently of oracle/ — so an exact round trip pins the oracle, not the oracle itself.
+
+def test_wp_forward_c_matches_the_python_transcription():
+    """synth_wp.c (used for sizes the pure-Python loop cannot reach) == weighted_residuals."""
+    from jxl_oxide_amd import synth_modular as sm
+    rng = np.random.default_rng(1)
+    for (h, w) in [(1, 1), (1, 7), (5, 1), (2, 2), (9, 13), (33, 40), (64, 3)]:
+        t = rng.integers(-300, 300, size=(h, w)).astype(np.int64)
+        assert np.array_equal(sm.tile_residuals(t, 6, fast_wp=True), sm.tile_residuals(t, 6, fast_wp=False)), (h, w)
+
+
+def test_channel_tiles_geometry():
+    """The decode units of an 8K default-Squeeze pyramid: whole small channels first, 2x2 LF-group tiles
+    for the deepest grouped levels, (256 >> shift) pass-group tiles for the shallow ones, nothing lost."""
+    from jxl_oxide_amd.synth_modular import _Grid, channel_tiles, default_squeeze_params
+    W, H = 7680, 4320
+    grids = [_Grid(i, 0, 0, W, H) for i in range(3)]
+    # bookkeeping only (no data): replay the carve of forward_squeeze
+    for (horizontal, in_place, begin, num_c) in default_squeeze_params(grids):
+        res = []
+        for g in grids[begin:begin + num_c]:
+            if horizontal:
+                aw = (g.w + 1) // 2
+                g.hshift += 1
+                res.append(_Grid(g.buf, g.x0 + aw, g.y0, g.w - aw, g.h, g.hshift, g.vshift, g.orig_w, g.orig_h))
+                g.w = aw
+            else:
+                ah = (g.h + 1) // 2
+                g.vshift += 1
+                res.append(_Grid(g.buf, g.x0, g.y0 + ah, g.w, g.h - ah, g.hshift, g.vshift, g.orig_w, g.orig_h))
+                g.h = ah
+        at = begin + num_c if in_place else len(grids)
+        grids[at:at] = res
+    tiles = channel_tiles(grids, 0, 256)
+    assert len(tiles) == len(grids) == 3 + 2 * 2 + 20 * 3
+    for g, tl in zip(grids, tiles):
+        assert sum(w * h for (_, _, w, h) in tl) == g.w * g.h       # a partition of the channel
+        assert all(h <= 256 and w <= 256 for (_, _, w, h) in tl)
+    assert tiles[0] == [(0, 0, 8, 5)]                                # most-squeezed average: one global unit
+    big = [i for i, g in enumerate(grids) if g.w > 256 or g.h > 256][0]
+    assert all(len(t) == 1 for t in tiles[:big]) and len(tiles[big]) > 1
+
+
+@pytest.mark.parametrize("case", [
+    dict(kind="squeeze", lossy=False, xyb=False, residual=5),
+    dict(kind="squeeze", lossy=False, xyb=False, residual=6),
+    dict(kind="squeeze", lossy=False, xyb=False, residual=13, pred_offset=3),
+    dict(kind="squeeze", lossy=False, xyb=False, residual=6, i16=False, rct_type=6),
+    dict(kind="squeeze", lossy=False, residual=6),
+    dict(kind="palette", residual=6),
+    dict(kind="palette", residual=4, i16=False),
+])
+@pytest.mark.parametrize("size", [(300, 200), (700, 520), (257, 600), (40, 9)])
+def test_predictor_on_transformed_channels_roundtrip(oracle, case, size):
+    w, h = size
+    wl = ModularWorkload(w, h, seed=3, **case)
+    got = oracle.modular_inverse(wl.desc(), wl.shapes(), wl.dtype)
+    for c in range(3):
+        assert np.array_equal(got[c], wl.expected[c]), f"{case} {size} channel {c}"
