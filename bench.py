@@ -339,12 +339,13 @@ def make_job(config, distinct, transport="grouped"):
 
     return {
         "metric": "Megapixels/sec decoded (8K Modular Squeeze lossy)", "dtype": "int16", "batched": False,
-        "workload": "7680x4320 Modular, lossy Squeeze (22 steps), 16-bit buffers, XYB dequant + EPF iters 2 (sigma_for_modular) + XYB->sRGB (BASELINE config 3)",
+        "workload": "7680x4320 Modular, lossy Squeeze (22 steps) + self-correcting-predictor residuals (single-leaf MA tree) on the 67 carved "
+                    "sub-channels, 16-bit buffers, XYB dequant + EPF iters 2 (sigma_for_modular) + XYB->sRGB (BASELINE config 3)",
         "out_w": W8K, "out_h": H8K,
-        "make": lambda d: ModularWorkload(W8K, H8K, kind="squeeze", lossy=True, i16=True, epf_iters=2, seed=3 + d),
+        "make": lambda d: ModularWorkload(W8K, H8K, kind="squeeze", lossy=True, i16=True, epf_iters=2, seed=3 + d, residual=6),
         "upload": lambda ctx, wl: ctx.modular_upload(wl.desc()),
         "render": render, "groups": (3, 2),
-        "group_names": {3: "modular: inverse Squeeze (segment-parallel kernels)", 2: "post: to_float + EPF + XYB->sRGB"},
+        "group_names": {3: "modular: predict_kernel (per carved sub-channel) + inverse Squeeze (segment-parallel kernels)", 2: "post: to_float + EPF + XYB->sRGB"},
         "alg_bytes": lambda f, g: W8K * H8K * (6 + 12),  # 3 x i16 in + 3 x f32 out per pixel
         "verify": verify, "traffic": lambda d, n: (None, None),
     }

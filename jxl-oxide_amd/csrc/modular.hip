@@ -728,61 +728,38 @@ __global__ __launch_bounds__(256) void palette_kernel(PalArgs g) {
     }
 }
 
-// decode_simple_grad arithmetic (image.rs:821-872) on one group_dim x group_dim tile per
-// workgroup: lane r owns row r and trails row r-1 by one column (wavefront), samples staged in LDS.
-template <typename S>
-__global__ __launch_bounds__(256) void gradient_kernel(void* buf, uint32_t stride, uint32_t width, uint32_t height,
-                                                       uint32_t tile_w, uint32_t tile_h) {
-    S* base = (S*)buf;
-    // into_groups_with_fixed_count (jxl-grid/src/mutable_subgrid.rs:480-515): tiles past the channel are empty
-    const uint32_t x0 = min(blockIdx.x * tile_w, width), y0 = min(blockIdx.y * tile_h, height);
-    const uint32_t gw = min(tile_w, width - x0), gh = min(tile_h, height - y0);
-    if (gw == 0 || gh == 0) return;
-    S* g = base + (size_t)y0 * stride + x0;
-    const uint32_t r = threadIdx.x;  // group_dim <= 256 rows
-    // wavefront: at step s lane r handles column s - r.  Rows of the previous lane are read back
-    // from global memory (L1/L2) after a workgroup barrier.
-    S w = 0;
-    for (uint32_t s = 0; s < gw + gh - 1; ++s) {
-        int32_t x = (int32_t)s - (int32_t)r;
-        if (r < gh && x >= 0 && x < (int32_t)gw) {
-            S* row = g + (size_t)r * stride;
-            S res = row[x];
-            S value;
-            if (r == 0) {
-                value = Wrap<S>::add(res, w);
-            } else {
-                const S* prev = row - stride;
-                if (x == 0) {
-                    value = Wrap<S>::add(res, prev[0]);
-                } else {
-                    int64_t n = prev[x], nw = prev[x - 1], ww = w;
-                    int64_t hi = ww > n ? ww : n, lo = ww > n ? n : ww;
-                    int64_t p = lo + hi - nw;
-                    p = p < lo ? lo : (p > hi ? hi : p);
-                    value = Wrap<S>::add(res, (S)p);
-                }
-            }
-            row[x] = value;
-            w = value;
-        }
-        __syncthreads();
-    }
-}
-
 // ---------------------------------------------------------------- device: M4, any single-leaf predictor
-// decode_single_node_slow / decode_one (jxl-modular/src/image.rs:878-949) for one tile per
-// workgroup: sample = residual * multiplier + offset + predict(neighbours), Wrapping<S>.
-// Lane r owns row r and trails row r-1 by three columns (NEE and the self-correcting predictor's
-// NE error reach two columns ahead in the previous row), one workgroup barrier per step.  The
-// neighbour registers (w, n, nw) and the self-correcting predictor's error registers follow
+// decode_single_node[_slow] / decode_one / decode_simple_grad (jxl-modular/src/image.rs:716-949) for ONE
+// (group, channel) subgrid per workgroup: sample = residual * multiplier + offset + predict(neighbours),
+// Wrapping<S>.  All subgrids of all transformed channels of a frame form ONE launch (a tile list built
+// by the host, largest first): a subgrid is a serial chain, so what fills the GPU is the number of
+// subgrids in flight, not the size of one.
+//
+// Lane r owns row r and trails row r-1 by three columns (NEE and the self-correcting predictor's NE
+// error reach two columns ahead in the previous row); one workgroup barrier per step.  Nothing on the
+// step-to-step critical path touches global memory:
+//   * every lane publishes its finished samples in an LDS ring (16 columns per row); the lanes below
+//     read N / NE / NEE / NN from the rings of rows r-1 and r-2 (the producer is 3 / 6 columns ahead);
+//   * residuals are requested 16 columns ahead — eight loads in flight per lane, rotating through
+//     eight registers of the 8x unrolled step loop — and parked in a second LDS ring;
+//   * results leave with fire-and-forget stores.
+// (The first form of this kernel read the previous rows back from global memory after every barrier:
+//  1.9 us per step, 37 ms for the 67 sub-channels of an 8K Squeeze frame, one launch per channel.)
+// The neighbour registers (w, n, nw) and the self-correcting predictor's error registers follow
 // PredictorState / Properties::record (predictor.rs:540-577) and SelfCorrectingPredictor
 // (predictor.rs:312-441) statement by statement; its two error rows live in LDS and are
 // overwritten in place exactly like the reference's `true_err_row` / `subpred_err_row`.
 constexpr uint32_t kPredMaxTileW = 1024;  // the self-correcting predictor's error rows live in LDS
+constexpr int kRing = 16;                 // columns per row in the LDS rings (power of two, > 6 + look-ahead)
+struct PredTile {
+    void* base;              // first sample of the subgrid
+    uint32_t stride, gw, gh; // elements; gh <= 256
+    uint32_t pad;
+};
 struct PredArgs {
-    void* buf;
-    uint32_t stride, width, height, tile_w, tile_h, predictor;
+    const PredTile* tiles;
+    uint32_t err_w;          // columns of the error rows in dynamic LDS (>= the widest subgrid; 1 when unused)
+    uint32_t predictor;
     int32_t mul, off;
     int32_t wp[11];
 };
@@ -790,26 +767,28 @@ struct PredArgs {
 __device__ __forceinline__ uint32_t div_lookup_dev(uint32_t i) { return i == 0 ? 0u : (1u << 24) / i; }  // predictor.rs:150-160
 
 template <typename S>
-__global__ __launch_bounds__(256) void predict_kernel(PredArgs a) {
-    __shared__ int32_t s_true_err[kPredMaxTileW];
-    __shared__ uint32_t s_sub_err[4][kPredMaxTileW];
-    S* base = (S*)a.buf;
-    // one (group, channel) subgrid per workgroup: into_groups_with_fixed_count, mutable_subgrid.rs:480-515
-    const uint32_t x0 = min(blockIdx.x * a.tile_w, a.width), y0 = min(blockIdx.y * a.tile_h, a.height);
-    const uint32_t gw = min(a.tile_w, a.width - x0), gh = min(a.tile_h, a.height - y0);
-    if (gw == 0 || gh == 0) return;  // workgroup-uniform
-    const uint32_t r = threadIdx.x;
-    S* row = base + (size_t)(y0 + r) * a.stride + x0;
-    const S* prev = row - a.stride;
-    const S* prev2 = prev - a.stride;
-    const bool active = r < gh;
-    const bool sc_on = a.predictor == 6;
-    for (uint32_t i = r; i < kPredMaxTileW; i += 256) {
-        s_true_err[i] = 0;
+__global__ __launch_bounds__(256) void predict_tiles_kernel(PredArgs a) {
+    // the self-correcting predictor's error rows: 5 x err_w words of dynamic LDS (err_w = widest subgrid of the launch)
+    extern __shared__ int32_t s_err[];
+    int32_t* s_true_err = s_err;
+    uint32_t* s_sub_err[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s_sub_err[k][i] = 0;
-    }
+    for (int k = 0; k < 4; ++k) s_sub_err[k] = reinterpret_cast<uint32_t*>(s_err) + (size_t)(k + 1) * a.err_w;
+    __shared__ uint32_t s_div[65];              // DIV_LOOKUP, predictor.rs:150-160 (a table as in the reference: the
+                                                // five divisions per sample were a quarter of the step's instructions)
+    if (threadIdx.x < 65) s_div[threadIdx.x] = div_lookup_dev(threadIdx.x);
+    __shared__ int32_t s_out[256][kRing + 1];   // finished samples, row r, column x & 15 (+1: bank spread)
+    __shared__ int32_t s_in[256][kRing + 1];    // residuals requested ahead
+    const PredTile t = a.tiles[blockIdx.x];
+    const uint32_t gw = t.gw, gh = t.gh;
+    const uint32_t r = threadIdx.x;
+    S* row = (S*)t.base + (size_t)r * t.stride;
+    const bool have_row = r < gh;
+    const bool sc_on = a.predictor == 6;
+    for (uint32_t i = r; i < 5 * a.err_w; i += 256) s_err[i] = 0;
     __syncthreads();
+    const int32_t* prev = s_out[r > 0 ? r - 1 : 0];
+    const int32_t* prev2 = s_out[r > 1 ? r - 2 : 0];
 
     // PredictorState registers
     int32_t w = 0, n = 0, nw = 0, ww1 = 0 /* sample at x-1 */, ww2 = 0 /* sample at x-2 */;
@@ -817,161 +796,177 @@ __global__ __launch_bounds__(256) void predict_kernel(PredArgs a) {
     int32_t te_w = 0, te_nw = 0, te_n = 0, te_ne = 0;
     uint32_t se_nw_ww[4] = {0, 0, 0, 0}, se_n_w[4] = {0, 0, 0, 0}, se_ne[4] = {0, 0, 0, 0};
 
-    const uint32_t steps = gw + 3 * (gh - 1);
-    for (uint32_t s = 0; s < steps; ++s) {
-        const int32_t x = (int32_t)s - 3 * (int32_t)r;
-        if (active && x >= 0 && x < (int32_t)gw) {
-            if (x == 0) {
-                // state at a row start: reset() for row 0, the row-end branch of record() otherwise
-                if (r == 0) {
-                    w = n = nw = 0;
-                } else {
-                    w = n = nw = (int32_t)prev[0];
-                    if (sc_on) {
-                        te_w = 0;
-                        te_n = s_true_err[0];
-                        te_nw = te_n;
+    int32_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // residuals in flight: pf[j] was requested 8 steps ago for column x + 8
+    const int32_t steps = (int32_t)(gw + 3 * (gh - 1));
+    for (int32_t s0 = -16; s0 < steps; s0 += 8) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { se_n_w[i] = s_sub_err[i][0]; se_nw_ww[i] = se_n_w[i]; }
-                        if (gw <= 1) {
-                            te_ne = te_n;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) se_ne[i] = se_n_w[i];
+        for (int j = 0; j < 8; ++j) {
+            const int32_t s = s0 + j;
+            const int32_t x = s - 3 * (int32_t)r;
+            // rows whose lanes are all idle (not within 16 columns of starting, or finished) skip the step
+            const bool busy = have_row && x >= -16 && x < (int32_t)gw;
+            if (__builtin_amdgcn_ballot_w64(busy) != 0) {
+                // ---- residual pipeline: park what arrived, request 16 columns ahead
+                if (busy) {
+                    if (x + 8 >= 0 && x + 8 < (int32_t)gw) s_in[r][(x + 8) & (kRing - 1)] = pf[j];
+                    if (x + 16 >= 0 && x + 16 < (int32_t)gw) pf[j] = (int32_t)row[x + 16];
+                }
+                if (busy && x >= 0) {
+                    if (x == 0) {
+                        // state at a row start: reset() for row 0, the row-end branch of record() otherwise
+                        if (r == 0) {
+                            w = n = nw = 0;
                         } else {
-                            te_ne = s_true_err[1];
+                            w = n = nw = prev[0];
+                            if (sc_on) {
+                                te_w = 0;
+                                te_n = s_true_err[0];
+                                te_nw = te_n;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) se_ne[i] = s_sub_err[i][1];
+                                for (int i = 0; i < 4; ++i) { se_n_w[i] = s_sub_err[i][0]; se_nw_ww[i] = se_n_w[i]; }
+                                if (gw <= 1) {
+                                    te_ne = te_n;
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) se_ne[i] = se_n_w[i];
+                                } else {
+                                    te_ne = s_true_err[1];
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) se_ne[i] = s_sub_err[i][1];
+                                }
+                            }
+                        }
+                    }
+                    // neighbours beyond w / n / nw (predictor.rs:226-273, EDGE = true everywhere)
+                    const bool no_prev = r == 0;
+                    const int32_t ne = (no_prev || x + 1 >= (int32_t)gw) ? n : prev[(x + 1) & (kRing - 1)];
+                    const int32_t nee = (no_prev || x + 2 >= (int32_t)gw) ? ne : prev[(x + 2) & (kRing - 1)];
+                    const int32_t nn = r >= 2 ? prev2[x & (kRing - 1)] : n;
+                    const int32_t ww = x >= 2 ? ww2 : w;
+
+                    int64_t sc_prediction = 0, subpred[4] = {0, 0, 0, 0};
+                    if (sc_on) {
+                        const int64_t tw = te_w, tnw = te_nw, tn = te_n, tne = te_ne;
+                        const int64_t n3 = (int64_t)n * 8, nw3 = (int64_t)nw * 8, ne3 = (int64_t)ne * 8, w3 = (int64_t)w * 8,
+                                      nn3 = (int64_t)nn * 8;
+                        subpred[0] = w3 + ne3 - n3;
+                        subpred[1] = n3 - (((tw + tn + tne) * (int64_t)a.wp[0]) >> 5);
+                        subpred[2] = w3 - (((tw + tn + tnw) * (int64_t)a.wp[1]) >> 5);
+                        subpred[3] = n3 - ((tnw * (int64_t)a.wp[2] + tn * (int64_t)a.wp[3] + tne * (int64_t)a.wp[4] +
+                                            (nn3 - n3) * (int64_t)a.wp[5] + (nw3 - w3) * (int64_t)a.wp[6]) >> 5);
+                        uint32_t weight[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t err_sum = se_nw_ww[i] + se_n_w[i] + se_ne[i];
+                            const uint64_t tt = ((uint64_t)err_sum + 1) >> 5;
+                            const uint32_t shift = tt ? 63u - (uint32_t)__builtin_clzll(tt) : 0u;
+                            weight[i] = 4 + (((uint32_t)a.wp[7 + i] * s_div[(err_sum >> shift) + 1]) >> shift);
+                        }
+                        uint32_t sum_weights = weight[0] + weight[1] + weight[2] + weight[3];
+                        const uint32_t log_weight = 31u - (uint32_t)__builtin_clz(sum_weights >> 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) weight[i] >>= log_weight;
+                        sum_weights = weight[0] + weight[1] + weight[2] + weight[3];
+                        int64_t acc = ((int64_t)sum_weights >> 1) - 1;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc += subpred[i] * (int64_t)weight[i];
+                        int64_t prediction = (acc * (int64_t)s_div[sum_weights]) >> 24;
+                        if (((tn ^ tw) | (tn ^ tnw)) <= 0) {
+                            const int64_t mn = min(min(n3, w3), ne3), mx = max(max(n3, w3), ne3);
+                            prediction = prediction < mn ? mn : (prediction > mx ? mx : prediction);
+                        }
+                        sc_prediction = prediction;
+                    }
+
+                    // Predictor::predict, predictor.rs:79-125
+                    int32_t pred;
+                    {
+                        const int64_t N = n, W = w, NW = nw;
+                        switch (a.predictor) {
+                            case 0: pred = 0; break;
+                            case 1: pred = w; break;
+                            case 2: pred = n; break;
+                            case 3: pred = (int32_t)((W + N) / 2); break;
+                            case 4: {
+                                const int64_t dn = N > NW ? N - NW : NW - N, dw = W > NW ? W - NW : NW - W;
+                                pred = dn < dw ? w : n;
+                                break;
+                            }
+                            case 5: {
+                                const int64_t g = N + W - NW, lo = W < N ? W : N, hi = W > N ? W : N;
+                                pred = (int32_t)(g < lo ? lo : (g > hi ? hi : g));
+                                break;
+                            }
+                            case 6: pred = (int32_t)((sc_prediction + 3) >> 3); break;
+                            case 7: pred = ne; break;
+                            case 8: pred = nw; break;
+                            case 9: pred = ww; break;
+                            case 10: pred = (int32_t)((W + NW) / 2); break;
+                            case 11: pred = (int32_t)((N + NW) / 2); break;
+                            case 12: pred = (int32_t)((N + (int64_t)ne) / 2); break;
+                            default:
+                                pred = (int32_t)((6 * N - 2 * (int64_t)nn + 7 * W + (int64_t)ww + (int64_t)nee + 3 * (int64_t)ne + 8) / 16);
+                                break;
+                        }
+                    }
+                    // decode_one: diff = residual.wrapping_muladd_i32(multiplier, offset); diff.add(prediction)
+                    const S res = (S)s_in[r][x & (kRing - 1)];
+                    const S diff = Wrap<S>::add(Wrap<S>::mul(res, (S)a.mul), (S)a.off);
+                    const S value = Wrap<S>::add(diff, (S)pred);
+                    row[x] = value;
+                    const int32_t sample = (int32_t)value;
+                    s_out[r][x & (kRing - 1)] = sample;
+
+                    if (sc_on) {
+                        // SelfCorrectingPredictor::record, predictor.rs:394-441 (the row-end branch is the
+                        // x == 0 block above, run by the next row's lane)
+                        const int64_t s8 = (int64_t)sample * 8;
+                        const int64_t true_err = sc_prediction - s8;
+                        uint32_t sub_err[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int64_t d = subpred[i] - s8;
+                            sub_err[i] = (uint32_t)(((uint64_t)(d < 0 ? -d : d) + 3) >> 3);
+                        }
+                        s_true_err[x] = (int32_t)true_err;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) s_sub_err[i][x] = sub_err[i];
+                        if (x + 1 < (int32_t)gw) {
+                            te_w = (int32_t)true_err;
+                            te_nw = te_n;
+                            te_n = te_ne;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                se_nw_ww[i] = se_n_w[i];
+                                se_n_w[i] = se_ne[i] + sub_err[i];
+                            }
+                            if (x + 2 >= (int32_t)gw) {
+                                te_ne = te_n;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) se_ne[i] = se_n_w[i];
+                            } else if (r != 0) {
+                                te_ne = s_true_err[x + 2];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) se_ne[i] = s_sub_err[i][x + 2];
+                            }
+                        }
+                    }
+                    // Properties::record, predictor.rs:552-576 (not at a row end)
+                    if (x + 1 < (int32_t)gw) {
+                        ww2 = ww1;
+                        ww1 = sample;
+                        w = sample;
+                        if (r == 0) {
+                            nw = sample;
+                            n = sample;
+                        } else {
+                            nw = n;
+                            n = prev[(x + 1) & (kRing - 1)];
                         }
                     }
                 }
             }
-            // neighbours beyond w / n / nw (predictor.rs:226-273, EDGE = true everywhere)
-            const bool no_prev = r == 0;
-            const int32_t ne = (no_prev || x + 1 >= (int32_t)gw) ? n : (int32_t)prev[x + 1];
-            const int32_t nee = (no_prev || x + 2 >= (int32_t)gw) ? ne : (int32_t)prev[x + 2];
-            const int32_t nn = r >= 2 ? (int32_t)prev2[x] : n;
-            const int32_t ww = x >= 2 ? ww2 : w;
-
-            int64_t sc_prediction = 0, subpred[4] = {0, 0, 0, 0};
-            if (sc_on) {
-                const int64_t tw = te_w, tnw = te_nw, tn = te_n, tne = te_ne;
-                const int64_t n3 = (int64_t)n * 8, nw3 = (int64_t)nw * 8, ne3 = (int64_t)ne * 8, w3 = (int64_t)w * 8,
-                              nn3 = (int64_t)nn * 8;
-                subpred[0] = w3 + ne3 - n3;
-                subpred[1] = n3 - (((tw + tn + tne) * (int64_t)a.wp[0]) >> 5);
-                subpred[2] = w3 - (((tw + tn + tnw) * (int64_t)a.wp[1]) >> 5);
-                subpred[3] = n3 - ((tnw * (int64_t)a.wp[2] + tn * (int64_t)a.wp[3] + tne * (int64_t)a.wp[4] +
-                                    (nn3 - n3) * (int64_t)a.wp[5] + (nw3 - w3) * (int64_t)a.wp[6]) >> 5);
-                uint32_t weight[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t err_sum = se_nw_ww[i] + se_n_w[i] + se_ne[i];
-                    const uint64_t t = ((uint64_t)err_sum + 1) >> 5;
-                    const uint32_t shift = t ? 63u - (uint32_t)__builtin_clzll(t) : 0u;
-                    weight[i] = 4 + (((uint32_t)a.wp[7 + i] * div_lookup_dev((err_sum >> shift) + 1)) >> shift);
-                }
-                uint32_t sum_weights = weight[0] + weight[1] + weight[2] + weight[3];
-                const uint32_t log_weight = 31u - (uint32_t)__builtin_clz(sum_weights >> 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) weight[i] >>= log_weight;
-                sum_weights = weight[0] + weight[1] + weight[2] + weight[3];
-                int64_t acc = ((int64_t)sum_weights >> 1) - 1;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc += subpred[i] * (int64_t)weight[i];
-                int64_t prediction = (acc * (int64_t)div_lookup_dev(sum_weights)) >> 24;
-                if (((tn ^ tw) | (tn ^ tnw)) <= 0) {
-                    const int64_t mn = min(min(n3, w3), ne3), mx = max(max(n3, w3), ne3);
-                    prediction = prediction < mn ? mn : (prediction > mx ? mx : prediction);
-                }
-                sc_prediction = prediction;
-            }
-
-            // Predictor::predict, predictor.rs:79-125
-            int32_t pred;
-            {
-                const int64_t N = n, W = w, NW = nw;
-                switch (a.predictor) {
-                    case 0: pred = 0; break;
-                    case 1: pred = w; break;
-                    case 2: pred = n; break;
-                    case 3: pred = (int32_t)((W + N) / 2); break;
-                    case 4: {
-                        const int64_t dn = N > NW ? N - NW : NW - N, dw = W > NW ? W - NW : NW - W;
-                        pred = dn < dw ? w : n;
-                        break;
-                    }
-                    case 5: {
-                        const int64_t g = N + W - NW, lo = W < N ? W : N, hi = W > N ? W : N;
-                        pred = (int32_t)(g < lo ? lo : (g > hi ? hi : g));
-                        break;
-                    }
-                    case 6: pred = (int32_t)((sc_prediction + 3) >> 3); break;
-                    case 7: pred = ne; break;
-                    case 8: pred = nw; break;
-                    case 9: pred = ww; break;
-                    case 10: pred = (int32_t)((W + NW) / 2); break;
-                    case 11: pred = (int32_t)((N + NW) / 2); break;
-                    case 12: pred = (int32_t)((N + (int64_t)ne) / 2); break;
-                    default:
-                        pred = (int32_t)((6 * N - 2 * (int64_t)nn + 7 * W + (int64_t)ww + (int64_t)nee + 3 * (int64_t)ne + 8) / 16);
-                        break;
-                }
-            }
-            // decode_one: diff = residual.wrapping_muladd_i32(multiplier, offset); diff.add(prediction)
-            const S diff = Wrap<S>::add(Wrap<S>::mul(row[x], (S)a.mul), (S)a.off);
-            const S value = Wrap<S>::add(diff, (S)pred);
-            row[x] = value;
-            const int32_t sample = (int32_t)value;
-
-            if (sc_on) {
-                // SelfCorrectingPredictor::record, predictor.rs:394-441 (the row-end branch is the
-                // x == 0 block above, run by the next row's lane)
-                const int64_t s8 = (int64_t)sample * 8;
-                const int64_t true_err = sc_prediction - s8;
-                uint32_t sub_err[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int64_t d = subpred[i] - s8;
-                    sub_err[i] = (uint32_t)(((uint64_t)(d < 0 ? -d : d) + 3) >> 3);
-                }
-                s_true_err[x] = (int32_t)true_err;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s_sub_err[i][x] = sub_err[i];
-                if (x + 1 < (int32_t)gw) {
-                    te_w = (int32_t)true_err;
-                    te_nw = te_n;
-                    te_n = te_ne;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        se_nw_ww[i] = se_n_w[i];
-                        se_n_w[i] = se_ne[i] + sub_err[i];
-                    }
-                    if (x + 2 >= (int32_t)gw) {
-                        te_ne = te_n;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) se_ne[i] = se_n_w[i];
-                    } else if (r != 0) {
-                        te_ne = s_true_err[x + 2];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) se_ne[i] = s_sub_err[i][x + 2];
-                    }
-                }
-            }
-            // Properties::record, predictor.rs:552-576 (not at a row end)
-            if (x + 1 < (int32_t)gw) {
-                ww2 = ww1;
-                ww1 = sample;
-                w = sample;
-                if (r == 0) {
-                    nw = sample;
-                    n = sample;
-                } else {
-                    nw = n;
-                    n = (int32_t)prev[x + 1];
-                }
-            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
@@ -1284,6 +1279,8 @@ struct ModularState {
     void* chk = nullptr;                      // segment link values of the squeeze step in flight
     size_t chk_bytes = 0;
     int* d_redo = nullptr;                    // lines redone serially (diagnostics)
+    PredTile* pred_tiles = nullptr;           // M4: every (group, channel) subgrid of the frame, longest first
+    uint32_t n_pred_tiles = 0, pred_err_w = 1;
     float* fpix[3] = {};
 };
 
@@ -1501,10 +1498,12 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     // size (:279-284, :300-305).  Every tile starts a fresh PredictorState (decode_single_node, :716-777).
     if (predict) {
         const uint32_t gd = m->desc.group_dim ? m->desc.group_dim : 256;
-        // decode_single_node's dispatch (image.rs:733-777)
-        const bool simple_grad = m->desc.residual_predictor == 5 && m->desc.residual_offset == 0 && m->desc.residual_multiplier == 1;
+        // (decode_single_node's dispatch, image.rs:733-777, sends Gradient with offset 0 / multiplier 1 to
+        //  decode_simple_grad: the same arithmetic as decode_one with Predictor::Gradient, one kernel here)
         bool global_phase = true;
-        for (size_t i = 0; i < l.size(); ++i) {
+        std::vector<PredTile> tiles;
+        uint32_t max_w = 1;
+        for (size_t i = 0; i < l.size() && !m->pred_tiles; ++i) {
             const Grid& g = l[i];
             if (g.w == 0 || g.h == 0) continue;
             uint32_t tw, th, ncols, nrows;
@@ -1525,22 +1524,38 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             }
             if (th > 256 || (m->desc.residual_predictor == 6 && tw > kPredMaxTileW))
                 return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tile larger than 256 rows (or 1024 columns with the self-correcting predictor)");
-            if (nrows > 65535) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "too many group rows");
             uint32_t stride = 0;
-            void* base = ptr(g, 0, &stride);
-            const dim3 grid(ncols, nrows);
-            if (simple_grad) {
-                if (i16) gradient_kernel<int16_t><<<grid, 256, 0, s>>>(base, stride, g.w, g.h, tw, th);
-                else gradient_kernel<int32_t><<<grid, 256, 0, s>>>(base, stride, g.w, g.h, tw, th);
-            } else {
-                PredArgs pa;
-                pa.buf = base; pa.stride = stride; pa.width = g.w; pa.height = g.h;
-                pa.tile_w = tw; pa.tile_h = th; pa.predictor = m->desc.residual_predictor;
-                pa.mul = m->desc.residual_multiplier; pa.off = m->desc.residual_offset;
-                for (int k = 0; k < 11; ++k) pa.wp[k] = m->desc.wp_params[k];
-                if (i16) predict_kernel<int16_t><<<grid, 256, 0, s>>>(pa);
-                else predict_kernel<int32_t><<<grid, 256, 0, s>>>(pa);
-            }
+            char* base = ptr(g, 0, &stride);
+            // into_groups_with_fixed_count (jxl-grid/src/mutable_subgrid.rs:480-515): subgrids past the channel are empty
+            for (uint32_t gy = 0; gy < nrows; ++gy)
+                for (uint32_t gx = 0; gx < ncols; ++gx) {
+                    const uint32_t x0 = std::min(gx * tw, g.w), y0 = std::min(gy * th, g.h);
+                    const uint32_t gw = std::min(tw, g.w - x0), gh = std::min(th, g.h - y0);
+                    if (gw == 0 || gh == 0) continue;
+                    tiles.push_back(PredTile{base + ((size_t)y0 * stride + x0) * esz, stride, gw, gh, 0});
+                    max_w = std::max(max_w, gw);
+                }
+        }
+        if (!m->pred_tiles) {
+            // longest chains first: a subgrid takes gw + 3 gh steps whatever else runs
+            std::stable_sort(tiles.begin(), tiles.end(), [](const PredTile& x, const PredTile& y) {
+                return x.gw + 3 * x.gh > y.gw + 3 * y.gh;
+            });
+            m->n_pred_tiles = (uint32_t)tiles.size();
+            m->pred_err_w = m->desc.residual_predictor == 6 ? max_w : 1;
+            if (int rc = malloc_dev(ctx, f, &m->pred_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(PredTile))) return rc;
+            // blocking copy from the host vector: the list is built once per frame (the geometry never changes)
+            if (!tiles.empty())
+                HIP_TRY(ctx, hipMemcpy(m->pred_tiles, tiles.data(), tiles.size() * sizeof(PredTile), hipMemcpyHostToDevice));
+        }
+        if (m->n_pred_tiles) {
+            PredArgs pa;
+            pa.tiles = m->pred_tiles; pa.err_w = m->pred_err_w; pa.predictor = m->desc.residual_predictor;
+            pa.mul = m->desc.residual_multiplier; pa.off = m->desc.residual_offset;
+            for (int k = 0; k < 11; ++k) pa.wp[k] = m->desc.wp_params[k];
+            const size_t lds = (size_t)5 * m->pred_err_w * 4;
+            if (i16) predict_tiles_kernel<int16_t><<<m->n_pred_tiles, 256, lds, s>>>(pa);
+            else predict_tiles_kernel<int32_t><<<m->n_pred_tiles, 256, lds, s>>>(pa);
         }
     }
 
