@@ -145,6 +145,15 @@ static void tone_map(float rgb[3], const float lum[3], float intensity_target, f
     rgb[2] *= ratio;
 }
 
+/* Hooks for tests/test_oracle_reference_vectors.py: the reference's own unit tests of these three
+ * functions (tf/pq.rs:455-537, convert/tone_map.rs:760-815) are replayed against the restatement. */
+float orc_test_linear_to_pq(float s, float intensity_target) { return linear_to_pq(s, intensity_target); }
+float orc_test_pq_to_linear(float s, float intensity_target) { return pq_to_linear(s, intensity_target); }
+void orc_test_tone_map(float rgb[3], const float lum[3], float intensity_target, float min_nits,
+                       float target_display_luminance) {
+    tone_map(rgb, lum, intensity_target, min_nits, target_display_luminance);
+}
+
 /* fastmath/powf.rs:3-4, :134-144 (data tables) */
 static const float POW2F_NUMER[3] = {1.01749063e1f, 4.88687798e1f, 9.85506591e1f};
 static const float POW2F_DENOM[4] = {2.10242958e-1f, -2.22328856e-2f, -1.94414990e1f, 9.85506633e1f};
