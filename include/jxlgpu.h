@@ -294,6 +294,9 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* frame, uint32_t stages, 
 int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uint32_t n, uint32_t stages);
 /* Copy the result of the frame's last render to `out` (planar f32; host or device memory). */
 int jxlgpu_frame_download_result(jxlgpu_ctx* ctx, jxlgpu_frame* frame, const JxlGpuOut* out);
+/* Size of the result of the frame's last render (jxlgpu_frame_out_size answers for a stage mask; this
+ * answers for what was actually rendered).  JXLGPU_ERR_INVALID_ARG before the first render.           */
+int jxlgpu_frame_result_size(const jxlgpu_frame* frame, uint32_t* width, uint32_t* height);
 /* upload + render(stages) + free in one call: the drop-in for `render_vardct` + filters + colour. */
 int jxlgpu_vardct_render_host(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* desc, uint32_t stages,
                               const JxlGpuOut* out);

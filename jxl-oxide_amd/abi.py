@@ -278,6 +278,7 @@ _SYMBOLS = [
     ("jxlgpu_vardct_render_host", C.c_int, [C.c_void_p, C.POINTER(VardctDesc), C.c_uint32, C.POINTER(Out)]),
     ("jxlgpu_frame_free", None, [C.c_void_p, C.c_void_p]),
     ("jxlgpu_frame_out_size", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("jxlgpu_frame_result_size", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("jxlgpu_frame_result_plane", f32p, [C.c_void_p, C.c_uint32]),
     ("jxlgpu_frame_download_lf", C.c_int, [C.c_void_p, C.c_void_p, f32p * 3]),
     ("jxlgpu_frame_format_output", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(FormatDesc), C.c_void_p, C.c_uint32,

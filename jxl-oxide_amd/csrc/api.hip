@@ -766,6 +766,13 @@ int jxlgpu_frame_out_size(const jxlgpu_frame* f, uint32_t stages, uint32_t* widt
     return JXLGPU_OK;
 }
 
+int jxlgpu_frame_result_size(const jxlgpu_frame* f, uint32_t* width, uint32_t* height) {
+    if (!f || !f->result[0]) return JXLGPU_ERR_INVALID_ARG;
+    if (width) *width = f->result_w;
+    if (height) *height = f->result_h;
+    return JXLGPU_OK;
+}
+
 const float* jxlgpu_frame_result_plane(const jxlgpu_frame* f, uint32_t c) {
     return (f && c < 3) ? f->result[c] : nullptr;
 }

@@ -110,9 +110,12 @@ class Context:
         arr = (C.c_void_p * len(frames))(*[f.handle for f in frames])
         self._check(self.lib.jxlgpu_vardct_render_batch(self.handle, arr, len(frames), stages))
 
-    def download_result(self, frame, stages=abi.STAGE_ALL):
-        """Planar f32 result of the frame's last render."""
-        w, h = frame.out_size(stages)
+    def download_result(self, frame, stages=None):
+        """Planar f32 result of the frame's last render, at the size that render produced (`stages` is
+        accepted for older callers and ignored)."""
+        cw, ch = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.jxlgpu_frame_result_size(frame.handle, C.byref(cw), C.byref(ch)))
+        w, h = cw.value, ch.value
         out = np.zeros((3, h, w), dtype=np.float32)
         o = abi.Out()
         for c in range(3):
