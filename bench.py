@@ -6,10 +6,12 @@
 Default (--config 2, the headline; with the sharding of config 4): a fixed batch of 64 independent
 4K (3840x2160) VarDCT d1 frames (XYB, Gabor + EPF iters 2, XYB->sRGB), sharded by frame across the
 N ranks (shard.frame_shard: 64 / N frames each, no data-path collective).  A "step" = every rank
-renders its frames — the full hot path V1-V8 + F1 + F2 + C1-C3 of SURVEY.md §8(a) — from decoded
-state already resident in HBM to f32 RGB planes in HBM, through jxlgpu_vardct_render_batch (one
-launch per stage for up to 32 frames).  Total work is fixed as N grows: "scaling": "strong".
-`value` = 64 x 8.2944 MP x K / wall time of the K timed steps (max over ranks).
+renders its frames `--passes` (8) times — the full hot path V1-V8 + F1 + F2 + C1-C3 of SURVEY.md
+§8(a) — from decoded state resident in HBM IN THE FORM THE ENTROPY DECODER EMITS IT (per-group
+non-zero coefficient lists, JXLGPU_COEFF_GROUPED: every device pass a decoded frame needs is inside
+the clock; there is no layout pass) to f32 RGB planes in HBM, through jxlgpu_vardct_render_batch
+(one launch per stage for up to 32 frames).  Total work is fixed as N grows: "scaling": "strong".
+`value` = 64 x passes x 8.2944 MP x K / wall time of the K timed steps (max over ranks).
 
 Besides `value`, rank 0 reports in the same JSON line:
   roofline       HBM roofline of the dominant kernel group, HIP events on the library's own stream
@@ -52,7 +54,10 @@ POST_ROWS_PER_SEG, POST_HALO_ROWS = int(os.environ.get("JXLGPU_BATCH_STREAM_ROWS
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--passes", type=int, default=None,
+                    help="passes over the resident batch per step (default 8 for the headline config: a step is then "
+                         "512 frame renders, ~60 ms — long enough for clocks to settle and for a utilisation sampler to see)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5))
     ap.add_argument("--frames", type=int, default=None, help="frames in the whole job (default 64; 8 for configs 3 / 5)")
@@ -95,8 +100,11 @@ def main():
     frames = [job["upload"](ctx, wls[i % args.distinct]) for i in mine]            # own device copy each; untimed
     mp_per_frame = job["out_w"] * job["out_h"] / 1e6
 
+    passes = args.passes if args.passes else (8 if args.config == 2 else 1)
+
     def step():
-        job["render"](ctx, frames)
+        for _ in range(passes):
+            job["render"](ctx, frames)
 
     def barrier():
         ctx.synchronize()
@@ -130,7 +138,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    value = n_total * args.steps * mp_per_frame / elapsed
+    value = n_total * passes * args.steps * mp_per_frame / elapsed
 
     # ---- stitched output (config 4's gather): u8 formatting on the device + one gather, timed apart
     gather_ms = None
@@ -153,7 +161,7 @@ def main():
     if rank == 0:
         f0 = frames[0]
         # a batched step = ceil(frames / 32) launches of the group; prof_n brackets in K steps
-        frames_per_launch = len(frames) * args.steps / max(prof_n, 1) if job["batched"] else 1
+        frames_per_launch = len(frames) * passes * args.steps / max(prof_n, 1) if job["batched"] else 1
         alg_frame = job["alg_bytes"](f0, dominant)
         avg_ms = prof_ms / max(prof_n, 1)
         achieved = alg_frame * frames_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -164,8 +172,9 @@ def main():
             "kernel": job["group_names"][dominant], "avg_launch_ms": round(avg_ms, 4), "launches": int(prof_n),
             "frames_per_launch": round(frames_per_launch, 2),
             "algorithmic_bytes_per_launch": int(alg_frame * frames_per_launch),
-            "group_ms_per_frame": {job["group_names"][g].split(":")[0]: round(group_ms[g] / max(len(frames), 1), 4) for g in group_ms},
-            "pipeline_algorithmic_frac": round(job["alg_bytes"](f0, None) * n_total * args.steps / elapsed / 1e9 / world / HBM_PEAK_GBS, 4),
+            "group_ms_per_frame": {job["group_names"][g].split(":")[0]: round(group_ms[g] / max(len(frames) * passes, 1), 4) for g in group_ms},
+            "pipeline_algorithmic_frac": round(job["alg_bytes"](f0, None) * n_total * passes * args.steps / elapsed / 1e9 / world / HBM_PEAK_GBS, 4),
+            "traffic_ratio": None if not traffic else round(traffic / (alg_frame * frames_per_launch), 3),
         }
         roofline_valu = None
         if args.config == 2 and dominant == 2:
@@ -208,10 +217,11 @@ def main():
             "config": {
                 "workload": job["workload"],
                 "frames_in_job": n_total,
-                "frames_per_gpu_per_step": len(frames),
+                "passes_per_step": passes,
+                "frames_per_gpu_per_step": len(frames) * passes,
                 "distinct_frames": args.distinct,
                 "sharding": "frames across ranks (shard.frame_shard), no data-path collective; one gather of the u8 output (gather_ms)",
-                "input": "decoded state resident in HBM (i32 coefficients in 8x8 cells, LF quant, block map)",
+                "input": job.get("input", "decoded state resident in HBM"),
                 "launches": "jxlgpu_vardct_render_batch: one launch per stage for <= 32 frames" if job["batched"] else "one frame at a time",
             },
             "roofline": roofline,
@@ -219,7 +229,7 @@ def main():
             "verified": verified,
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "value_with_gather": None if gather_ms is None else round(
-                n_total * mp_per_frame / (elapsed / args.steps + gather_ms * 1e-3), 1),
+                n_total * passes * mp_per_frame / (elapsed / args.steps + passes * gather_ms * 1e-3), 1),
             "end_to_end": e2e,
             "cpu_baseline": cpu,
         }
@@ -281,6 +291,12 @@ def make_job(config, distinct, transport="grouped"):
 
         return {
             "metric": "Megapixels/sec decoded (4K VarDCT d1)", "dtype": "f32", "batched": True,
+            "input": {"grouped": "decoded state resident in HBM exactly as the entropy decoder emits it: per pass group the non_zeros counts and "
+                                 "(dx, dy, coeff) triples of write_hf_coeff (4 B per non-zero coefficient), LF quant, block map; the transform "
+                                 "kernels consume the lists directly — NO device-side layout pass (retile / zero-fill + scatter) exists on this path",
+                      "dense_i32": "decoded state resident in HBM with the coefficients already in 8x8 cells: the per-frame retile pass of dense "
+                                   "row-major planes (jxlgpu_vardct_upload) is NOT in the timed region (round-2 form of the bench)",
+                      "sparse_i16": "as dense_i32 (zero-fill + scatter at upload, not timed)"}[transport],
             "workload": f"{W4K}x{H4K} VarDCT d1 XYB, Gabor + EPF iters 2, XYB->sRGB f32 planar (BASELINE config 2 frames, config 4 batch of 64)",
             "out_w": W4K, "out_h": H4K,
             "make": lambda d: VardctWorkload(W4K, H4K, seed=2000 + d),
@@ -392,9 +408,10 @@ def cpu_baseline(config, seconds):
         return None
     return {
         "value": best["MP_per_s"], "unit": "MP/s", "cores": best["cores"], "kind": "port",
+        "MP_per_s_per_core": round(best["MP_per_s"] / max(best["cores"], 1), 3),
         "sample": f"{best['procs']} frames in parallel x {best['threads']} OpenMP threads each, whole frames of the same workload for "
                   f"{best['seconds']} s (oracle/: scalar C restatement of jxl-oxide's generic path, -O3 -march=native; the reference's "
-                  "rayon workers run SSE/AVX2 code on x86, which would be faster still)",
+                  "rayon workers run SSE/AVX2 code on x86, which would be faster still: this is NOT jxl-oxide's rayon speed)",
         "host_threads": ncpu, "splits": table,
     }
 
