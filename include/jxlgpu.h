@@ -282,6 +282,21 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* desc, jxlgpu_f
  * them): passing `out` with it is JXLGPU_ERR_INVALID_ARG.  Frames (after upsampling) taller than
  * 65535 rows are rejected at upload with JXLGPU_ERR_UNSUPPORTED.                                    */
 int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* frame, uint32_t stages, const JxlGpuOut* out);
+/* Region (cropped) render: `RenderContext::request_image_region` / `render_frame_cropped`
+ * (jxl-render/src/lib.rs:232, jxl-oxide-tests/tests/crop/mod.rs:8-222).  `region` is a rectangle of the
+ * frame's OUTPUT (after upsampling), `Region { left, top, width, height }` of jxl-render/src/region.rs:4-10;
+ * it is intersected with the frame.  The result is region.width x region.height samples, bit-identical to
+ * that rectangle of a whole-frame render: the device transforms only the varblocks the padded colour region
+ * touches (the padding rules of jxl-render/src/util.rs:51-120: upsampling support, EPF / Gabor reach) and
+ * runs the filters, upsampling and colour transform on the rectangle.  The LF image (V1-V3) is always
+ * whole: it is 1/64 of the frame.  `stages` must include JXLGPU_STAGE_TRANSFORM.  Noise synthesis
+ * (seeded per absolute group) with a region is JXLGPU_ERR_UNSUPPORTED.                                */
+typedef struct {
+    int32_t left, top;
+    uint32_t width, height;
+} JxlGpuRegion;
+int jxlgpu_vardct_render_region(jxlgpu_ctx* ctx, jxlgpu_frame* frame, uint32_t stages, const JxlGpuRegion* region,
+                                const JxlGpuOut* out);
 /* Batch variant: `n` uploaded frames, one launch per stage for all of them — what the
  * reference's callers do with a parallel loop over keyframes (jxl-oxide-cli/src/decode.rs:293-304).
  * Asynchronous, like a render with out == NULL: after jxlgpu_synchronize the results are on the
@@ -440,6 +455,10 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* desc, jxlgpu
 int jxlgpu_modular_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* frame, void* const* planes_or_null);
 /* Inverse transforms + int->float + filters + upsampling + colour, like jxlgpu_vardct_render.       */
 int jxlgpu_modular_render(jxlgpu_ctx* ctx, jxlgpu_frame* frame, uint32_t stages, const JxlGpuOut* out);
+/* The same for a region of the output (see jxlgpu_vardct_render_region): the inverse transforms are
+ * whole-image (Squeeze has no locality), everything after them runs on the rectangle.               */
+int jxlgpu_modular_render_region(jxlgpu_ctx* ctx, jxlgpu_frame* frame, uint32_t stages, const JxlGpuRegion* region,
+                                 const JxlGpuOut* out);
 
 #ifdef __cplusplus
 }

@@ -202,6 +202,10 @@ class VardctDesc(C.Structure):
     ]
 
 
+class Region(C.Structure):
+    _fields_ = [("left", C.c_int32), ("top", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
 class Out(C.Structure):
     _fields_ = [("planes", f32p * 3), ("stride", C.c_uint32), ("mem", C.c_uint32)]
 
@@ -273,6 +277,7 @@ _SYMBOLS = [
     ("jxlgpu_profile_read", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("jxlgpu_vardct_upload", C.c_int, [C.c_void_p, C.POINTER(VardctDesc), C.POINTER(C.c_void_p)]),
     ("jxlgpu_vardct_render", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Out)]),
+    ("jxlgpu_vardct_render_region", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Region), C.POINTER(Out)]),
     ("jxlgpu_vardct_render_batch", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32]),
     ("jxlgpu_frame_download_result", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Out)]),
     ("jxlgpu_vardct_render_host", C.c_int, [C.c_void_p, C.POINTER(VardctDesc), C.c_uint32, C.POINTER(Out)]),
@@ -287,6 +292,7 @@ _SYMBOLS = [
     ("jxlgpu_modular_upload", C.c_int, [C.c_void_p, C.POINTER(ModularDesc), C.POINTER(C.c_void_p)]),
     ("jxlgpu_modular_inverse", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     ("jxlgpu_modular_render", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Out)]),
+    ("jxlgpu_modular_render_region", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Region), C.POINTER(Out)]),
     ("jxlgpu_blend_rects", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                      C.c_uint32, C.c_uint32, C.POINTER(BlendRect), C.c_uint32]),
 ]

@@ -53,7 +53,7 @@ void ctx_dev_release(jxlgpu_ctx* ctx, void* p) {
 
 hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
                              uint32_t in_tiled_w8, float* const out[3], uint32_t out_stride, bool gabor, int epf_iters,
-                             bool color, jxlgpu_ctx* ctx);
+                             bool color, jxlgpu_ctx* ctx, const PixRect* rc = nullptr);
 bool fused_post_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, bool gabor, int epf_iters);
 hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
                          uint32_t in_tiled_w8, float* const out[3], uint32_t out_stride, bool gabor, int epf_iters,
@@ -809,9 +809,12 @@ int jxlgpu_frame_download_lf(jxlgpu_ctx* ctx, const jxlgpu_frame* f, float* cons
 // `cur` holds W x H samples with stride `*cur_stride`; on return it points at the result.
 // `tiled_in` (VarDCT): the input is the cell-tiled transform output f->pix_t instead of `cur`; the
 // fused post kernels read it as it is, every other consumer gets row-major planes first.
+// `region` (null: everything): the rectangle of the OUTPUT (after upsampling) that is wanted.  The
+// stages are cut to it where the kernels can be (fused filters, upsampling, colour); the planes keep
+// the whole frame's addressing, so the caller finds the result at (region->x0, region->y0).
 int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuFilterParams& fp,
                     uint32_t up_factor, float* cur[3], uint32_t* cur_stride, uint32_t* ow, uint32_t* oh,
-                    bool tiled_in) {
+                    bool tiled_in, const PixRect* region) {
     hipStream_t s = ctx->stream;
     const uint32_t W = f->width, H = f->height;
     const bool do_gab = (stages & JXLGPU_STAGE_GABOR) && fp.gab_enabled;
@@ -820,6 +823,20 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
     const bool do_color = (stages & JXLGPU_STAGE_COLOR) && (f->desc.color.enabled || f->desc.color.ycbcr);
     const bool do_noise = (stages & JXLGPU_STAGE_NOISE) && f->desc.noise.enabled;
     const bool fuse_color = do_color && !do_up && !do_noise;  // noise sits between upsampling and colour
+    if (region && do_noise)
+        return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "noise synthesis with a region (the generator is seeded per absolute group)");
+    // the rectangle of coded samples the output region needs: its own, or with 2x / 4x / 8x upsampling the
+    // samples under it plus the two of the 5x5 kernel's reach (upsampling.rs:45-132; util.rs:60-83)
+    PixRect crect{0, 0, (int)W, (int)H};
+    if (region) {
+        const int k = do_up ? (int)up_factor : 1;
+        auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+        crect = PixRect{fdiv(region->x0, k) - (do_up ? 2 : 0), fdiv(region->y0, k) - (do_up ? 2 : 0),
+                        fdiv(region->x1 + k - 1, k) + (do_up ? 2 : 0), fdiv(region->y1 + k - 1, k) + (do_up ? 2 : 0)};
+        crect.x0 = std::max(crect.x0, 0); crect.y0 = std::max(crect.y0, 0);
+        crect.x1 = std::min(crect.x1, (int)W); crect.y1 = std::min(crect.y1, (int)H);
+    }
+    const PixRect* crp = region ? &crect : nullptr;
 
     // Fast path: everything after the transform in one tile kernel (fused_kernels.hip)
     const bool fused = (do_gab || epf_iters) && fused_post_supported(ctx, f, do_gab, epf_iters);
@@ -834,7 +851,7 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
         const float* in[3] = {tiled_in ? f->pix_t : cur[0], cur[1], cur[2]};
         float** dst = (!tiled_in && cur[0] == f->buf_a[0]) ? f->buf_b : f->buf_a;
         HIP_TRY(ctx, launch_fused_post(s, f, in, *cur_stride, tiled_in ? f->w8 : 0u, dst, f->wr, do_gab, epf_iters,
-                                       fuse_color, ctx));
+                                       fuse_color, ctx, crp));
         for (int c = 0; c < 3; ++c) cur[c] = dst[c];
         *cur_stride = f->wr;
         if (fuse_color) {
@@ -869,13 +886,18 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
         // 2x (BASELINE config 5): one streaming pass for the three planes, colour transform fused
         // when nothing (noise) sits between the two
         const bool fuse = do_color && !do_noise;
+        // output window: the region; for the 2x streaming kernel, the input samples under it
+        PixRect win2{0, 0, (int)W, (int)H};
+        if (region) win2 = PixRect{std::max(region->x0, 0) / 2, std::max(region->y0, 0) / 2,
+                                   std::min((region->x1 + 1) / 2, (int)W), std::min((region->y1 + 1) / 2, (int)H)};
         if (k == 2 && f->have_up2 && !ctx->tune.no_fused &&
-            launch_upsample2_stream(s, cur, *cur_stride, W, H, f->up, W * k, f->up2_wq, fuse ? &f->color : nullptr)) {
+            launch_upsample2_stream(s, cur, *cur_stride, W, H, f->up, W * k, f->up2_wq, fuse ? &f->color : nullptr,
+                                    region ? &win2 : nullptr)) {
             for (int c = 0; c < 3; ++c) cur[c] = f->up[c];
             *ow = W * k; *oh = H * k; *cur_stride = W * k;
             if (fuse) return JXLGPU_OK;
         } else {
-            for (int c = 0; c < 3; ++c) launch_upsample(s, cur[c], *cur_stride, W, H, f->up[c], W * k, k, kern);
+            for (int c = 0; c < 3; ++c) launch_upsample(s, cur[c], *cur_stride, W, H, f->up[c], W * k, k, kern, region);
             for (int c = 0; c < 3; ++c) cur[c] = f->up[c];
             *ow = W * k; *oh = H * k; *cur_stride = W * k;
         }
@@ -906,9 +928,35 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
                      f->noise_corr_x, f->noise_corr_b);
     }
     if (ctx->tune.debug_sync) HIP_TRY(ctx, hipStreamSynchronize(s));
-    if (do_color) launch_color(s, f->color, cur, *cur_stride, *ow, *oh);
+    if (do_color && region) {
+        // in place on the rectangle (whole-frame addressing kept)
+        float* sub[3];
+        for (int c = 0; c < 3; ++c) sub[c] = cur[c] + (size_t)region->y0 * *cur_stride + region->x0;
+        launch_color(s, f->color, sub, *cur_stride, (uint32_t)(region->x1 - region->x0), (uint32_t)(region->y1 - region->y0));
+    } else if (do_color) {
+        launch_color(s, f->color, cur, *cur_stride, *ow, *oh);
+    }
     if (ctx->tune.debug_sync) HIP_TRY(ctx, hipStreamSynchronize(s));
     return JXLGPU_OK;
+}
+
+// Clips a caller's region to the w x h output; false if nothing is left.
+bool clip_region(const JxlGpuRegion* r, uint32_t w, uint32_t h, PixRect* out) {
+    if (!r) return false;
+    const int64_t x0 = std::max<int64_t>(r->left, 0), y0 = std::max<int64_t>(r->top, 0);
+    const int64_t x1 = std::min<int64_t>((int64_t)r->left + r->width, w), y1 = std::min<int64_t>((int64_t)r->top + r->height, h);
+    if (x1 <= x0 || y1 <= y0) return false;
+    *out = PixRect{(int)x0, (int)y0, (int)x1, (int)y1};
+    return true;
+}
+
+int finish_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stride, uint32_t ow, uint32_t oh,
+                  const JxlGpuOut* out);
+// finish_render for a region: the planes keep the whole frame's addressing, the result is the rectangle
+int finish_render_region(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stride, const PixRect& r, const JxlGpuOut* out) {
+    float* sub[3];
+    for (int c = 0; c < 3; ++c) sub[c] = cur[c] + (size_t)r.y0 * stride + r.x0;
+    return finish_render(ctx, f, sub, stride, (uint32_t)(r.x1 - r.x0), (uint32_t)(r.y1 - r.y0), out);
 }
 
 // Host-side copy out of the pinned staging buffer, split over a few threads (one memcpy stream
@@ -1176,6 +1224,7 @@ static void fill_transform_args(jxlgpu_ctx* ctx, const jxlgpu_frame* f, Transfor
     ta.big_tmp = f->big_tmp;
     ta.deq_lut = f->deq_lut;
     ta.nz = f->nz;
+    ta.rect[0] = ta.rect[1] = 0; ta.rect[2] = ta.rect[3] = 65535;
 #ifdef JXL_TR_PROFILE
     ta.prof = ctx->tr_prof;
 #else
@@ -1201,19 +1250,51 @@ int render_subsampled(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const J
         }
     float* cur[3] = {f->pix[0], f->pix[1], f->pix[2]};
     uint32_t stride = f->wr, ow = f->width, oh = f->height;
-    TRY(run_post_stages(ctx, f, stages, f->desc.filter, 1, cur, &stride, &ow, &oh, false));
+    TRY(run_post_stages(ctx, f, stages, f->desc.filter, 1, cur, &stride, &ow, &oh, false, nullptr));
     ctx->prof_end(PROF_POST);
     return finish_render(ctx, f, cur, stride, ow, oh, out);
 }
 
 extern "C" {
 
+static int vardct_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuRegion* region_in,
+                              const JxlGpuOut* out);
+
 int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuOut* out) {
+    return vardct_render_impl(ctx, f, stages, nullptr, out);
+}
+
+int jxlgpu_vardct_render_region(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuRegion* region,
+                                const JxlGpuOut* out) {
+    if (!region) return JXLGPU_ERR_INVALID_ARG;
+    return vardct_render_impl(ctx, f, stages, region, out);
+}
+
+static int vardct_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuRegion* region_in,
+                              const JxlGpuOut* out) {
     if (!ctx || !f || f->kind_of_frame != 0) return JXLGPU_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!f->subs.empty()) return render_subsampled(ctx, f, stages, out);
     hipStream_t s = ctx->stream;
     const JxlGpuVardctDesc& d = f->desc;
+    // ---- region renders: the output rectangle, and from it the cells V4-V8 have to produce
+    PixRect region{0, 0, 0, 0};
+    bool cut = false;   // V4-V8 and the post stages are cut to the region (else: whole frame, cropped at the end)
+    if (region_in) {
+        if (!(stages & JXLGPU_STAGE_TRANSFORM)) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "a region render needs JXLGPU_STAGE_TRANSFORM");
+        uint32_t fw = 0, fh = 0;
+        jxlgpu_frame_out_size(f, stages, &fw, &fh);
+        if (!clip_region(region_in, fw, fh, &region)) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "the region does not intersect the frame");
+        const bool any_filter = ((stages & JXLGPU_STAGE_GABOR) && d.filter.gab_enabled) || ((stages & JXLGPU_STAGE_EPF) && d.filter.epf_iters);
+        // cut when every consumer of the transform output can be: the fused filters, or no filters at all
+        cut = f->subs.empty() && (!any_filter || fused_post_supported(ctx, f, true, 2));
+    }
+    if (!f->subs.empty()) {
+        // chroma-subsampled frames (JPEG transcodes): whole frame, the region is cropped from it
+        if (!region_in) return render_subsampled(ctx, f, stages, out);
+        TRY(render_subsampled(ctx, f, stages, nullptr));
+        float* cur[3] = {const_cast<float*>(f->result[0]), const_cast<float*>(f->result[1]), const_cast<float*>(f->result[2])};
+        return finish_render_region(ctx, f, cur, f->result_stride, region, out);
+    }
 
     // ---- V1-V3
     LfArgs la;
@@ -1233,6 +1314,15 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
     // ---- V4-V8
     TransformArgs ta;
     fill_transform_args(ctx, f, &ta);
+    if (cut) {
+        // coded samples the post stages may read: the colour rectangle of the region (upsampling support
+        // included) + the reach of the cut launches (tiles of 32 + a 7-sample halo, twice for EPF iters 3): 96
+        const int k = ((stages & JXLGPU_STAGE_UPSAMPLE) && d.upsampling.factor > 1) ? (int)d.upsampling.factor : 1;
+        const int pad = 96 + (k > 1 ? 2 : 0);
+        const int x0 = region.x0 / k - pad, y0 = region.y0 / k - pad, x1 = (region.x1 + k - 1) / k + pad, y1 = (region.y1 + k - 1) / k + pad;
+        ta.rect[0] = (uint32_t)(std::max(x0, 0) / 8); ta.rect[1] = (uint32_t)(std::max(y0, 0) / 8);
+        ta.rect[2] = (uint32_t)std::min<int>((x1 + 7) / 8, (int)f->w8); ta.rect[3] = (uint32_t)std::min<int>((y1 + 7) / 8, (int)f->h8);
+    }
     ctx->prof_begin(PROF_TRANSFORM);
     // few, long work items first (64-px, 32-px shapes, the special 8x8 family), the bulk last
     if (f->sparse_tr) {
@@ -1256,8 +1346,10 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, cons
     float* cur[3] = {nullptr, nullptr, nullptr};  // the input of the post stages is the tiled f->pix_t
     uint32_t stride = f->wr, ow = f->width, oh = f->height;
     ctx->prof_begin(PROF_POST);
-    TRY(run_post_stages(ctx, f, stages, d.filter, d.upsampling.factor ? d.upsampling.factor : 1, cur, &stride, &ow, &oh, true));
+    TRY(run_post_stages(ctx, f, stages, d.filter, d.upsampling.factor ? d.upsampling.factor : 1, cur, &stride, &ow, &oh, true,
+                        cut ? &region : nullptr));
     ctx->prof_end(PROF_POST);
+    if (region_in) return finish_render_region(ctx, f, cur, stride, region, out);
     return finish_render(ctx, f, cur, stride, ow, oh, out);
 }
 
@@ -1390,7 +1482,7 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
                 uint32_t stride = f->wr, ow = f->width, oh = f->height;
                 ctx->prof_begin(PROF_POST);
                 TRY(run_post_stages(ctx, f, stages, f->desc.filter, f->desc.upsampling.factor ? f->desc.upsampling.factor : 1,
-                                    cur, &stride, &ow, &oh, true));
+                                    cur, &stride, &ow, &oh, true, nullptr));
                 ctx->prof_end(PROF_POST);
                 TRY(finish_render(ctx, f, cur, stride, ow, oh, nullptr));
             }

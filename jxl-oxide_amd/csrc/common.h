@@ -66,6 +66,8 @@ struct TransformArgs {
     float* big_tmp;            // 6 row-major planes of pstride x (h8*8): working storage of the >=128 path
     const float* deq_lut;      // 256 x quant_bias_numerator / k (k >= 2), or nullptr: divide
     const uint32_t* nz;        // JXLGPU_COEFF_GROUPED: every group's (dx | dy << 8 | coeff << 16) words; `coeff` is null then
+    uint32_t rect[4];          // cells [x0, x1) x [y0, y1) = rect[0..3]: only varblocks touching it are transformed
+                               // (region renders; {0, 0, 65535, 65535} otherwise)
 #ifdef JXL_TR_PROFILE
     unsigned long long* prof;  // tools only (make PROF=1): per-phase s_memtime sums, 4 families x 16 slots
 #endif
@@ -85,6 +87,12 @@ struct SmoothArgs {
     float* out[3];
     uint32_t w8, h8;
     float lf_div[3];           // lf_x, lf_y, lf_b (vardct/mod.rs:420-422)
+};
+
+// Half-open pixel rectangle (region renders: jxlgpu_*_render_region).
+struct PixRect {
+    int x0, y0, x1, y1;
+    bool empty() const { return x1 <= x0 || y1 <= y0; }
 };
 
 struct PlaneSet {
@@ -323,6 +331,9 @@ struct jxlgpu_frame {
     bool batch_pk = false;               // the batched post launch of this frame is the packed kernel
     uint32_t* ring_tiles = nullptr;      // border ring of the streaming post path: tile origins x0 | y0 << 16
     uint32_t n_ring_tiles = 0, n_ring_h = 0;  // the first n_ring_h are 32 x 16 (top / bottom), the rest 16 x 32
+    std::vector<uint32_t> ring_host;     // the same list on the host (region renders launch the tiles they touch)
+    uint32_t* region_tiles[2] = {};      // region renders: tile lists of the launches in flight
+    size_t region_tiles_cap[2] = {};
     float* up_weights[3] = {};  // expanded 5x5 kernels per phase for 2x/4x/8x
     float up2_wq[25] = {};      // host copy of the 2x kernel (kernel argument of the streaming form)
     bool have_up2 = false;
@@ -398,6 +409,6 @@ void launch_color(hipStream_t s, const ColorArgs& c, float* const planes[3], uin
                   uint32_t width, uint32_t height);
 bool launch_upsample2_stream(hipStream_t s, const float* const in[3], uint32_t in_stride, uint32_t w, uint32_t h,
                              float* const out[3], uint32_t out_stride, const float* weights_quarter_host,
-                             const ColorArgs* color);
+                             const ColorArgs* color, const PixRect* window = nullptr);
 void launch_upsample(hipStream_t s, const float* in, uint32_t in_stride, uint32_t w, uint32_t h,
-                     float* out, uint32_t out_stride, int k, const float* kernels);
+                     float* out, uint32_t out_stride, int k, const float* kernels, const PixRect* window = nullptr);

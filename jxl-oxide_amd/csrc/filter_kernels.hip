@@ -81,11 +81,13 @@ void launch_color(hipStream_t s, const ColorArgs& c, float* const planes[3], uin
 template <int K>
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, uint32_t in_stride,
                                                        uint32_t w, uint32_t h, float* __restrict__ out,
-                                                       uint32_t out_stride, const float* __restrict__ kernels) {
+                                                       uint32_t out_stride, const float* __restrict__ kernels,
+                                                       uint32_t ox0, uint32_t oy0, uint32_t ox1, uint32_t oy1) {
     constexpr int MAT_N = K / 2;
-    uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-    uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w * K || y >= h * K) return;
+    // output window [ox0, ox1) x [oy0, oy1) (region renders; the whole w*K x h*K plane otherwise)
+    uint32_t x = ox0 + blockIdx.x * 64 + (threadIdx.x & 63);
+    uint32_t y = oy0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= ox1 || y >= oy1) return;
     int ref_x = x / K, ref_y = y / K;
     int xm = x % K, ym = y % K;
     int mat_x = min(xm, K - xm - 1), mat_y = min(ym, K - ym - 1);
@@ -117,9 +119,13 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
 }
 
 void launch_upsample(hipStream_t s, const float* in, uint32_t in_stride, uint32_t w, uint32_t h,
-                     float* out, uint32_t out_stride, int k, const float* kernels) {
-    dim3 grid(ceil_div(w * k, 64), ceil_div(h * k, 4));
-    if (k == 2) upsample_kernel<2><<<grid, 256, 0, s>>>(in, in_stride, w, h, out, out_stride, kernels);
-    else if (k == 4) upsample_kernel<4><<<grid, 256, 0, s>>>(in, in_stride, w, h, out, out_stride, kernels);
-    else upsample_kernel<8><<<grid, 256, 0, s>>>(in, in_stride, w, h, out, out_stride, kernels);
+                     float* out, uint32_t out_stride, int k, const float* kernels, const PixRect* window) {
+    // `window`: output samples to produce (null: all of them)
+    const uint32_t ox0 = window ? (uint32_t)window->x0 : 0u, oy0 = window ? (uint32_t)window->y0 : 0u;
+    const uint32_t ox1 = window ? (uint32_t)window->x1 : w * k, oy1 = window ? (uint32_t)window->y1 : h * k;
+    if (ox1 <= ox0 || oy1 <= oy0) return;
+    dim3 grid(ceil_div(ox1 - ox0, 64), ceil_div(oy1 - oy0, 4));
+    if (k == 2) upsample_kernel<2><<<grid, 256, 0, s>>>(in, in_stride, w, h, out, out_stride, kernels, ox0, oy0, ox1, oy1);
+    else if (k == 4) upsample_kernel<4><<<grid, 256, 0, s>>>(in, in_stride, w, h, out, out_stride, kernels, ox0, oy0, ox1, oy1);
+    else upsample_kernel<8><<<grid, 256, 0, s>>>(in, in_stride, w, h, out, out_stride, kernels, ox0, oy0, ox1, oy1);
 }

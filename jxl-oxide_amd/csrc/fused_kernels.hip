@@ -561,6 +561,27 @@ bool fused_post_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, bool gab
 // Fills the arguments of the fused post stage of one frame and decides whether the streaming kernel
 // applies (Gabor + 2 EPF steps on a frame with an interior; the ring-tile list is created on first
 // use).  *plain_srgb: the colour tail is the plain XYB -> sRGB list (branch-free epilogue).
+// Region renders: the origins (x0 | y0 << 16) in `tiles` go to scratch slot `slot` of the frame, in
+// stream order (the source is pageable: the runtime stages it before hipMemcpyAsync returns).
+static hipError_t upload_region_tiles(jxlgpu_ctx* ctx, jxlgpu_frame* f, int slot, const std::vector<uint32_t>& tiles,
+                                      const uint32_t** dev) {
+    const size_t n = std::max<size_t>(tiles.size(), 1);
+    if (f->region_tiles_cap[slot] < n) {
+        void* p = nullptr;
+        hipError_t e = ctx_dev_malloc(ctx, &p, n * 2 * 4);
+        if (e != hipSuccess) return e;
+        f->allocs.push_back(p);  // the old one (if any) stays with the frame until it is freed: launches may still read it
+        f->region_tiles[slot] = static_cast<uint32_t*>(p);
+        f->region_tiles_cap[slot] = n * 2;
+    }
+    if (!tiles.empty()) {
+        hipError_t e = hipMemcpyAsync(f->region_tiles[slot], tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return e;
+    }
+    *dev = f->region_tiles[slot];
+    return hipSuccess;
+}
+
 hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
                          uint32_t in_tiled_w8, float* const out[3], uint32_t out_stride, bool gabor, int epf_iters,
                          bool color, FusedArgs* pa, bool* stream_out, bool* plain_srgb, int rows_per_seg) {
@@ -604,6 +625,7 @@ hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in
             f->ring_tiles = static_cast<uint32_t*>(p);
             f->n_ring_tiles = (uint32_t)ring.size();
             f->n_ring_h = n_h;
+            f->ring_host = ring;
         }
     }
     *stream_out = stream;
@@ -637,12 +659,24 @@ hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in
 // Returns a HIP error instead of silently skipping the launch (the caller switches `cur` to `out`
 // only on success).  If the ring-tile list cannot be allocated the whole frame runs through the
 // tile kernel, which needs no list.
+// `rc` (region renders; null = the whole frame): only the output samples of that rectangle are needed.
+// The launches are cut to it — the streaming rectangle to the whole cells it touches, the ring / tile
+// launches to the tiles it touches — so what is written is a superset of `rc` made of the very same
+// values a whole-frame render writes there; the inputs have to be valid 48 samples around `rc`.
 hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
                              uint32_t in_tiled_w8, float* const out[3], uint32_t out_stride, bool gabor, int epf_iters,
-                             bool color, jxlgpu_ctx* ctx) {
+                             bool color, jxlgpu_ctx* ctx, const PixRect* rc) {
     FusedArgs a;
     bool stream = false, plain_srgb = false;
     hipError_t e;
+    // tiles of tw x th at the origins of a regular grid that touch `r`
+    auto grid_tiles = [&](const PixRect& r, int tw, int th) {
+        std::vector<uint32_t> v;
+        for (int y0 = std::max(0, r.y0) / th * th; y0 < std::min((int)f->height, r.y1); y0 += th)
+            for (int x0 = std::max(0, r.x0) / tw * tw; x0 < std::min((int)f->width, r.x1); x0 += tw)
+                v.push_back((uint32_t)x0 | ((uint32_t)y0 << 16));
+        return v;
+    };
     // epf_iters == 3 on a frame the streaming kernels can take: step 0 (+ the Gabor-like stage) through
     // the tile kernel into the frame's spare plane set, then steps 1, 2 (+ colour) through the streaming
     // path — every stage still mirrors its own input at the border.  The all-in-one tile kernel pays
@@ -652,15 +686,56 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
         float* const* tmp = out[0] == f->buf_a[0] ? f->buf_b : f->buf_a;
         e = fused_prepare(ctx, f, in, in_stride, in_tiled_w8, tmp, f->wr, gabor, 4, false, &a, &stream, &plain_srgb, 0);
         if (e != hipSuccess) return e;
-        e = launch_tile_kernel(s, a, gabor, 4, dim3(ceil_div(f->width, T), ceil_div(f->height, T)));
+        if (rc) {
+            // step 0 has to cover what steps 1, 2 read around the launches cut to `rc`: 40 samples around it
+            const PixRect r0{rc->x0 - 40, rc->y0 - 40, rc->x1 + 40, rc->y1 + 40};
+            const std::vector<uint32_t> tl = grid_tiles(r0, T, T);
+            if ((e = upload_region_tiles(ctx, f, 0, tl, &a.tiles)) != hipSuccess) return e;
+            if (!tl.empty()) e = launch_tile_kernel(s, a, gabor, 4, dim3((uint32_t)tl.size()));
+        } else {
+            e = launch_tile_kernel(s, a, gabor, 4, dim3(ceil_div(f->width, T), ceil_div(f->height, T)));
+        }
         if (e != hipSuccess) return e;
         const float* const in2[3] = {tmp[0], tmp[1], tmp[2]};
-        return launch_fused_post(s, f, in2, f->wr, 0u, out, out_stride, false, 2, color, ctx);
+        return launch_fused_post(s, f, in2, f->wr, 0u, out, out_stride, false, 2, color, ctx, rc);
     }
     e = fused_prepare(ctx, f, in, in_stride, in_tiled_w8, out, out_stride, gabor, epf_iters, color, &a, &stream,
                       &plain_srgb, 0);
     if (e != hipSuccess) return e;
-    if (!stream) return launch_tile_kernel(s, a, gabor, epf_iters, dim3(ceil_div(f->width, T), ceil_div(f->height, T)));
+    if (!stream) {
+        if (!rc) return launch_tile_kernel(s, a, gabor, epf_iters, dim3(ceil_div(f->width, T), ceil_div(f->height, T)));
+        const std::vector<uint32_t> tl = grid_tiles(*rc, T, T);
+        if ((e = upload_region_tiles(ctx, f, 1, tl, &a.tiles)) != hipSuccess) return e;
+        return tl.empty() ? hipSuccess : launch_tile_kernel(s, a, gabor, epf_iters, dim3((uint32_t)tl.size()));
+    }
+    std::vector<uint32_t> ring_sel;   // region renders: the ring tiles `rc` touches (horizontal ones first)
+    uint32_t ring_sel_h = 0;
+    const uint32_t* ring_dev = nullptr;
+    if (rc) {
+        // the streaming rectangle cut to the whole cells `rc` touches (it stays a multiple of 8 away from sx0 / sy0)
+        a.sx0 = std::max(a.sx0, rc->x0 / 8 * 8); a.sy0 = std::max(a.sy0, rc->y0 / 8 * 8);
+        a.sx1 = std::min(a.sx1, (rc->x1 + 7) / 8 * 8); a.sy1 = std::min(a.sy1, (rc->y1 + 7) / 8 * 8);
+        if (a.sx1 > a.sx0 && a.sy1 > a.sy0) {
+            const int total = a.sy1 - a.sy0;
+            const int base_rows = ctx ? ctx->tune.stream_rows : 48;
+            const int n = std::max(1, (total + base_rows / 2) / base_rows);
+            a.rows_per_seg = ((total + n - 1) / n + 3) / 4 * 4;
+            a.strips = (a.sx1 - a.sx0 + (a.pk ? PW : SW) - 1) / (a.pk ? PW : SW);
+            a.segs = (total + a.rows_per_seg - 1) / a.rows_per_seg;
+        } else {
+            a.strips = a.segs = 0;
+        }
+        for (uint32_t i = 0; i < (uint32_t)f->ring_host.size(); ++i) {
+            const int x0 = (int)(f->ring_host[i] & 0xffffu), y0 = (int)(f->ring_host[i] >> 16);
+            const int tw = i < f->n_ring_h ? kRingL : kRingT, th = i < f->n_ring_h ? kRingT : kRingL;
+            if (x0 < rc->x1 && x0 + tw > rc->x0 && y0 < rc->y1 && y0 + th > rc->y0) {
+                ring_sel.push_back(f->ring_host[i]);
+                if (i < f->n_ring_h) ++ring_sel_h;
+            }
+        }
+        // ordered on `s` in front of the fork event: the side stream's ring launch sees the list
+        if ((e = upload_region_tiles(ctx, f, 1, ring_sel, &ring_dev)) != hipSuccess) return e;
+    }
     const int waves = a.strips * a.segs;
     const bool side = ctx && ctx->stream2;
     if (side && (e = hipEventRecord(ctx->ev_fork, s)) != hipSuccess) return e;  // inputs are ready here
@@ -675,7 +750,9 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
         if (gabor) post_pk_kernel<TF, TILED, true><<<sgrid, 256, 0, s>>>(a);          \
         else post_pk_kernel<TF, TILED, false><<<sgrid, 256, 0, s>>>(a);               \
     } while (0)
-    if (a.pk && a.in_w8) {
+    if (waves == 0) {
+        // region inside the border ring: no streaming launch
+    } else if (a.pk && a.in_w8) {
         if (plain_srgb) STREAM_PK(JXLGPU_TF_SRGB, true); else STREAM_PK(-1, true);
     } else if (a.pk) {
         if (plain_srgb) STREAM_PK(JXLGPU_TF_SRGB, false); else STREAM_PK(-1, false);
@@ -688,16 +765,24 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
 #undef STREAM_PK
     if ((e = hipGetLastError()) != hipSuccess) return e;
     a.tiles = f->ring_tiles;
+    uint32_t n_ring = f->n_ring_tiles;
+    if (rc) {
+        a.tiles = ring_dev;
+        n_ring = (uint32_t)ring_sel.size();
+        a.n_ring_h = ring_sel_h;
+    }
     // the border ring (a few hundred long-latency tiles) runs beside the streaming kernel
     constexpr size_t ring_lds = 2 * 3 * PostCfg<true, 2, kRingL, kRingT>::PLANE * sizeof(float);
     hipStream_t rs = side ? ctx->stream2 : s;
     if (side && (e = hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0)) != hipSuccess) return e;
-    if (gabor) {
-        if (a.in_w8) post_ring_kernel<true, true><<<f->n_ring_tiles, 256, ring_lds, rs>>>(a);
-        else post_ring_kernel<true, false><<<f->n_ring_tiles, 256, ring_lds, rs>>>(a);
+    if (n_ring == 0) {
+        // region inside the streaming rectangle: no ring launch
+    } else if (gabor) {
+        if (a.in_w8) post_ring_kernel<true, true><<<n_ring, 256, ring_lds, rs>>>(a);
+        else post_ring_kernel<true, false><<<n_ring, 256, ring_lds, rs>>>(a);
     } else {
-        if (a.in_w8) post_ring_kernel<false, true><<<f->n_ring_tiles, 256, ring_lds, rs>>>(a);
-        else post_ring_kernel<false, false><<<f->n_ring_tiles, 256, ring_lds, rs>>>(a);
+        if (a.in_w8) post_ring_kernel<false, true><<<n_ring, 256, ring_lds, rs>>>(a);
+        else post_ring_kernel<false, false><<<n_ring, 256, ring_lds, rs>>>(a);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (side) {

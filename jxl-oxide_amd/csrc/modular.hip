@@ -22,9 +22,12 @@
 
 #include "common.h"
 
+bool clip_region(const JxlGpuRegion* r, uint32_t w, uint32_t h, PixRect* out);
+int finish_render_region(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stride, const PixRect& r, const JxlGpuOut* out);
+bool fused_post_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, bool gabor, int epf_iters);
 int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuFilterParams& fp,
                     uint32_t up_factor, float* cur[3], uint32_t* cur_stride, uint32_t* ow, uint32_t* oh,
-                    bool tiled_in);
+                    bool tiled_in, const PixRect* region);
 int finish_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stride, uint32_t ow, uint32_t oh,
                   const JxlGpuOut* out);
 int upload_post_params(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuUpsampling& up);
@@ -1878,7 +1881,19 @@ int jxlgpu_modular_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f, void* const* planes
     return JXLGPU_OK;
 }
 
+static int modular_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuRegion* region_in, const JxlGpuOut* out);
+
 int jxlgpu_modular_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuOut* out) {
+    return modular_render_impl(ctx, f, stages, nullptr, out);
+}
+
+int jxlgpu_modular_render_region(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuRegion* region,
+                                 const JxlGpuOut* out) {
+    if (!region) return JXLGPU_ERR_INVALID_ARG;
+    return modular_render_impl(ctx, f, stages, region, out);
+}
+
+static int modular_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuRegion* region_in, const JxlGpuOut* out) {
     if (!ctx || !f || f->kind_of_frame != 1) return JXLGPU_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ModularState* m = static_cast<ModularState*>(f->modular);
@@ -1904,10 +1919,20 @@ int jxlgpu_modular_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, con
     float* cur[3] = {m->fpix[0], m->fpix[1], m->fpix[2]};
     uint32_t stride = f->wr, ow = f->width, oh = f->height;
     ctx->prof_begin(PROF_POST);
+    PixRect region{0, 0, 0, 0};
+    bool cut = false;
+    if (region_in) {
+        uint32_t fw = 0, fh = 0;
+        jxlgpu_frame_out_size(f, stages, &fw, &fh);
+        if (!clip_region(region_in, fw, fh, &region)) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "the region does not intersect the frame");
+        const bool any_filter = ((stages & JXLGPU_STAGE_GABOR) && f->desc.filter.gab_enabled) || ((stages & JXLGPU_STAGE_EPF) && f->desc.filter.epf_iters);
+        cut = !any_filter || fused_post_supported(ctx, f, true, 2);  // the staged filters run on whole planes: crop afterwards
+    }
     rc = run_post_stages(ctx, f, stages, f->desc.filter, f->desc.upsampling.factor ? f->desc.upsampling.factor : 1,
-                         cur, &stride, &ow, &oh, false);
+                         cur, &stride, &ow, &oh, false, cut ? &region : nullptr);
     ctx->prof_end(PROF_POST);
     if (rc) return rc;
+    if (region_in) return finish_render_region(ctx, f, cur, stride, region, out);
     return finish_render(ctx, f, cur, stride, ow, oh, out);
 }
 

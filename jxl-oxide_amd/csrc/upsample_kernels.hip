@@ -29,6 +29,7 @@ struct UpStreamArgs {
     ColorArgs color;
     uint32_t do_color;
     int rows_per_seg, strips, segs;
+    int wx0, wy0, wx1, wy1;   // input columns / rows whose 2x2 outputs are produced (the whole plane, or a region's)
 };
 
 __device__ __forceinline__ float lane_m1(float v) {   // value held by lane - 1
@@ -53,11 +54,11 @@ __global__ __launch_bounds__(256) void upsample2_stream_kernel(UpStreamArgs a) {
     const int lane = threadIdx.x & 63;
     const int strip = wave % a.strips, seg = wave / a.strips;
     if (seg >= a.segs) return;
-    const int x = strip * UW - 2 + lane;
+    const int x = a.wx0 + strip * UW - 2 + lane;
     const int xl = mirror_idx(min(max(x, -a.w), 2 * a.w - 1), a.w);
-    const bool store_lane = lane >= 2 && lane < 2 + UW && x < a.w;
+    const bool store_lane = lane >= 2 && lane < 2 + UW && x < a.wx1;
     const uint32_t x_out_off = (uint32_t)(2 * max(x, 0)) * 4u;
-    const int y0 = seg * a.rows_per_seg, y1 = min(y0 + a.rows_per_seg, a.h);
+    const int y0 = a.wy0 + seg * a.rows_per_seg, y1 = min(y0 + a.rows_per_seg, a.wy1);
     UpState st;
 #pragma unroll
     for (int s = 0; s < 5; ++s)
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void upsample2_stream_kernel(UpStreamArgs a) {
 // its own behaviour below 2 samples, kept by the stage-at-a-time kernel).
 bool launch_upsample2_stream(hipStream_t s, const float* const in[3], uint32_t in_stride, uint32_t w, uint32_t h,
                              float* const out[3], uint32_t out_stride, const float* weights_quarter_host,
-                             const ColorArgs* color) {
+                             const ColorArgs* color, const PixRect* window) {
     if (w < 8 || h < 8) return false;
     UpStreamArgs a;
     memset(&a, 0, sizeof(a));
@@ -157,8 +158,11 @@ bool launch_upsample2_stream(hipStream_t s, const float* const in[3], uint32_t i
     memcpy(a.wq, weights_quarter_host, sizeof(a.wq));
     if (color) { a.color = *color; a.do_color = 1; }
     a.rows_per_seg = 64;
-    a.strips = (int)ceil_div(w, UW);
-    a.segs = (int)ceil_div(h, (uint32_t)a.rows_per_seg);
+    a.wx0 = window ? window->x0 : 0; a.wy0 = window ? window->y0 : 0;
+    a.wx1 = window ? window->x1 : (int)w; a.wy1 = window ? window->y1 : (int)h;
+    if (a.wx1 <= a.wx0 || a.wy1 <= a.wy0) return true;
+    a.strips = (int)ceil_div((uint32_t)(a.wx1 - a.wx0), UW);
+    a.segs = (int)ceil_div((uint32_t)(a.wy1 - a.wy0), (uint32_t)a.rows_per_seg);
     const int waves = a.strips * a.segs;
     if (color) upsample2_stream_kernel<true><<<(waves + 3) / 4, 256, 0, s>>>(a);
     else upsample2_stream_kernel<false><<<(waves + 3) / 4, 256, 0, s>>>(a);

@@ -105,6 +105,25 @@ class Context:
         self._check(self.lib.jxlgpu_vardct_render(self.handle, frame.handle, stages, C.byref(o)))
         return out
 
+    def _render_region(self, fn, frame, stages, region):
+        left, top, width, height = region
+        out = np.zeros((3, height, width), dtype=np.float32)
+        o = abi.Out()
+        for c in range(3):
+            o.planes[c] = out[c].ctypes.data_as(abi.f32p)
+        o.stride = width
+        o.mem = abi.MEM_HOST
+        r = abi.Region(left, top, width, height)
+        self._check(fn(self.handle, frame.handle, stages, C.byref(r), C.byref(o)))
+        return out
+
+    def vardct_render_region(self, frame, stages, region):
+        """`region` = (left, top, width, height) of the output, inside the frame -> planes[3][height, width]."""
+        return self._render_region(self.lib.jxlgpu_vardct_render_region, frame, stages, region)
+
+    def modular_render_region(self, frame, stages, region):
+        return self._render_region(self.lib.jxlgpu_modular_render_region, frame, stages, region)
+
     def vardct_render_batch(self, frames, stages):
         """One launch per stage for all `frames` (asynchronous; results stay on the device)."""
         arr = (C.c_void_p * len(frames))(*[f.handle for f in frames])

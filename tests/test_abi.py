@@ -62,7 +62,7 @@ def test_field_offsets_match_the_compiler():
              ("JxlGpuColorParams", abi.ColorParams), ("JxlGpuUpsampling", abi.Upsampling),
              ("JxlGpuNoiseParams", abi.NoiseParams), ("JxlGpuLfGroup", abi.LfGroup), ("JxlGpuHfGroup", abi.HfGroup),
              ("JxlGpuVardctDesc", abi.VardctDesc),
-             ("JxlGpuOut", abi.Out), ("JxlGpuBlendRect", abi.BlendRect), ("JxlGpuSqueezeStep", abi.SqueezeStep),
+             ("JxlGpuOut", abi.Out), ("JxlGpuRegion", abi.Region), ("JxlGpuBlendRect", abi.BlendRect), ("JxlGpuSqueezeStep", abi.SqueezeStep),
              ("JxlGpuTransform", abi.Transform), ("JxlGpuModularChannel", abi.ModularChannel),
              ("JxlGpuModularDesc", abi.ModularDesc)]
     lines, want = [], []
