@@ -23,7 +23,7 @@ Besides `value`, rank 0 reports in the same JSON line:
   gather_ms      the stitched-output step of config 4: u8 interleaved formatting on the device + ONE
                  gather of every rank's frames to rank 0 (RCCL over xGMI for N > 1), timed separately
                  from `value`; `value_with_gather` includes it;
-  end_to_end     upload (sparse i16 coefficient transport) + render + u8 download per frame, PCIe
+  end_to_end     upload (grouped coefficient transport) + render + u8 download per frame, PCIe
                  inclusive (never `value`);
   cpu_baseline   the CPU oracle (C restatement of the reference's generic path, -O3 -march=native,
                  OpenMP inside a frame x frames in parallel) on this box's host cores, bounded sample.
@@ -94,17 +94,49 @@ def main():
     ctx = runtime.Context(local_rank)
 
     n_total = args.frames or (64 if args.config == 2 else 8)
-    mine = list(shard.frame_shard(n_total, rank, world))
     job = make_job(args.config, args.distinct, args.transport)
+    # config 5 at N > 1 (BASELINE: "groups sharded across the GPUs"): every rank holds every frame and renders
+    # its band of output rows of each (jxlgpu_vardct_render_region); everything else shards whole frames
+    band_sharded = args.config == 5 and world > 1
+    mine = list(range(n_total)) if band_sharded else list(shard.frame_shard(n_total, rank, world))
     wls = {d: job["make"](d) for d in sorted({i % args.distinct for i in mine})}  # untimed
     frames = [job["upload"](ctx, wls[i % args.distinct]) for i in mine]            # own device copy each; untimed
     mp_per_frame = job["out_w"] * job["out_h"] / 1e6
 
     passes = args.passes if args.passes else (8 if args.config == 2 else 1)
 
-    def step():
-        for _ in range(passes):
+    # ---- N > 1: the stitched output is part of the job.  Every step's result is formatted on the device and
+    # gathered to rank 0 (RCCL over xGMI) by shard.PipelinedGather: the gather of step k overlaps the kernels of
+    # step k + 1, the host never waits inside the timed region, and `value` INCLUDES it.
+    gather, gather_fmt, band = None, None, None
+    if world > 1 and args.config in (2, 5):
+        if band_sharded:
+            bands = shard.band_rows(job["out_h"], world)
+            band = bands[rank]
+            hb = max(b[1] - b[0] for b in bands)
+            gather_fmt = abi.FMT_U16   # "16-bit" output samples of config 5
+            shape = (n_total, hb, job["out_w"], 3 * 2)   # as bytes: every RCCL build moves uint8
+        else:
+            gather_fmt = abi.FMT_U8
+            shape = (-(-n_total // world), job["out_h"], job["out_w"], 3)
+        gather = shard.PipelinedGather(shape, torch.uint8, "cuda", lib_stream=ctx.stream(), dst=0)
+    gstep = [0]
+
+    def render_only():
+        if band_sharded:
+            for f in frames:
+                ctx.vardct_render_region(f, abi.STAGE_ALL, (0, band[0], job["out_w"], band[1] - band[0]), to_host=False)
+        else:
             job["render"](ctx, frames)
+
+    def step(with_gather=True):
+        for _ in range(passes):
+            render_only()
+            if gather is not None and with_gather and frames:
+                buf = gather.slot(gstep[0])
+                shard.format_frames_into(ctx, frames, gather_fmt, buf)
+                gather.submit(gstep[0])
+                gstep[0] += 1
 
     def barrier():
         ctx.synchronize()
@@ -113,6 +145,17 @@ def main():
             dist.barrier()
 
     # ---- warmup; find the dominant kernel group with event brackets (one batch at a time)
+    gather_error = None
+    if gather is not None:
+        # the first overlapped step runs under a guard: if this torch / RCCL build rejects any piece of the plumbing
+        # (every rank fails at the same call), the job goes on without the gather instead of losing the measurement
+        try:
+            step()
+            barrier()
+        except Exception as e:  # noqa: BLE001
+            gather_error = f"{type(e).__name__}: {e}"[:300]
+            print(f"[bench] rank {rank}: overlapped gather unavailable ({gather_error}); timing the render only", file=sys.stderr)
+            gather = None
     for _ in range(max(args.warmup, 1)):
         step()
     barrier()
@@ -139,10 +182,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = n_total * passes * args.steps * mp_per_frame / elapsed
+    value_render_only = None
+    if gather is not None:
+        # the same K steps without the formatting + gather, for comparison (not the headline at N > 1)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(with_gather=False)
+        barrier()
+        e2 = time.perf_counter() - t0
+        t = torch.tensor([e2], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        value_render_only = n_total * passes * args.steps * mp_per_frame / float(t.item())
 
     # ---- stitched output (config 4's gather): u8 formatting on the device + one gather, timed apart
     gather_ms = None
-    if not args.no_extras and args.config == 2 and frames:
+    if not args.no_extras and args.config == 2 and frames and world == 1:
         shard.gather_formatted_batch(ctx, frames, abi.FMT_U8)  # warm (allocations, RCCL channels)
         barrier()
         reps = 3
@@ -150,12 +205,12 @@ def main():
         for _ in range(reps):
             shard.gather_formatted_batch(ctx, frames, abi.FMT_U8)
         barrier()
-        gather = (time.perf_counter() - t0) / reps
+        gather_s = (time.perf_counter() - t0) / reps
         if world > 1:
-            t = torch.tensor([gather], dtype=torch.float64, device="cuda")
+            t = torch.tensor([gather_s], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            gather = float(t.item())
-        gather_ms = gather * 1e3
+            gather_s = float(t.item())
+        gather_ms = gather_s * 1e3
 
     out = None
     if rank == 0:
@@ -193,8 +248,29 @@ def main():
                                      "and columns are recomputed (%d/%d x %d/%d)" % (
                                          POST_STRIP + 8, POST_STRIP, rows + POST_HALO_ROWS, rows)}
         verified = None
-        if not args.no_verify:
+        if not args.no_verify and not band_sharded:
             verified = job["verify"](ctx, frames, mine, wls, args.distinct)
+        if not args.no_verify and gather is not None:
+            # the stitched output as it arrived on rank 0: one frame that another rank rendered (config 2 / 4), or frame 0
+            # reassembled from every rank's band (config 5), against the oracle's formatted render
+            from oracle import pyoracle
+            got_all = gather.finish(gstep[0] - 1)
+            if band_sharded:
+                wl = wls[0]
+                exp, _ = pyoracle.vardct_render(wl.desc(), abi.STAGE_ALL, job["out_w"], job["out_h"])
+                exp16 = pyoracle.format_output(exp, gather_fmt, 1)
+                ok = True
+                for r, (y0, y1) in enumerate(shard.band_rows(job["out_h"], world)):
+                    ok &= bool(np.array_equal(got_all[r][0, :y1 - y0].cpu().numpy().view(np.uint16), exp16[y0:y1]))
+                gv = {"ok": ok, "what": "frame 0 reassembled on rank 0 from the %d gathered u16 bands == oracle render, formatted" % world}
+            else:
+                other = list(shard.frame_shard(n_total, world - 1, world))[0]
+                wl = wls.get(other % args.distinct) or job["make"](other % args.distinct)
+                exp, _ = pyoracle.vardct_render(wl.desc(), abi.STAGE_ALL, job["out_w"], job["out_h"])
+                ok = bool(np.array_equal(got_all[world - 1][0].cpu().numpy(), pyoracle.format_output(exp, gather_fmt, 1)))
+                gv = {"ok": ok, "what": "first frame of rank %d as gathered on rank 0 (u8) == oracle render, formatted" % (world - 1)}
+            verified = dict(verified or {"ok": True}, gathered=gv)
+            verified["ok"] = bool(verified["ok"] and gv["ok"])
         e2e = None
         if not args.no_extras and args.config == 2:
             e2e = end_to_end(ctx, wls[mine[0] % args.distinct], mp_per_frame)
@@ -211,6 +287,11 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "strong",
+            "value_includes": ("render + device formatting + gather of the stitched output to rank 0 (overlapped: shard.PipelinedGather)"
+                               if gather is not None else "render (N = 1: the output is on the one GPU; formatting timed apart as gather_ms)"),
+            "value_render_only": None if value_render_only is None else round(value_render_only, 1),
+            "gather_error": gather_error,
+            "gathered_GB_per_step": None if gather is None else round(gather.bytes_to_dst / max(gstep[0], 1) * passes / 1e9, 3),
             "vs_baseline": None,
             "dtype": job["dtype"],
             "data": "synthetic",
@@ -220,7 +301,9 @@ def main():
                 "passes_per_step": passes,
                 "frames_per_gpu_per_step": len(frames) * passes,
                 "distinct_frames": args.distinct,
-                "sharding": "frames across ranks (shard.frame_shard), no data-path collective; one gather of the u8 output (gather_ms)",
+                "sharding": ("one frame = N bands of output rows, one per rank (shard.band_rows + jxlgpu_vardct_render_region), u16 bands gathered to rank 0"
+                             if band_sharded else
+                             "frames across ranks (shard.frame_shard), no data-path collective; the u8 output gathered to rank 0"),
                 "input": job.get("input", "decoded state resident in HBM"),
                 "launches": "jxlgpu_vardct_render_batch: one launch per stage for <= 32 frames" if job["batched"] else "one frame at a time",
             },
@@ -368,9 +451,9 @@ def make_job(config, distinct, transport="grouped"):
 
 
 def end_to_end(ctx, wl, mp_per_frame):
-    """PCIe-inclusive: upload (sparse i16 coefficients) + render + u8 interleaved download, per frame."""
+    """PCIe-inclusive: upload (grouped non-zero lists) + render + u8 interleaved download, per frame."""
     from jxl_oxide_amd import abi
-    d = wl.desc(coeff_transport="sparse_i16")
+    d = wl.desc(coeff_transport="grouped")
     best = 1e9
     for _ in range(4):
         t0 = time.perf_counter()
@@ -380,7 +463,7 @@ def end_to_end(ctx, wl, mp_per_frame):
         best = min(best, time.perf_counter() - t0)
         f.free()
     return {"ms_per_frame": round(best * 1e3, 3), "MP_per_s": round(mp_per_frame / best, 1),
-            "what": "jxlgpu_vardct_upload (sparse i16 coefficient lists, 7 MB instead of 99.5 MB) + render + u8 interleaved D2H, one frame at a time, best of 4"}
+            "what": "jxlgpu_vardct_upload (grouped non-zero lists, 4.6 MB instead of 99.5 MB of dense planes; host work-list build included) + render + u8 interleaved D2H, one frame at a time, best of 4"}
 
 
 def cpu_baseline(config, seconds):

@@ -43,6 +43,12 @@ class Frame:
         self.ctx._check(self.ctx.lib.jxlgpu_frame_out_size(self.handle, stages, C.byref(w), C.byref(h)))
         return w.value, h.value
 
+    def result_size(self):
+        """(width, height) of the frame's last render (a region render: the region's)."""
+        w, h = C.c_uint32(), C.c_uint32()
+        self.ctx._check(self.ctx.lib.jxlgpu_frame_result_size(self.handle, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
     def algorithmic_bytes(self, stages):
         return int(self.ctx.lib.jxlgpu_frame_algorithmic_bytes(self.handle, stages))
 
@@ -105,8 +111,12 @@ class Context:
         self._check(self.lib.jxlgpu_vardct_render(self.handle, frame.handle, stages, C.byref(o)))
         return out
 
-    def _render_region(self, fn, frame, stages, region):
+    def _render_region(self, fn, frame, stages, region, to_host=True):
         left, top, width, height = region
+        if not to_host:  # the result stays on the device (jxlgpu_frame_result_plane / jxlgpu_frame_format_output)
+            r = abi.Region(left, top, width, height)
+            self._check(fn(self.handle, frame.handle, stages, C.byref(r), None))
+            return None
         out = np.zeros((3, height, width), dtype=np.float32)
         o = abi.Out()
         for c in range(3):
@@ -117,12 +127,12 @@ class Context:
         self._check(fn(self.handle, frame.handle, stages, C.byref(r), C.byref(o)))
         return out
 
-    def vardct_render_region(self, frame, stages, region):
+    def vardct_render_region(self, frame, stages, region, to_host=True):
         """`region` = (left, top, width, height) of the output, inside the frame -> planes[3][height, width]."""
-        return self._render_region(self.lib.jxlgpu_vardct_render_region, frame, stages, region)
+        return self._render_region(self.lib.jxlgpu_vardct_render_region, frame, stages, region, to_host)
 
-    def modular_render_region(self, frame, stages, region):
-        return self._render_region(self.lib.jxlgpu_modular_render_region, frame, stages, region)
+    def modular_render_region(self, frame, stages, region, to_host=True):
+        return self._render_region(self.lib.jxlgpu_modular_render_region, frame, stages, region, to_host)
 
     def vardct_render_batch(self, frames, stages):
         """One launch per stage for all `frames` (asynchronous; results stay on the device)."""
@@ -164,8 +174,9 @@ class Context:
                                                 new_stride, new_w, new_h, arr, len(rects)))
 
     def format_output(self, frame, sample_format, orientation=1):
-        """Interleaved, oriented f32/u16/u8 image of the last render (formatted on the device)."""
-        w, h = frame.out_size(abi.STAGE_ALL)
+        """Interleaved, oriented f32/u16/u8 image of the last render — a whole frame or a region —
+        formatted on the device."""
+        w, h = frame.result_size()
         ow, oh = (w, h) if orientation <= 4 else (h, w)
         dt = {abi.FMT_F32: np.float32, abi.FMT_U16: np.uint16, abi.FMT_U8: np.uint8}[sample_format]
         out = np.zeros((oh, ow, 3), dtype=dt)

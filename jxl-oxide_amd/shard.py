@@ -40,6 +40,20 @@ def band_plan(height, world, group_dim=256):
     return plan
 
 
+def band_rows(height, world, align=8):
+    """[(y0, y1)] per rank: OUTPUT rows of a frame split into `world` bands of whole `align`-row units
+    (BASELINE config 5: the groups of one frame sharded across the GPUs).  Each rank renders its band
+    with jxlgpu_vardct_render_region: the library transforms the varblocks within reach of the band
+    (<= 98 coded rows beyond it, whatever the band's size) — not the whole 256-row halo group rows that
+    `band_plan` + `slice_vardct_band` (round 2, kept for the CPU tests) recompute."""
+    units = -(-height // align)
+    out = []
+    for r in range(world):
+        u = frame_shard(units, r, world)
+        out.append((min(u.start * align, height), min(u.stop * align, height)))
+    return out
+
+
 def slice_vardct_band(wl, ext_y0, ext_y1):
     """A shallow copy of a synth.VardctWorkload restricted to coded rows [ext_y0, ext_y1)
     (multiples of the group size, except the frame's last row): every per-frame array is cut along
@@ -109,27 +123,132 @@ def gather_formatted(ctx, frame, sample_format, orientation=1, dst=0, group=None
     return gather_planes(local, dst=dst, group=group)
 
 
-def gather_formatted_batch(ctx, frames, sample_format, orientation=1, dst=0, group=None):
-    """Config 4's stitched output: every frame of this rank formatted on the device into ONE tensor
-    (n, h, w, 3), then ONE gather to `dst` (RCCL over xGMI for world > 1; nothing to move for
-    world == 1).  Frames must have the same size.  Returns the list of per-rank tensors on `dst`."""
+def torch_dtype_of(sample_format):
+    import torch
+
+    from . import abi
+    return {abi.FMT_F32: torch.float32, abi.FMT_U16: torch.uint16, abi.FMT_U8: torch.uint8}[sample_format]
+
+
+def format_frames_into(ctx, frames, sample_format, local, orientation=1, first_slot=0):
+    """The last render of every frame (whole frames or regions of the same size), formatted on the device
+    (jxlgpu_frame_format_output) into slots first_slot, first_slot + 1, ... of the (slots, h, w, 3) tensor
+    `local` on this rank's GPU.  Asynchronous on the library's stream."""
     import ctypes as C
 
+    from . import abi
+    fmt = abi.FormatDesc(sample_format, orientation)
+    rw, rh = C.c_uint32(), C.c_uint32()
+    step = local[0].numel() * local.element_size()
+    assert first_slot + len(frames) <= local.shape[0]
+    for i, f in enumerate(frames):
+        ctx._check(ctx.lib.jxlgpu_frame_format_output(ctx.handle, f.handle, C.byref(fmt), local.data_ptr() + (first_slot + i) * step,
+                                                      abi.MEM_DEVICE, C.byref(rw), C.byref(rh)))
+        # a result shorter than the slot (the last band of a frame) fills the slot's first rows
+        assert rw.value == local.shape[2] and rh.value <= local.shape[1], "results must have the slot's width and fit its height"
+        # (the tensor may be a byte view of wider samples: (slots, h, w, 3 * sample_size) uint8)
+
+
+def gather_formatted_batch(ctx, frames, sample_format, orientation=1, dst=0, group=None, slots=None):
+    """Config 4's stitched output: every frame of this rank formatted on the device into ONE tensor
+    (slots, h, w, 3), then ONE gather to `dst` (RCCL over xGMI for world > 1; nothing to move for
+    world == 1).  Frames must have the same size.  `slots`: frames per rank rounded up over the job
+    (ranks own blocks that differ by one frame when the batch does not divide: every rank gathers the
+    same shape, the unused slot stays empty); default: all_reduce(max) of the local counts.  A rank
+    without frames passes `slots` and a frame size through `like`... it cannot know one: the bench
+    gives every rank at least one frame or uses PipelinedGather with an explicit shape.
+    Returns the list of per-rank tensors on `dst` (None elsewhere)."""
     import torch
     import torch.distributed as dist
 
     from . import abi
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    if slots is None:
+        slots = len(frames)
+        if multi:
+            t = torch.tensor([slots], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            slots = int(t.item())
+    if not frames:
+        raise ValueError("gather_formatted_batch: this rank owns no frame (give the gather an explicit shape: PipelinedGather)")
     w, h = frames[0].out_size(abi.STAGE_ALL)
     ow, oh = (w, h) if orientation <= 4 else (h, w)
-    dt = {abi.FMT_F32: torch.float32, abi.FMT_U16: torch.uint16, abi.FMT_U8: torch.uint8}[sample_format]
-    local = torch.empty((len(frames), oh, ow, 3), dtype=dt, device="cuda")
-    fmt = abi.FormatDesc(sample_format, orientation)
-    rw, rh = C.c_uint32(), C.c_uint32()
-    step = local[0].numel() * local.element_size()
-    for i, f in enumerate(frames):
-        ctx._check(ctx.lib.jxlgpu_frame_format_output(ctx.handle, f.handle, C.byref(fmt), local.data_ptr() + i * step,
-                                                      abi.MEM_DEVICE, C.byref(rw), C.byref(rh)))
+    local = torch.zeros((max(slots, len(frames)), oh, ow, 3), dtype=torch_dtype_of(sample_format), device="cuda")
+    format_frames_into(ctx, frames, sample_format, local, orientation)
     ctx.synchronize()
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not multi:
         return [local]
     return gather_planes(local, dst=dst, group=group)
+
+
+class PipelinedGather:
+    """One tensor per step from every rank to `dst`, overlapped with the next step's rendering.
+
+    The library renders and formats on its own HIP stream; RCCL works on its own stream behind torch's
+    current stream.  Per step:  slot(step) -> the local tensor to format into (its previous gather is
+    waited for ON THE LIBRARY'S STREAM, not by the host);  submit(step) -> an event on the library's
+    stream makes torch's stream wait for the formatting, the gather is issued with async_op=True, and
+    an event behind it guards the buffer.  The host never blocks, so step k + 1's kernels run while
+    step k's bytes cross xGMI.  Two buffer sets; finish() drains.  On CPU tensors (gloo, the tests) the
+    same calls run synchronously.  VERDICT r2 item 5a."""
+
+    def __init__(self, shape, dtype, device, lib_stream=None, dst=0, group=None, depth=2, force_collective=False):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.torch = dist, torch
+        self.group, self.dst = group, dst
+        # force_collective: issue the gather even in a one-rank group (exercises the stream / event plumbing on one GPU)
+        self.multi = dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective)
+        self.rank = dist.get_rank(group) if self.multi else 0
+        self.world = dist.get_world_size(group) if self.multi else 1
+        self.depth = depth
+        self.cuda = torch.device(device).type == "cuda"
+        self.local = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
+        self.recv = [None] * depth
+        if self.multi and self.rank == dst:
+            self.recv = [[torch.zeros(shape, dtype=dtype, device=device) for _ in range(self.world)] for _ in range(depth)]
+        self.ext = torch.cuda.ExternalStream(lib_stream) if (self.cuda and lib_stream) else None
+        self.done = [None] * depth   # event behind the gather that last read local[i]
+        self.work = [None] * depth
+        self.bytes_to_dst = 0
+
+    def slot(self, step):
+        i = step % self.depth
+        if self.done[i] is not None and self.ext is not None:
+            self.ext.wait_event(self.done[i])      # the formatting kernels queue behind the gather that read this buffer
+        elif self.work[i] is not None and not self.cuda:
+            self.work[i].wait()
+        return self.local[i]
+
+    def submit(self, step):
+        i = step % self.depth
+        if not self.multi:
+            return
+        torch, dist = self.torch, self.dist
+        if self.ext is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.ext)
+            torch.cuda.current_stream().wait_event(ev)
+        w = dist.gather(self.local[i], self.recv[i] if self.rank == self.dst else None, dst=self.dst, group=self.group,
+                        async_op=True)
+        self.work[i] = w
+        if self.cuda:
+            w.wait()                                # torch's stream (not the host) waits for the collective
+            d = torch.cuda.Event()
+            d.record(torch.cuda.current_stream())
+            self.done[i] = d
+        else:
+            w.wait()
+        if self.rank == self.dst:
+            self.bytes_to_dst += (self.world - 1) * self.local[i].numel() * self.local[i].element_size()
+
+    def finish(self, step=None):
+        """Drains; returns the per-rank tensors of `step` on dst (own slot = local copy), else None."""
+        if self.cuda:
+            self.torch.cuda.synchronize()
+        if step is None or not self.multi:
+            return [self.local[(step or 0) % self.depth]] if step is not None else None
+        i = step % self.depth
+        if self.rank != self.dst:
+            return None
+        return self.recv[i]

@@ -107,6 +107,25 @@ def _worker(rank, world, port, q):
             for r in range(world):
                 for k, i in enumerate(shard.frame_shard(n_frames, r, world)):
                     ok &= bool(np.array_equal(gathered[r][k].numpy(), pyoracle.format_output(render(i), abi.FMT_U8, 1)))
+        # (4) shard.PipelinedGather (the overlapped gather of bench.py at N > 1), here on CPU tensors: three steps,
+        #     two buffer sets, uneven frame blocks (an empty slot on the rank that owns one frame less)
+        pg = shard.PipelinedGather((slots, 40, 72, 3), torch.uint8, "cpu", dst=0)
+        last = None
+        for step in range(3):
+            buf = pg.slot(step)
+            buf.zero_()
+            for k, i in enumerate(sorted(mine_u8)):
+                buf[k] = torch.from_numpy(mine_u8[i]) + step      # a different payload every step
+            pg.submit(step)
+            last = step
+        got = pg.finish(last)
+        if rank == 0:
+            for r in range(world):
+                for k, i in enumerate(shard.frame_shard(n_frames, r, world)):
+                    exp = (pyoracle.format_output(render(i), abi.FMT_U8, 1).astype(np.int32) + last).astype(np.uint8)
+                    ok &= bool(np.array_equal(got[r][k].numpy(), exp))
+        ok &= shard.band_rows(4320, 8)[0] == (0, 544) and shard.band_rows(4320, 8)[-1][1] == 4320
+        ok &= [b for b in shard.band_rows(100, 3)] == [(0, 40), (40, 72), (72, 100)]
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
