@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 13u
+#define JXLGPU_ABI_VERSION 14u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -214,6 +214,17 @@ typedef struct {
      * frames (jpeg_upsampling != 0).                                                             */
     uint32_t num_hf_groups;
     const JxlGpuHfGroup* hf_groups;
+    /* A truncated stream rendered as far as it goes (`allow_partial`, jxl-render/src/vardct/mod.rs:275-305:
+     * a pass group whose decode failed part-way keeps what was decoded): with JXLGPU_COEFF_GROUPED a group
+     * may then list FEWER varblocks than its block map holds — the rest have no HF coefficients.        */
+    uint32_t allow_partial;
+    /* frame_header.flags.use_lf_frame(): the LF image is the blended render of a previously decoded LF
+     * frame (lf_level = 1), used as it is — no LF dequantisation, CfL-LF or adaptive smoothing
+     * (jxl-render/src/vardct/mod.rs:175-179).  Three f32 planes X, Y, B of ceil(width / 8) x ceil(height / 8)
+     * samples, row stride `lf_frame_stride` elements; NULL = decode the LF from lf_quant (V1-V3).  With an LF
+     * frame the lf_quant pointers of the LF groups may be NULL.                                           */
+    const float* lf_frame[3];
+    uint32_t lf_frame_stride;
     uint32_t num_lf_groups;       /* frame_header.num_lf_groups(), raster order                    */
     const JxlGpuLfGroup* lf_groups;
     /* Quantizer / LfChannelDequantization / LfChannelCorrelation (jxl-vardct/src/lf.rs:11-34) */

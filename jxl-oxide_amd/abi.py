@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -178,6 +178,9 @@ class VardctDesc(C.Structure):
         ("sparse_count", C.c_uint64 * 3),
         ("num_hf_groups", C.c_uint32),
         ("hf_groups", C.POINTER(HfGroup)),
+        ("allow_partial", C.c_uint32),
+        ("lf_frame", f32p * 3),
+        ("lf_frame_stride", C.c_uint32),
         ("num_lf_groups", C.c_uint32),
         ("lf_groups", C.POINTER(LfGroup)),
         ("global_scale", C.c_uint32),

@@ -483,6 +483,10 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     if ((uint64_t)f->wr * f->hr * 3 >= (1ull << 30))  // kernels address the tiled planes with 32-bit word offsets
         return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "frame larger than 357 megapixels");
 
+    const bool use_lf_frame = d->lf_frame[0] || d->lf_frame[1] || d->lf_frame[2];
+    if (use_lf_frame && (!d->lf_frame[0] || !d->lf_frame[1] || !d->lf_frame[2] || d->lf_frame_stride < f->w8))
+        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "lf_frame needs three planes with lf_frame_stride >= ceil(width / 8)");
+    f->lf_from_frame = use_lf_frame;
     const size_t ncell = (size_t)f->w8 * f->h8, ntile = (size_t)f->w64 * f->h64;
     const size_t npix = (size_t)f->wr * f->hr;
     const bool i16 = d->lf_sample_type == JXLGPU_SAMPLE_I16;
@@ -516,7 +520,7 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
             lf_scale[(size_t)g * 3 + c] = (float)((double)d->m_lf[c] * (double)precision_scale / (double)scale_inv);
         // util.rs:275-298: lf_x <- channel 1, lf_y <- channel 0, lf_b <- channel 2
         static const int SRC[3] = {1, 0, 2};
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < 3 && !use_lf_frame; ++c) {
             const uint8_t* src = static_cast<const uint8_t*>(lg.lf_quant[SRC[c]]);
             if (!src) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null lf_quant");
             for (uint32_t y = 0; y < bh; ++y)
@@ -581,8 +585,11 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
                         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "missing dequant matrix for a used transform");
                     VbEntry v{make_uint4(x | (y << 16), t, (uint32_t)hf_mul[(size_t)y * f->w8 + x], 0), 0};
                     if (hg) {
-                        if (vb_k >= hg->num_varblocks) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "fewer nz_count entries than varblocks in a group");
-                        const uint16_t* cnt = hg->nz_count + 3 * (size_t)vb_k;  // decode order: Y, X, B
+                        static const uint16_t kNone[3] = {0, 0, 0};
+                        if (vb_k >= hg->num_varblocks && !d->allow_partial)
+                            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "fewer nz_count entries than varblocks in a group");
+                        // allow_partial: the group's decode stopped before this varblock — no HF coefficients
+                        const uint16_t* cnt = vb_k < hg->num_varblocks ? hg->nz_count + 3 * (size_t)vb_k : kNone;  // decode order: Y, X, B
                         const uint32_t max_nz = 63u * bw * bh;                 // hf_coeff.rs:193
                         if (cnt[0] > max_nz || cnt[1] > max_nz || cnt[2] > max_nz)
                             return fail(ctx, JXLGPU_ERR_INVALID_ARG, "non_zeros too large");
@@ -595,7 +602,7 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
                     lists[class_of(t)].push_back(v);
                 }
             if (hg) {
-                if (vb_k != hg->num_varblocks || nz_k != hg->num_nz)
+                if ((vb_k != hg->num_varblocks && !(d->allow_partial && vb_k > hg->num_varblocks)) || nz_k != hg->num_nz)
                     return fail(ctx, JXLGPU_ERR_INVALID_ARG, "HF group lists do not match the block map");
                 nz_total += nz_k;
                 if (nz_total >= (1ull << 32)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "more than 2^32 non-zero coefficients");
@@ -656,6 +663,12 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
         f->lfq[c] = p;
         TRY(dev_alloc(ctx, f, &f->lf_a[c], ncell));
         TRY(dev_alloc(ctx, f, &f->lf[c], ncell));
+        if (use_lf_frame) {
+            // the LF frame's samples ARE the LF image (vardct/mod.rs:175-179): both LF plane sets hold them
+            for (float* dst : {f->lf_a[c], f->lf[c]})
+                HIP_TRY(ctx, hipMemcpy2D(dst, (size_t)f->w8 * 4, d->lf_frame[c], (size_t)d->lf_frame_stride * 4, (size_t)f->w8 * 4,
+                                         f->h8, hipMemcpyHostToDevice));
+        }
         if (o.no_post) continue;
         TRY(dev_alloc(ctx, f, &f->buf_a[c], npix));
         TRY(dev_alloc(ctx, f, &f->buf_b[c], npix));
@@ -748,7 +761,7 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
         if (bad) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "sparse coefficient position outside the frame");
     }
     // pointers inside the descriptor copy are dead from here on
-    for (int c = 0; c < 3; ++c) f->desc.coeff[c] = nullptr;
+    for (int c = 0; c < 3; ++c) f->desc.coeff[c] = f->desc.lf_frame[c] = nullptr;
     f->desc.lf_groups = nullptr;
     f->desc.hf_groups = nullptr;
     memset(f->desc.dequant, 0, sizeof(f->desc.dequant));
@@ -1050,6 +1063,8 @@ int upload_subsampled(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_frame**
         return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "chroma-subsampled frame with non-separable upsampling");
     if (d->coeff_format != JXLGPU_COEFF_DENSE)
         return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "sparse / grouped coefficient transport on a chroma-subsampled frame");
+    if (d->lf_frame[0] || d->lf_frame[1] || d->lf_frame[2])
+        return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "chroma-subsampled frame with an LF frame stays on the CPU path");
     if (d->width == 0 || d->height == 0 || d->width > (1u << 18) || d->height > (1u << 18))
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "bad frame size");
     if (d->height > 65535u) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "output taller than 65535 rows");
@@ -1301,8 +1316,10 @@ static int vardct_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages,
     SmoothArgs sa;
     fill_lf_args(f, &la, &sa);
     ctx->prof_begin(PROF_LF);
-    launch_lf_dequant_cfl(s, la);
-    if (!d.skip_adaptive_lf_smoothing) launch_lf_smooth(s, sa);
+    if (!f->lf_from_frame) {
+        launch_lf_dequant_cfl(s, la);
+        if (!d.skip_adaptive_lf_smoothing) launch_lf_smooth(s, sa);
+    }
     ctx->prof_end(PROF_LF);
     if (!(stages & JXLGPU_STAGE_TRANSFORM)) {
         HIP_TRY(ctx, hipGetLastError());
@@ -1362,7 +1379,7 @@ static int ensure_dev_args(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     const uint32_t upf = d.upsampling.factor ? d.upsampling.factor : 1;
     f->batch_tr_ok = false;
     // V1-V8 of any single-geometry frame made of <= 64-px varblocks can share launches ...
-    if (f->kind_of_frame != 0 || !f->subs.empty() || !f->buf_a[0] || f->list_count[CLS_BIG] || f->nometa_count) {
+    if (f->kind_of_frame != 0 || !f->subs.empty() || !f->buf_a[0] || f->list_count[CLS_BIG] || f->nometa_count || f->lf_from_frame) {
         f->dev_args_ready = true;
         return JXLGPU_OK;
     }

@@ -297,6 +297,7 @@ struct jxlgpu_frame {
     uint32_t* nzc = nullptr;             // per entry: count Y | count X << 16
     uint64_t nz_total = 0;
     bool sparse_tr = false;              // V4-V8 run the list-fed kernels
+    bool lf_from_frame = false;          // the LF image came from an LF frame (descriptor lf_frame): V1-V3 are skipped
     uint32_t class_first[CLS_COUNT] = {};
     uint32_t list_count[CLS_COUNT] = {};
     bool has_no_meta_groups = false;

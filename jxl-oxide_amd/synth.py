@@ -170,7 +170,7 @@ class VardctWorkload:
     def __init__(self, width, height, seed=0, epf_iters=2, gabor=True, tf=abi.TF_SRGB,
                  intensity_target=255.0, upsampling=1, types=None, lf_i16=True,
                  zero_fraction=0.85, skip_lf_smoothing=False, hdr_pq=False, group_dim=256,
-                 color_mode=None, noise=False):
+                 color_mode=None, noise=False, lf_frame=False):
         rng = np.random.default_rng(SEED_BASE + seed)
         self.width, self.height = width, height
         self.group_dim = group_dim
@@ -226,6 +226,16 @@ class VardctWorkload:
         self.lfq = [smooth(180.0, 220.0).astype(lf_dtype),   # Y
                     smooth(60.0, 0.0).astype(lf_dtype),      # X
                     smooth(90.0, 120.0).astype(lf_dtype)]    # B
+
+        # ---- LF frame (frame_header.flags.use_lf_frame): the LF image arrives as f32 XYB samples of an
+        # earlier frame's render — drawn after everything else so that the other planes do not depend on the switch
+        self.lf_frame = None
+        if lf_frame:
+            r2 = np.random.default_rng(SEED_BASE + seed + 7717)
+            self.lf_stride = w8 + 5   # rows of the LF frame's buffer are wider than the image
+            base = np.stack([0.01 * r2.normal(size=(h8, self.lf_stride)), 0.3 + 0.2 * r2.random(size=(h8, self.lf_stride)),
+                             0.3 + 0.2 * r2.random(size=(h8, self.lf_stride))])
+            self.lf_frame = np.ascontiguousarray(base.astype(np.float32))
 
         w64, h64 = -(-width // 64), -(-height // 64)
         self.xfy = rng.integers(-16, 17, size=(h64, w64)).astype(np.int32)
@@ -286,7 +296,7 @@ class VardctWorkload:
         self._keep = []
 
     # ---- descriptor
-    def desc(self, coeff_transport="dense_i32", sparse_split=False):
+    def desc(self, coeff_transport="dense_i32", sparse_split=False, partial=None):
         """`coeff_transport`: "dense_i32" (the reference's framebuffer), "dense_i16", "sparse_i32",
         "sparse_i16" (SURVEY §8f rank 2).  `sparse_split` splits every value over two list entries
         at the same position, as two passes of a progressive frame would (hf_coeff.rs:234 `+=`)."""
@@ -296,13 +306,24 @@ class VardctWorkload:
         d.group_dim = self.group_dim
         d.lf_sample_type = self.lf_sample_type
         keep_c = []
+        if self.lf_frame is not None:
+            for c in range(3):
+                d.lf_frame[c] = self.lf_frame[c].ctypes.data_as(abi.f32p)
+            d.lf_frame_stride = self.lf_stride
+        coeff_planes = self.coeff
+        if partial is not None:
+            # a truncated stream (allow_partial): `partial` = {group index: varblocks decoded before the stream ended}.
+            # Dense transports hold what the decoder wrote: zeros for the varblocks it never reached.
+            d.allow_partial = 1
+            coeff_planes = self.truncated_coeff(partial)
+            keep_c.append(coeff_planes)
         v16 = coeff_transport.endswith("i16")
         d.coeff_sample_type = abi.SAMPLE_I16 if v16 else abi.SAMPLE_I32
         d.coeff_stride = self.wr
         if coeff_transport.startswith("dense"):
             d.coeff_format = abi.COEFF_DENSE
             for c in range(3):
-                plane = self.coeff[c]
+                plane = coeff_planes[c]
                 if v16:
                     assert np.abs(plane).max() < 32768
                     plane = np.ascontiguousarray(plane.astype(np.int16))
@@ -310,14 +331,14 @@ class VardctWorkload:
                 d.coeff[c] = plane.ctypes.data
         elif coeff_transport == "grouped":
             d.coeff_format = abi.COEFF_GROUPED
-            hf_groups, arrays = self.grouped_lists()
+            hf_groups, arrays = self.grouped_lists(partial)
             keep_c += [hf_groups, arrays]
             d.num_hf_groups = len(hf_groups)
             d.hf_groups = C.cast(hf_groups, C.POINTER(abi.HfGroup))
         else:
             d.coeff_format = abi.COEFF_SPARSE
             for c in range(3):
-                flat = self.coeff[c].reshape(-1)
+                flat = coeff_planes[c].reshape(-1)
                 pos = np.flatnonzero(flat).astype(np.uint32)
                 val = flat[pos]
                 if sparse_split:  # second "pass" refines the same positions; order shuffled
@@ -393,7 +414,26 @@ class VardctWorkload:
         self._keep = [groups, keep, keep_c]
         return d
 
-    def grouped_lists(self):
+    def _decode_order(self):
+        gc = self.group_dim // 8
+        groups_x = -(-self.width // self.group_dim)
+        ys, xs = np.nonzero(self.kind <= 26)
+        gid = (ys // gc) * groups_x + xs // gc
+        order = np.lexsort((xs, ys, gid))          # group, then raster inside the group
+        return ys[order], xs[order], gid[order]
+
+    def truncated_coeff(self, partial):
+        """The dense planes a decoder leaves when group g's stream ends after partial[g] varblocks."""
+        ys, xs, gid = self._decode_order()
+        out = self.coeff.copy()
+        for g, keep in partial.items():
+            idx = np.flatnonzero(gid == g)[keep:]
+            for i in idx:
+                bw, bh = DCT_SELECT_SIZE[int(self.kind[ys[i], xs[i]])]
+                out[:, ys[i] * 8:(ys[i] + bh) * 8, xs[i] * 8:(xs[i] + bw) * 8] = 0
+        return out
+
+    def grouped_lists(self, partial=None):
         """JXLGPU_COEFF_GROUPED: per 256x256 pass group, the `non_zeros` counts and the
         (dx, dy, coeff) triples in the order `write_hf_coeff` decodes them (hf_coeff.rs:97-254):
         Data cells of the group in raster order, channels Y, X, B.  The order of the triples inside
@@ -436,9 +476,13 @@ class VardctWorkload:
         nz_first = np.concatenate([[0], np.cumsum(counts.sum(axis=1))])[vb_first]
         hf = (abi.HfGroup * n_groups)()
         u16p, u32p = C.POINTER(C.c_uint16), C.POINTER(C.c_uint32)
+        nz_cum = np.concatenate([[0], np.cumsum(counts.sum(axis=1))])
         for g in range(n_groups):
             hf[g].num_varblocks = int(vb_first[g + 1] - vb_first[g])
             hf[g].num_nz = int(nz_first[g + 1] - nz_first[g])
+            if partial and g in partial:   # the group's stream ended after this many varblocks
+                hf[g].num_varblocks = min(hf[g].num_varblocks, int(partial[g]))
+                hf[g].num_nz = int(nz_cum[vb_first[g] + hf[g].num_varblocks] - nz_first[g])
             hf[g].nz_count = C.cast(counts16.ctypes.data + 6 * int(vb_first[g]), u16p)
             hf[g].nz = C.cast(words.ctypes.data + 4 * int(nz_first[g]), u32p)
         return hf, (counts16, words)

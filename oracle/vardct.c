@@ -387,6 +387,14 @@ void orc_vardct_lf(const JxlGpuVardctDesc* d, float* const lf[3]) {
     size_t w8 = (d->width + 7) / 8, h8 = (d->height + 7) / 8;
     size_t lf_dim = (size_t)d->group_dim * 8;
     size_t per_row = (d->width + lf_dim - 1) / lf_dim;
+    if (d->lf_frame[0]) {
+        /* vardct/mod.rs:175-179: `lf_frame` given -> the blended LF frame IS lf_xyb; CfL-LF and the
+         * adaptive smoothing belong to the other branch of that `if` */
+        for (int c = 0; c < 3; ++c)
+            for (size_t y = 0; y < h8; ++y)
+                memcpy(lf[c] + y * w8, d->lf_frame[c] + y * d->lf_frame_stride, sizeof(float) * w8);
+        return;
+    }
     for (uint32_t g = 0; g < d->num_lf_groups; ++g) {
         const JxlGpuLfGroup* lg = &d->lf_groups[g];
         size_t gx = g % per_row, gy = g / per_row;

@@ -157,3 +157,56 @@ def test_negative_quant_bias_takes_the_dense_kernels(gpu_ctx, oracle):
         _same(gpu_ctx.vardct_render(f, S_TR), exp, "negative quant_bias")
     finally:
         f.free()
+
+
+@pytest.mark.parametrize("transport", ["grouped", "dense_i32", "sparse_i16"])
+def test_truncated_stream_allow_partial(gpu_ctx, oracle, transport):
+    """`allow_partial` (jxl-render/src/vardct/mod.rs:275-305): the stream of some pass groups ends early; what was
+    decoded stays, the varblocks never reached have no HF coefficients and are still dequantised + transformed with
+    their LF.  Grouped lists then hold fewer varblocks than the block map; without the flag that is an error."""
+    from jxl_oxide_amd.runtime import JxlGpuError
+    wl = VardctWorkload(700, 520, seed=21, zero_fraction=0.5)   # 3 x 3 pass groups
+    partial = {1: 0, 4: 37, 8: 5, 5: 10 ** 6}                   # nothing / part / part / everything decoded
+    exp, _ = oracle.vardct_render(wl.desc(partial=partial), S_ALL, wl.width, wl.height)
+    full, _ = oracle.vardct_render(wl.desc(), S_ALL, wl.width, wl.height)
+    assert not np.array_equal(exp, full)
+    f = gpu_ctx.vardct_upload(wl.desc(coeff_transport=transport, partial=partial))
+    try:
+        _same(gpu_ctx.vardct_render(f, S_ALL), exp, f"partial, {transport}")
+    finally:
+        f.free()
+    if transport == "grouped":
+        d = wl.desc(coeff_transport="grouped", partial=partial)
+        d.allow_partial = 0
+        with pytest.raises(JxlGpuError) as e:
+            gpu_ctx.vardct_upload(d)
+        assert e.value.code == abi.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("transport", ["grouped", "dense_i32"])
+@pytest.mark.parametrize("size", [(264, 200), (2100, 300)])
+def test_lf_frame_replaces_the_lf_stages(gpu_ctx, oracle, transport, size):
+    """frame_header.flags.use_lf_frame (vardct/mod.rs:175-179): the LF image is handed over as f32 XYB planes; V1-V3
+    do not run (the lf_quant pointers may be NULL), everything downstream reads those planes."""
+    w, h = size
+    wl = VardctWorkload(w, h, seed=31, lf_frame=True)
+    d0 = wl.desc()
+    exp, exp_lf = oracle.vardct_render(d0, S_ALL, w, h, want_lf=True, w8=wl.w8, h8=wl.h8)
+    assert np.array_equal(exp_lf, wl.lf_frame[:, :, :wl.w8])
+    d = wl.desc(coeff_transport=transport)
+    for g in range(d.num_lf_groups):
+        for c in range(3):
+            d.lf_groups[g].lf_quant[c] = None
+    f = gpu_ctx.vardct_upload(d)
+    try:
+        _same(gpu_ctx.vardct_render(f, S_ALL), exp, f"lf_frame {transport}")
+        _same(gpu_ctx.download_lf(f, wl.w8, wl.h8), exp_lf, "LF image == the LF frame")
+        # batched entry point and region render on the same frame
+        gpu_ctx.vardct_render_batch([f], S_ALL)
+        gpu_ctx.synchronize()
+        _same(gpu_ctx.download_result(f), exp, "lf_frame, batch entry point")
+        reg = (40, 24, min(160, w - 40), min(120, h - 24))
+        got = gpu_ctx.vardct_render_region(f, S_ALL, reg)
+        _same(got, np.ascontiguousarray(exp[:, reg[1]:reg[1] + reg[3], reg[0]:reg[0] + reg[2]]), "lf_frame, region")
+    finally:
+        f.free()

@@ -193,3 +193,35 @@ def test_upsampling_matches_independent_numpy(oracle, k):
     oracle.lib().orc_upsample_inner(const.ctypes.data_as(f32p), 7, 7, 6, out2.ctypes.data_as(f32p), 7 * k, k,
                                     weights.ctypes.data_as(f32p))
     assert np.allclose(out2, 0.625, atol=1e-6)
+
+
+def test_lf_frame_equals_own_lf_fed_back(oracle):
+    """vardct/mod.rs:175-179: with an LF frame the LF image is taken as it is.  Feeding the oracle's own V1-V3 output
+    back as the LF frame must reproduce the ordinary render bit for bit (V4-V8 and the filters read nothing else of
+    the LF path), and a different LF frame must change it."""
+    from jxl_oxide_amd import abi
+    from jxl_oxide_amd.synth import VardctWorkload
+    wl = VardctWorkload(300, 264, seed=4)
+    ref, lf = oracle.vardct_render(wl.desc(), abi.STAGE_ALL, 300, 264, want_lf=True, w8=wl.w8, h8=wl.h8)
+    wl2 = VardctWorkload(300, 264, seed=4, lf_frame=True)
+    assert np.array_equal(wl2.coeff, wl.coeff) and np.array_equal(wl2.kind, wl.kind)
+    other, _ = oracle.vardct_render(wl2.desc(), abi.STAGE_ALL, 300, 264)
+    assert not np.array_equal(other, ref)
+    wl2.lf_frame = np.ascontiguousarray(np.pad(lf, ((0, 0), (0, 0), (0, wl2.lf_stride - wl.w8))))
+    got, lf2 = oracle.vardct_render(wl2.desc(), abi.STAGE_ALL, 300, 264, want_lf=True, w8=wl.w8, h8=wl.h8)
+    assert np.array_equal(lf2.view(np.uint32), lf.view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_truncated_groups_keep_their_lf(oracle):
+    """allow_partial: a group whose stream ended before its first varblock renders as its LF alone (zero HF):
+    untouched groups are bit-identical to the full render at least 3 varblock rows away from the truncated one
+    (EPF / Gabor reach), the truncated group differs."""
+    from jxl_oxide_amd import abi
+    from jxl_oxide_amd.synth import VardctWorkload
+    wl = VardctWorkload(768, 256, seed=9, zero_fraction=0.4)
+    S = abi.STAGE_LF | abi.STAGE_TRANSFORM
+    full, _ = oracle.vardct_render(wl.desc(), S, 768, 256)
+    part, _ = oracle.vardct_render(wl.desc(partial={1: 0}), S, 768, 256)
+    assert np.array_equal(full[:, :, :256], part[:, :, :256]) and np.array_equal(full[:, :, 512:], part[:, :, 512:])
+    assert not np.array_equal(full[:, :, 256:512], part[:, :, 256:512])
