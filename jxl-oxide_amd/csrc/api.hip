@@ -326,6 +326,8 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
         if (r >= 8 && r <= 4096) ctx->tune.sqz_seg = r;
     }
     if (const char* v = getenv("JXLGPU_SQZ_RUNIN")) ctx->tune.sqz_runin = (uint32_t)atoi(v);
+    if (const char* v = getenv("JXLGPU_UP2_VARIANT")) ctx->tune.up2_variant = atoi(v);
+    if (const char* v = getenv("JXLGPU_UP2_ROWS")) ctx->tune.up2_rows = atoi(v);
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
@@ -905,7 +907,7 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
                                    std::min((region->x1 + 1) / 2, (int)W), std::min((region->y1 + 1) / 2, (int)H)};
         if (k == 2 && f->have_up2 && !ctx->tune.no_fused &&
             launch_upsample2_stream(s, cur, *cur_stride, W, H, f->up, W * k, f->up2_wq, fuse ? &f->color : nullptr,
-                                    region ? &win2 : nullptr)) {
+                                    region ? &win2 : nullptr, ctx->num_cus, ctx->tune.up2_variant, ctx->tune.up2_rows)) {
             for (int c = 0; c < 3; ++c) cur[c] = f->up[c];
             *ow = W * k; *oh = H * k; *cur_stride = W * k;
             if (fuse) return JXLGPU_OK;

@@ -210,6 +210,8 @@ struct Tuning {
                                  // for the 8-, 16-, 32- and 64-px launch (0: one workgroup per item, no run-ahead)
     int sqz_seg = 64;            // JXLGPU_SQZ_SEG: pairs per inverse-Squeeze segment
     uint32_t sqz_runin = 1;      // JXLGPU_SQZ_RUNIN: 0 forces the Squeeze fix-up path (tests)
+    int up2_variant = 0;         // JXLGPU_UP2_VARIANT: 1 = register-ring form of the 2x upsampling kernel (0: LDS ring)
+    int up2_rows = 0;            // JXLGPU_UP2_ROWS: rows per wave segment of that kernel (0: one resident round)
 };
 
 struct jxlgpu_ctx {
@@ -410,6 +412,6 @@ void launch_color(hipStream_t s, const ColorArgs& c, float* const planes[3], uin
                   uint32_t width, uint32_t height);
 bool launch_upsample2_stream(hipStream_t s, const float* const in[3], uint32_t in_stride, uint32_t w, uint32_t h,
                              float* const out[3], uint32_t out_stride, const float* weights_quarter_host,
-                             const ColorArgs* color, const PixRect* window = nullptr);
+                             const ColorArgs* color, const PixRect* window, uint32_t num_cus, int variant, int rows);
 void launch_upsample(hipStream_t s, const float* in, uint32_t in_stride, uint32_t w, uint32_t h,
                      float* out, uint32_t out_stride, int k, const float* kernels, const PixRect* window = nullptr);

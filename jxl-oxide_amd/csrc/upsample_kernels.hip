@@ -141,14 +141,134 @@ __global__ __launch_bounds__(256) void upsample2_stream_kernel(UpStreamArgs a) {
     }
 }
 
+// ---- LDS-ring form (the default).  The register ring above holds 75 window samples + 30 cached extrema
+// per lane (183 VGPRs: two waves per SIMD), and a dependent VALU instruction of one wave issues only every
+// ~6th slot on gfx950 (tools/pk_probe.hip), so two resident waves of mostly serial arithmetic (25-term sums,
+// IEEE division / square-root expansions of the colour transform) leave the SIMD idle more than half of the
+// time.  Here the five window rows live in a wave-private LDS ring (row-major, one sample per lane + two
+// pad samples per side; the x-2..x+2 neighbours are plain LDS reads at lane offsets: no DPP, no 5x
+// replication), a lane keeps only the 25 samples of the channel it is summing, and the kernel fits four to
+// five waves per SIMD.  The four phase sums of a sample run as two packed chains: phase xm = 1 uses the
+// horizontally flipped kernel, so (w[iy][ix], w[iy][4 - ix]) * (s, s) accumulates (xm = 0, xm = 1) with one
+// v_pk_mul_f32 + one v_pk_add_f32 per tap — the reference's mul-then-add, each rounded once, per half.
+typedef float uf2 __attribute__((ext_vector_type(2)));
+constexpr int RING_STRIDE = 68;  // floats per (slot, channel) row: 2 pad + 64 lanes + 2 pad
+
+template <bool COLOR, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void upsample2_lds_kernel(UpStreamArgs a) {
+    __shared__ float ring_all[4][5][3][RING_STRIDE];
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave = blockIdx.x * 4 + wib;
+    const int lane = threadIdx.x & 63;
+    const int strip = wave % a.strips, seg = wave / a.strips;
+    if (seg >= a.segs) return;
+    float* const ring = &ring_all[wib][0][0][0];
+    const int x = a.wx0 + strip * UW - 2 + lane;
+    const int xl = mirror_idx(min(max(x, -a.w), 2 * a.w - 1), a.w);
+    const bool store_lane = lane >= 2 && lane < 2 + UW && x < a.wx1;
+    const uint32_t x_out_off = (uint32_t)(2 * max(x, 0)) * 4u;
+    const int y0 = a.wy0 + seg * a.rows_per_seg, y1 = min(y0 + a.rows_per_seg, a.wy1);
+    // weight pairs (xm = 0, xm = 1), uniform: 64-bit scalar register pairs with two different halves
+    uf2 wp[5][5];
+#pragma unroll
+    for (int iy = 0; iy < 5; ++iy)
+#pragma unroll
+        for (int ix = 0; ix < 5; ++ix) {
+            wp[iy][ix] = uf2{a.wq[iy * 5 + ix], a.wq[iy * 5 + 4 - ix]};
+            asm volatile("" : "+s"(wp[iy][ix]));
+        }
+    int slot = 0;   // ring slot that receives row j (wave-uniform)
+#pragma unroll 1
+    for (int j = y0 - 2; j < y1 + 2; ++j) {
+        const int jm = mirror_idx(j, a.h);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            ring[(slot * 3 + c) * RING_STRIDE + 2 + lane] = (a.in[c] + (size_t)(uint32_t)jm * a.in_stride)[xl];
+        // the ring is private to the wave and LDS operations of one wave execute in order: compiler fences only
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int newest = slot;
+        slot = slot == 4 ? 0 : slot + 1;   // now the oldest row's slot (window row iy = 0) == next row's target
+        const int r = j - 2;
+        if (r < y0) continue;  // wave-uniform
+        float o[2][2][3];      // [ym][xm][c]
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float V[5][5];
+            int sl = newest;
+#pragma unroll
+            for (int iy = 4; iy >= 0; --iy) {   // window row iy = input row r - 2 + iy; the newest slot holds iy = 4
+                const float* row = ring + (sl * 3 + c) * RING_STRIDE + lane;
+#pragma unroll
+                for (int ix = 0; ix < 5; ++ix) V[iy][ix] = row[ix];
+                sl = sl == 0 ? 4 : sl - 1;
+            }
+            float mn, mx;
+            {
+                float rmn[5], rmx[5];
+#pragma unroll
+                for (int iy = 0; iy < 5; ++iy) {
+                    rmn[iy] = fminf(fminf(fminf(V[iy][0], V[iy][1]), fminf(V[iy][2], V[iy][3])), V[iy][4]);
+                    rmx[iy] = fmaxf(fmaxf(fmaxf(V[iy][0], V[iy][1]), fmaxf(V[iy][2], V[iy][3])), V[iy][4]);
+                }
+                mn = rmn[0]; mx = rmx[0];
+#pragma unroll
+                for (int iy = 1; iy < 5; ++iy) { mn = fminf(mn, rmn[iy]); mx = fmaxf(mx, rmx[iy]); }
+            }
+            uf2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};   // output rows ym = 0, 1 (flip_v: kernel rows reversed)
+#pragma unroll
+            for (int iy = 0; iy < 5; ++iy)
+#pragma unroll
+                for (int ix = 0; ix < 5; ++ix) {
+                    const uf2 sv = {V[iy][ix], V[iy][ix]};
+                    acc0 = acc0 + wp[iy][ix] * sv;
+                    acc1 = acc1 + wp[4 - iy][ix] * sv;
+                }
+            const bool bad = !isfinite(mn);
+            const float nanv = __builtin_nanf("");
+#pragma unroll
+            for (int ym = 0; ym < 2; ++ym)
+#pragma unroll
+                for (int xm = 0; xm < 2; ++xm) {
+                    float v = ym ? (xm ? acc1.y : acc1.x) : (xm ? acc0.y : acc0.x);
+                    v = v < mn ? mn : v;
+                    v = v > mx ? mx : v;
+                    o[ym][xm][c] = bad ? nanv : v;
+                }
+        }
+#pragma unroll 1
+        for (int ym = 0; ym < 2; ++ym) {
+            float p0[3], p1[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { p0[c] = ym ? o[1][0][c] : o[0][0][c]; p1[c] = ym ? o[1][1][c] : o[0][1][c]; }
+            if constexpr (COLOR) {
+                color_pixel(a.color, p0);
+                color_pixel(a.color, p1);
+            }
+            if (store_lane) {
+                const size_t orow = (size_t)(uint32_t)(2 * r + ym) * a.out_stride;  // uniform
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(a.out[c] + orow) + x_out_off);
+                    *reinterpret_cast<float2*>(p) = make_float2(p0[c], p1[c]);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // 2x upsampling of three planes (+ the colour transform when `color` is non-null) in one launch.
 // Returns false when the streaming form does not apply (tiny frames: the reference's padding has
 // its own behaviour below 2 samples, kept by the stage-at-a-time kernel).
+// `variant`: 0 = LDS-ring kernel, 1 = register-ring kernel; `rows`: rows per wave segment, 0 = sized so that the
+// launch is ONE resident round of the chip (every wave of this kernel runs equally long: a second, nearly empty
+// round would double the launch time — 64-row segments of a 4K input were 2176 waves on 2048 slots).
 bool launch_upsample2_stream(hipStream_t s, const float* const in[3], uint32_t in_stride, uint32_t w, uint32_t h,
                              float* const out[3], uint32_t out_stride, const float* weights_quarter_host,
-                             const ColorArgs* color, const PixRect* window) {
+                             const ColorArgs* color, const PixRect* window, uint32_t num_cus, int variant, int rows) {
     if (w < 8 || h < 8) return false;
     UpStreamArgs a;
     memset(&a, 0, sizeof(a));
@@ -157,14 +277,27 @@ bool launch_upsample2_stream(hipStream_t s, const float* const in[3], uint32_t i
     a.w = (int)w; a.h = (int)h;
     memcpy(a.wq, weights_quarter_host, sizeof(a.wq));
     if (color) { a.color = *color; a.do_color = 1; }
-    a.rows_per_seg = 64;
     a.wx0 = window ? window->x0 : 0; a.wy0 = window ? window->y0 : 0;
     a.wx1 = window ? window->x1 : (int)w; a.wy1 = window ? window->y1 : (int)h;
     if (a.wx1 <= a.wx0 || a.wy1 <= a.wy0) return true;
     a.strips = (int)ceil_div((uint32_t)(a.wx1 - a.wx0), UW);
-    a.segs = (int)ceil_div((uint32_t)(a.wy1 - a.wy0), (uint32_t)a.rows_per_seg);
+    const uint32_t nrows = (uint32_t)(a.wy1 - a.wy0);
+    const uint32_t waves_per_simd = variant == 1 ? 2u : (color ? 4u : 5u);
+    if (rows <= 0) {
+        const uint32_t slots = num_cus * 4u * waves_per_simd;
+        const uint32_t segs_fit = std::max(1u, slots / (uint32_t)a.strips);   // segments per strip that stay resident together
+        rows = (int)std::max(16u, ceil_div(nrows, segs_fit));                // (a 4-row run-in per segment: not below 16)
+    }
+    a.rows_per_seg = rows;
+    a.segs = (int)ceil_div(nrows, (uint32_t)a.rows_per_seg);
     const int waves = a.strips * a.segs;
-    if (color) upsample2_stream_kernel<true><<<(waves + 3) / 4, 256, 0, s>>>(a);
-    else upsample2_stream_kernel<false><<<(waves + 3) / 4, 256, 0, s>>>(a);
+    const dim3 grid((waves + 3) / 4);
+    if (variant == 1) {
+        if (color) upsample2_stream_kernel<true><<<grid, 256, 0, s>>>(a);
+        else upsample2_stream_kernel<false><<<grid, 256, 0, s>>>(a);
+    } else {
+        if (color) upsample2_lds_kernel<true, 4><<<grid, 256, 0, s>>>(a);
+        else upsample2_lds_kernel<false, 5><<<grid, 256, 0, s>>>(a);
+    }
     return true;
 }
