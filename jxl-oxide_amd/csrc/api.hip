@@ -326,6 +326,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
         if (r >= 8 && r <= 4096) ctx->tune.sqz_seg = r;
     }
     if (const char* v = getenv("JXLGPU_SQZ_RUNIN")) ctx->tune.sqz_runin = (uint32_t)atoi(v);
+    ctx->tune.pred_wg = getenv("JXLGPU_PRED_WG") != nullptr;
     if (const char* v = getenv("JXLGPU_UP2_VARIANT")) ctx->tune.up2_variant = atoi(v);
     if (const char* v = getenv("JXLGPU_UP2_ROWS")) ctx->tune.up2_rows = atoi(v);
     if (hipSetDevice(device) != hipSuccess ||

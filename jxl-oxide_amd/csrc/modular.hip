@@ -753,11 +753,12 @@ __global__ __launch_bounds__(256) void palette_kernel(PalArgs g) {
 // (predictor.rs:312-441) statement by statement; its two error rows live in LDS and are
 // overwritten in place exactly like the reference's `true_err_row` / `subpred_err_row`.
 constexpr uint32_t kPredMaxTileW = 1024;  // the self-correcting predictor's error rows live in LDS
+constexpr uint32_t kPredLaneMaxW = 512;   // widest subgrid of the lane-packed kernel (row r - 2 is 2 D <= 16 ring columns ahead)
 constexpr int kRing = 16;                 // columns per row in the LDS rings (power of two, > 6 + look-ahead)
 struct PredTile {
     void* base;              // first sample of the subgrid
     uint32_t stride, gw, gh; // elements; gh <= 256
-    uint32_t pad;
+    uint32_t packed;         // 1: handled by the lane-packed kernel (P lanes of a wave), 0: a workgroup of its own
 };
 struct PredArgs {
     const PredTile* tiles;
@@ -969,6 +970,237 @@ __global__ __launch_bounds__(256) void predict_tiles_kernel(PredArgs a) {
                 }
             }
             __syncthreads();
+        }
+    }
+}
+
+// ---- lane-packed form (the default for subgrids up to 512 columns).  In the kernel above a subgrid owns a
+// whole 256-thread workgroup and only gw / 3 of its rows are inside the subgrid at any step: 11 lanes for the
+// 32 x 64 tiles of a deep Squeeze level, 43 for a 128-column one — and every wave that holds one of them issues
+// the full step (measured on the 67 sub-channels of an 8K Squeeze frame: 1.4 us per step, the VALU time of the
+// 2.3 waves that are partly active, 4.8 ms per frame).  Here a subgrid gets P = pow2ceil(gw) / 4 lanes (1..64)
+// of ONE wave and row r + 1 trails row r by D = pow2ceil(gw) / P >= 4 columns: a lane that finishes row r has
+// exactly reached the start step of row r + P, so it walks rows k, k + P, k + 2P, ... back to back (its stream
+// position u = step - D k splits into round u >> log2(DP) and column u & (DP - 1)), every lane is busy from its
+// first row to its last, a wave carries 64 / P subgrids, and there is no workgroup barrier: the rings belong to
+// the wave, whose LDS operations execute in order.  Same registers, same statements per sample as above
+// (predictor.rs:26-442, image.rs:716-949); only the schedule differs, and any number of rows is taken.
+struct PredWave {
+    uint32_t first, count;    // tiles[first .. first + count): the subgrids of this wave, P lanes each
+    uint32_t log2p, log2dp;   // P lanes per subgrid; DP = D * P columns per round (>= every gw of the wave)
+    uint32_t steps, pad[3];   // max over the wave's subgrids of gw + D (gh - 1)
+};
+
+template <typename S>
+__global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const PredWave* waves) {
+    extern __shared__ int32_t s_err[];          // 5 x err_w words: true_err, sub_err[4]; a subgrid's columns start at slot * (err_w * P / 64)
+    __shared__ uint32_t s_div[65];
+    __shared__ int32_t s_out[64][kRing + 1];    // finished samples of the lane's current / previous rows, stream position & 15
+    __shared__ int32_t s_in[64][kRing + 1];     // residuals requested ahead, stream position & 15
+    const PredWave wv = waves[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t log2p = wv.log2p, log2dp = wv.log2dp, P = 1u << log2p, DPm1 = (1u << log2dp) - 1u;
+    const int32_t D = (int32_t)(1u << (log2dp - log2p));
+    const uint32_t slot = lane >> log2p, k = lane & (P - 1);
+    const bool have_tile = slot < wv.count;
+    PredTile t = a.tiles[wv.first + (have_tile ? slot : 0)];
+    const uint32_t gw = have_tile ? t.gw : 0, gh = have_tile ? t.gh : 0;
+    const uint32_t ecol = slot * ((a.err_w << log2p) >> 6);   // this subgrid's first column in the error rows
+    int32_t* s_true_err = s_err + ecol;
+    uint32_t* s_sub_err[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_sub_err[i] = reinterpret_cast<uint32_t*>(s_err) + (size_t)(i + 1) * a.err_w + ecol;
+    for (uint32_t i = lane; i < 5 * a.err_w; i += 64) s_err[i] = 0;
+    s_div[lane] = div_lookup_dev(lane);
+    if (lane == 0) s_div[64] = div_lookup_dev(64);
+    __syncthreads();
+    const bool sc_on = a.predictor == 6;
+    // rows r - 1 and r - 2 live in the rings of lanes k - 1 and k - 2 (mod P), one round back where the index wrapped
+    const uint32_t lane0 = lane & ~(P - 1);
+    uint32_t wrap1 = 0, wrap2 = 0;
+    int32_t q1 = (int32_t)k - 1, q2 = (int32_t)k - 2;
+    while (q1 < 0) { q1 += (int32_t)P; ++wrap1; }
+    while (q2 < 0) { q2 += (int32_t)P; ++wrap2; }
+    const int32_t* prev = s_out[lane0 + (uint32_t)q1];
+    const int32_t* prev2 = s_out[lane0 + (uint32_t)q2];
+
+    int32_t w = 0, n = 0, nw = 0, ww1 = 0, ww2 = 0;
+    int32_t te_w = 0, te_nw = 0, te_n = 0, te_ne = 0;
+    uint32_t se_nw_ww[4] = {0, 0, 0, 0}, se_n_w[4] = {0, 0, 0, 0}, se_ne[4] = {0, 0, 0, 0};
+    int32_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int32_t steps = (int32_t)wv.steps;
+    const int32_t u0 = -D * (int32_t)k;
+    // the element at stream position q: round q >> log2dp, column q & (DP - 1); inside the subgrid?
+    auto where = [&](int32_t q, uint32_t* r, uint32_t* x) -> bool {
+        *r = k + (((uint32_t)q >> log2dp) << log2p);
+        *x = (uint32_t)q & DPm1;
+        return q >= 0 && *r < gh && *x < gw;
+    };
+    for (int32_t s0 = -16; s0 < steps; s0 += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int32_t u = u0 + s0 + j;
+            {   // residual pipeline: park what arrived for position u + 8, request position u + 16
+                uint32_t rq, xq;
+                if (where(u + 8, &rq, &xq)) s_in[lane][(u + 8) & (kRing - 1)] = pf[j];
+                if (where(u + 16, &rq, &xq)) pf[j] = (int32_t)((const S*)t.base)[(size_t)rq * t.stride + xq];
+            }
+            uint32_t r, ux;
+            if (where(u, &r, &ux)) {
+                const int32_t x = (int32_t)ux;
+                const uint32_t round = (uint32_t)u >> log2dp;
+                // ring positions of column 0 of rows r, r - 1, r - 2 (stream position of their lane & 15)
+                const uint32_t ob = (round << log2dp) & (kRing - 1);
+                const uint32_t pb1 = ((round - wrap1) << log2dp) & (kRing - 1), pb2 = ((round - wrap2) << log2dp) & (kRing - 1);
+                if (x == 0) {
+                    if (r == 0) {
+                        w = n = nw = 0;
+                    } else {
+                        w = n = nw = prev[pb1];
+                        if (sc_on) {
+                            te_w = 0;
+                            te_n = s_true_err[0];
+                            te_nw = te_n;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { se_n_w[i] = s_sub_err[i][0]; se_nw_ww[i] = se_n_w[i]; }
+                            if (gw <= 1) {
+                                te_ne = te_n;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) se_ne[i] = se_n_w[i];
+                            } else {
+                                te_ne = s_true_err[1];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) se_ne[i] = s_sub_err[i][1];
+                            }
+                        }
+                    }
+                }
+                const bool no_prev = r == 0;
+                const int32_t ne = (no_prev || x + 1 >= (int32_t)gw) ? n : prev[(pb1 + x + 1) & (kRing - 1)];
+                const int32_t nee = (no_prev || x + 2 >= (int32_t)gw) ? ne : prev[(pb1 + x + 2) & (kRing - 1)];
+                const int32_t nn = r >= 2 ? prev2[(pb2 + x) & (kRing - 1)] : n;
+                const int32_t ww = x >= 2 ? ww2 : w;
+
+                int64_t sc_prediction = 0, subpred[4] = {0, 0, 0, 0};
+                if (sc_on) {
+                    const int64_t tw = te_w, tnw = te_nw, tn = te_n, tne = te_ne;
+                    const int64_t n3 = (int64_t)n * 8, nw3 = (int64_t)nw * 8, ne3 = (int64_t)ne * 8, w3 = (int64_t)w * 8,
+                                  nn3 = (int64_t)nn * 8;
+                    subpred[0] = w3 + ne3 - n3;
+                    subpred[1] = n3 - (((tw + tn + tne) * (int64_t)a.wp[0]) >> 5);
+                    subpred[2] = w3 - (((tw + tn + tnw) * (int64_t)a.wp[1]) >> 5);
+                    subpred[3] = n3 - ((tnw * (int64_t)a.wp[2] + tn * (int64_t)a.wp[3] + tne * (int64_t)a.wp[4] +
+                                        (nn3 - n3) * (int64_t)a.wp[5] + (nw3 - w3) * (int64_t)a.wp[6]) >> 5);
+                    uint32_t weight[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t err_sum = se_nw_ww[i] + se_n_w[i] + se_ne[i];
+                        const uint64_t tt = ((uint64_t)err_sum + 1) >> 5;
+                        const uint32_t shift = tt ? 63u - (uint32_t)__builtin_clzll(tt) : 0u;
+                        weight[i] = 4 + (((uint32_t)a.wp[7 + i] * s_div[(err_sum >> shift) + 1]) >> shift);
+                    }
+                    uint32_t sum_weights = weight[0] + weight[1] + weight[2] + weight[3];
+                    const uint32_t log_weight = 31u - (uint32_t)__builtin_clz(sum_weights >> 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) weight[i] >>= log_weight;
+                    sum_weights = weight[0] + weight[1] + weight[2] + weight[3];
+                    int64_t acc = ((int64_t)sum_weights >> 1) - 1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc += subpred[i] * (int64_t)weight[i];
+                    int64_t prediction = (acc * (int64_t)s_div[sum_weights]) >> 24;
+                    if (((tn ^ tw) | (tn ^ tnw)) <= 0) {
+                        const int64_t mn = min(min(n3, w3), ne3), mx = max(max(n3, w3), ne3);
+                        prediction = prediction < mn ? mn : (prediction > mx ? mx : prediction);
+                    }
+                    sc_prediction = prediction;
+                }
+
+                int32_t pred;
+                {
+                    const int64_t N = n, W = w, NW = nw;
+                    switch (a.predictor) {
+                        case 0: pred = 0; break;
+                        case 1: pred = w; break;
+                        case 2: pred = n; break;
+                        case 3: pred = (int32_t)((W + N) / 2); break;
+                        case 4: {
+                            const int64_t dn = N > NW ? N - NW : NW - N, dw = W > NW ? W - NW : NW - W;
+                            pred = dn < dw ? w : n;
+                            break;
+                        }
+                        case 5: {
+                            const int64_t g = N + W - NW, lo = W < N ? W : N, hi = W > N ? W : N;
+                            pred = (int32_t)(g < lo ? lo : (g > hi ? hi : g));
+                            break;
+                        }
+                        case 6: pred = (int32_t)((sc_prediction + 3) >> 3); break;
+                        case 7: pred = ne; break;
+                        case 8: pred = nw; break;
+                        case 9: pred = ww; break;
+                        case 10: pred = (int32_t)((W + NW) / 2); break;
+                        case 11: pred = (int32_t)((N + NW) / 2); break;
+                        case 12: pred = (int32_t)((N + (int64_t)ne) / 2); break;
+                        default:
+                            pred = (int32_t)((6 * N - 2 * (int64_t)nn + 7 * W + (int64_t)ww + (int64_t)nee + 3 * (int64_t)ne + 8) / 16);
+                            break;
+                    }
+                }
+                const S res = (S)s_in[lane][u & (kRing - 1)];
+                const S diff = Wrap<S>::add(Wrap<S>::mul(res, (S)a.mul), (S)a.off);
+                const S value = Wrap<S>::add(diff, (S)pred);
+                ((S*)t.base)[(size_t)r * t.stride + ux] = value;
+                const int32_t sample = (int32_t)value;
+                s_out[lane][(ob + ux) & (kRing - 1)] = sample;
+
+                if (sc_on) {
+                    const int64_t s8 = (int64_t)sample * 8;
+                    const int64_t true_err = sc_prediction - s8;
+                    uint32_t sub_err[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int64_t d = subpred[i] - s8;
+                        sub_err[i] = (uint32_t)(((uint64_t)(d < 0 ? -d : d) + 3) >> 3);
+                    }
+                    s_true_err[x] = (int32_t)true_err;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s_sub_err[i][x] = sub_err[i];
+                    if (x + 1 < (int32_t)gw) {
+                        te_w = (int32_t)true_err;
+                        te_nw = te_n;
+                        te_n = te_ne;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            se_nw_ww[i] = se_n_w[i];
+                            se_n_w[i] = se_ne[i] + sub_err[i];
+                        }
+                        if (x + 2 >= (int32_t)gw) {
+                            te_ne = te_n;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) se_ne[i] = se_n_w[i];
+                        } else if (r != 0) {
+                            te_ne = s_true_err[x + 2];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) se_ne[i] = s_sub_err[i][x + 2];
+                        }
+                    }
+                }
+                if (x + 1 < (int32_t)gw) {
+                    ww2 = ww1;
+                    ww1 = sample;
+                    w = sample;
+                    if (r == 0) {
+                        nw = sample;
+                        n = sample;
+                    } else {
+                        nw = n;
+                        n = prev[(pb1 + x + 1) & (kRing - 1)];
+                    }
+                }
+            }
+            // one wave: its LDS operations execute in program order, the step boundary is a compiler fence
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
@@ -1283,7 +1515,9 @@ struct ModularState {
     size_t chk_bytes = 0;
     int* d_redo = nullptr;                    // lines redone serially (diagnostics)
     PredTile* pred_tiles = nullptr;           // M4: every (group, channel) subgrid of the frame, longest first
-    uint32_t n_pred_tiles = 0, pred_err_w = 1;
+    uint32_t n_pred_tiles = 0, pred_err_w = 1;   // ... of which the first n_pred_wide go through the workgroup-per-subgrid kernel
+    uint32_t n_pred_wide = 0, n_pred_waves = 0, pred_lane_err_w = 256;
+    PredWave* pred_waves = nullptr;            // lane-packed launch: one entry per wave
     float* fpix[3] = {};
 };
 
@@ -1525,8 +1759,11 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 if (g.hshift > 31 || g.vshift > 31 || tw == 0 || th == 0)
                     return fail(ctx, JXLGPU_ERR_INVALID_ARG, "channel shift too large after transform");  // image.rs:265-273
             }
-            if (th > 256 || (m->desc.residual_predictor == 6 && tw > kPredMaxTileW))
-                return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tile larger than 256 rows (or 1024 columns with the self-correcting predictor)");
+            // subgrids up to kPredLaneMaxW columns take the lane-packed kernel (any height); wider ones the
+            // workgroup-per-subgrid kernel: a lane per row, at most 256 rows
+            const bool lanes_ok = !ctx->tune.pred_wg && tw <= kPredLaneMaxW;
+            if (!lanes_ok && (th > 256 || (m->desc.residual_predictor == 6 && tw > kPredMaxTileW)))
+                return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tile wider than 512 columns with more than 256 rows (or wider than 1024 with the self-correcting predictor)");
             uint32_t stride = 0;
             char* base = ptr(g, 0, &stride);
             // into_groups_with_fixed_count (jxl-grid/src/mutable_subgrid.rs:480-515): subgrids past the channel are empty
@@ -1535,30 +1772,73 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     const uint32_t x0 = std::min(gx * tw, g.w), y0 = std::min(gy * th, g.h);
                     const uint32_t gw = std::min(tw, g.w - x0), gh = std::min(th, g.h - y0);
                     if (gw == 0 || gh == 0) continue;
-                    tiles.push_back(PredTile{base + ((size_t)y0 * stride + x0) * esz, stride, gw, gh, 0});
-                    max_w = std::max(max_w, gw);
+                    tiles.push_back(PredTile{base + ((size_t)y0 * stride + x0) * esz, stride, gw, gh, lanes_ok ? 1u : 0u});
+                    if (!lanes_ok) max_w = std::max(max_w, gw);
                 }
         }
         if (!m->pred_tiles) {
-            // longest chains first: a subgrid takes gw + 3 gh steps whatever else runs
-            std::stable_sort(tiles.begin(), tiles.end(), [](const PredTile& x, const PredTile& y) {
-                return x.gw + 3 * x.gh > y.gw + 3 * y.gh;
+            auto pow2ceil = [](uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; };
+            auto log2u = [](uint32_t v) { uint32_t l = 0; while ((1u << l) < v) ++l; return l; };
+            // lanes per subgrid: P = pow2ceil(gw) / 4 (1..64); columns per round DP = max(4 P, pow2ceil(gw))
+            auto lanes_of = [&](const PredTile& t) { return std::min(64u, std::max(1u, pow2ceil(t.gw) / 4)); };
+            auto dp_of = [&](const PredTile& t) { return std::max(4 * lanes_of(t), pow2ceil(t.gw)); };
+            auto steps_of = [&](const PredTile& t) { return t.packed ? t.gw + (dp_of(t) / lanes_of(t)) * (t.gh - 1) : t.gw + 3 * (t.gh - 1); };
+            // wide subgrids first (own launch), then the lane-packed ones by (P, DP), longest chains first inside a class
+            std::stable_sort(tiles.begin(), tiles.end(), [&](const PredTile& x, const PredTile& y) {
+                if (x.packed != y.packed) return x.packed < y.packed;
+                if (x.packed) {
+                    if (lanes_of(x) != lanes_of(y)) return lanes_of(x) > lanes_of(y);
+                    if (dp_of(x) != dp_of(y)) return dp_of(x) > dp_of(y);
+                }
+                return steps_of(x) > steps_of(y);
             });
+            uint32_t n_wide = 0;
+            while (n_wide < tiles.size() && !tiles[n_wide].packed) ++n_wide;
+            std::vector<PredWave> waves;
+            uint32_t lane_err_w = 256;
+            for (uint32_t i = n_wide; i < tiles.size();) {
+                const uint32_t P = lanes_of(tiles[i]), DP = dp_of(tiles[i]), T = 64 / P;
+                PredWave w{};
+                w.first = i; w.log2p = log2u(P); w.log2dp = log2u(DP);
+                while (i < tiles.size() && w.count < T && lanes_of(tiles[i]) == P && dp_of(tiles[i]) == DP) {
+                    w.steps = std::max(w.steps, steps_of(tiles[i]));
+                    ++w.count; ++i;
+                }
+                if (DP > 256) lane_err_w = 512;
+                waves.push_back(w);
+            }
+            // longest waves first
+            std::stable_sort(waves.begin(), waves.end(), [](const PredWave& x, const PredWave& y) { return x.steps > y.steps; });
             m->n_pred_tiles = (uint32_t)tiles.size();
+            m->n_pred_wide = n_wide;
+            m->n_pred_waves = (uint32_t)waves.size();
             m->pred_err_w = m->desc.residual_predictor == 6 ? max_w : 1;
+            m->pred_lane_err_w = m->desc.residual_predictor == 6 ? lane_err_w : 64;
             if (int rc = malloc_dev(ctx, f, &m->pred_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(PredTile))) return rc;
-            // blocking copy from the host vector: the list is built once per frame (the geometry never changes)
+            if (int rc = malloc_dev(ctx, f, &m->pred_waves, std::max<size_t>(waves.size(), 1) * sizeof(PredWave))) return rc;
+            // blocking copies from the host vectors: the lists are built once per frame (the geometry never changes)
             if (!tiles.empty())
                 HIP_TRY(ctx, hipMemcpy(m->pred_tiles, tiles.data(), tiles.size() * sizeof(PredTile), hipMemcpyHostToDevice));
+            if (!waves.empty())
+                HIP_TRY(ctx, hipMemcpy(m->pred_waves, waves.data(), waves.size() * sizeof(PredWave), hipMemcpyHostToDevice));
         }
         if (m->n_pred_tiles) {
             PredArgs pa;
-            pa.tiles = m->pred_tiles; pa.err_w = m->pred_err_w; pa.predictor = m->desc.residual_predictor;
+            pa.tiles = m->pred_tiles; pa.predictor = m->desc.residual_predictor;
             pa.mul = m->desc.residual_multiplier; pa.off = m->desc.residual_offset;
             for (int k = 0; k < 11; ++k) pa.wp[k] = m->desc.wp_params[k];
-            const size_t lds = (size_t)5 * m->pred_err_w * 4;
-            if (i16) predict_tiles_kernel<int16_t><<<m->n_pred_tiles, 256, lds, s>>>(pa);
-            else predict_tiles_kernel<int32_t><<<m->n_pred_tiles, 256, lds, s>>>(pa);
+            if (m->n_pred_wide) {
+                pa.err_w = m->pred_err_w;
+                const size_t lds = (size_t)5 * m->pred_err_w * 4;
+                if (i16) predict_tiles_kernel<int16_t><<<m->n_pred_wide, 256, lds, s>>>(pa);
+                else predict_tiles_kernel<int32_t><<<m->n_pred_wide, 256, lds, s>>>(pa);
+            }
+            if (m->n_pred_waves) {
+                pa.err_w = m->pred_lane_err_w;
+                const size_t lds = (size_t)5 * m->pred_lane_err_w * 4;
+                if (i16) predict_lanes_kernel<int16_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves);
+                else predict_lanes_kernel<int32_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves);
+            }
         }
     }
 
@@ -1730,7 +2010,7 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "residual_predictor is neither 0xFFFFFFFF nor a Predictor (0..13)");
     if (d->xyb_encoded)
         if (const char* why = color_params_unsupported(d->color)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, why);
-    if (d->residual_predictor <= 13 && d->group_dim > 256) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tiles larger than 256");
+    if (d->residual_predictor <= 13 && d->group_dim > kPredLaneMaxW) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tiles wider than 512");
     if (d->num_transforms && !d->transforms) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null transform list");
     if (d->num_meta_channels && !d->meta_channels) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null meta channel list");
     for (uint32_t c = 0; c < d->num_meta_channels; ++c)

@@ -263,9 +263,9 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void upsample2_lds_kernel(UpSt
 // 2x upsampling of three planes (+ the colour transform when `color` is non-null) in one launch.
 // Returns false when the streaming form does not apply (tiny frames: the reference's padding has
 // its own behaviour below 2 samples, kept by the stage-at-a-time kernel).
-// `variant`: 0 = LDS-ring kernel, 1 = register-ring kernel; `rows`: rows per wave segment, 0 = sized so that the
-// launch is ONE resident round of the chip (every wave of this kernel runs equally long: a second, nearly empty
-// round would double the launch time — 64-row segments of a 4K input were 2176 waves on 2048 slots).
+// `variant`: 0 = LDS-ring kernel, 1 = register-ring kernel; `rows`: rows per wave segment, 0 = sized from the
+// chip's resident wave slots (a fixed 64 rows made a 4K input 2176 waves on the 2048 slots of the register-ring
+// kernel: a second, nearly empty round doubled the launch time).
 bool launch_upsample2_stream(hipStream_t s, const float* const in[3], uint32_t in_stride, uint32_t w, uint32_t h,
                              float* const out[3], uint32_t out_stride, const float* weights_quarter_host,
                              const ColorArgs* color, const PixRect* window, uint32_t num_cus, int variant, int rows) {
@@ -285,8 +285,17 @@ bool launch_upsample2_stream(hipStream_t s, const float* const in[3], uint32_t i
     const uint32_t waves_per_simd = variant == 1 ? 2u : (color ? 4u : 5u);
     if (rows <= 0) {
         const uint32_t slots = num_cus * 4u * waves_per_simd;
-        const uint32_t segs_fit = std::max(1u, slots / (uint32_t)a.strips);   // segments per strip that stay resident together
-        rows = (int)std::max(16u, ceil_div(nrows, segs_fit));                // (a 4-row run-in per segment: not below 16)
+        if (variant == 1) {
+            // register-ring kernel: ONE resident round (every wave runs equally long; its run-in rows are full-price)
+            const uint32_t segs_fit = std::max(1u, slots / (uint32_t)a.strips);
+            rows = (int)std::max(16u, ceil_div(nrows, segs_fit));
+        } else {
+            // LDS-ring kernel: a run-in row is three loads and three LDS writes, so short segments are cheap and about
+            // four rounds of waves keep every SIMD at its resident limit to the end (measured on a 4K input, rows per
+            // segment 34 / 24 / 17 / 12 / 8: 0.78 / 0.78 / 0.74 / 0.75 / 0.73 ms for the whole post stage)
+            const uint32_t segs_want = std::max(1u, 4u * slots / (uint32_t)a.strips);
+            rows = (int)std::max(8u, ceil_div(nrows, segs_want));
+        }
     }
     a.rows_per_seg = rows;
     a.segs = (int)ceil_div(nrows, (uint32_t)a.rows_per_seg);

@@ -431,12 +431,14 @@ class ModularWorkload:
     transforms, exercises wrapping)."""
 
     def __init__(self, width, height, kind="squeeze", seed=0, i16=True, lossy=True, rct_type=None,
-                 xyb=True, epf_iters=0, gabor=False, bit_depth=8, predictor=5, pred_offset=0, residual=None):
+                 xyb=True, epf_iters=0, gabor=False, bit_depth=8, predictor=5, pred_offset=0, residual=None,
+                 group_dim=256):
         """`residual` (kinds 'squeeze', 'palette'): a Predictor id — the buffers then hold the RESIDUALS of
         that predictor (single-leaf MA tree) for every transformed channel, computed decode unit by decode
         unit (channel_tiles) from the transformed samples; None: they hold the samples themselves."""
         rng = np.random.default_rng(SEED_BASE + 0x100 + seed)
         self.width, self.height, self.kind = width, height, kind
+        self.group_dim = group_dim
         self.dtype = np.int16 if i16 else np.int32
         self.sample_type = abi.SAMPLE_I16 if i16 else abi.SAMPLE_I32
         self.bit_depth = bit_depth
@@ -456,9 +458,9 @@ class ModularWorkload:
             rgb = [np.clip(p, 0, 255) for p in base]
             self.expected = [p.astype(self.dtype) for p in rgb]
             if predictor == 6:
-                chans = [weighted_residuals(p, 256) for p in rgb]
+                chans = [weighted_residuals(p, group_dim) for p in rgb]
             else:
-                chans = [predictor_residuals(p, 256, predictor, pred_offset) for p in rgb]
+                chans = [predictor_residuals(p, group_dim, predictor, pred_offset) for p in rgb]
             self.residual_predictor = predictor
             self.residual_offset = pred_offset
             self.buffers = [p.astype(self.dtype) for p in chans]
@@ -469,7 +471,7 @@ class ModularWorkload:
             t = 6 if rct_type is None else rct_type
             a, b, c = forward_rct(rgb[0], rgb[1], rgb[2], t)
             self.transforms.append(("rct", 0, t))
-            chans = [gradient_residuals(p, 256) for p in (a, b, c)]
+            chans = [gradient_residuals(p, group_dim) for p in (a, b, c)]
             self.residual_predictor = 5
             self.buffers = [p.astype(self.dtype) for p in chans]
         elif kind == "squeeze":
@@ -501,7 +503,7 @@ class ModularWorkload:
             forward_squeeze(bufs, grids, steps, quant)
             self.transforms.append(("squeeze", None))
             if residual is not None:
-                residuals_in_place(bufs, [], grids, 0, 256, residual, pred_offset)
+                residuals_in_place(bufs, [], grids, 0, group_dim, residual, pred_offset)
                 self.residual_predictor, self.residual_offset = residual, pred_offset
             self.buffers = [b.astype(self.dtype) for b in bufs]
         elif kind == "palette":
@@ -514,7 +516,7 @@ class ModularWorkload:
                 # transformed channel list: [palette table (meta, unshiftable), index channel]
                 grids = [_Grid(~0, 0, 0, ncol, 3, -1, -1), _Grid(0, 0, 0, W, H)]
                 bufs, metas = [idx], [pal]
-                residuals_in_place(bufs, metas, grids, 1, 256, residual, pred_offset)
+                residuals_in_place(bufs, metas, grids, 1, group_dim, residual, pred_offset)
                 self.residual_predictor, self.residual_offset = residual, pred_offset
             self.meta.append(pal.astype(self.dtype))
             self.buffers = [idx.astype(self.dtype), np.zeros((H, W), self.dtype), np.zeros((H, W), self.dtype)]
@@ -610,7 +612,7 @@ class ModularWorkload:
         d.residual_multiplier = self.residual_multiplier
         d.residual_offset = self.residual_offset
         d.wp_params[:] = DEFAULT_WP
-        d.group_dim = 256
+        d.group_dim = self.group_dim
         d.xyb_encoded = 1 if self.xyb else 0
         d.m_lf_unscaled[:] = [(1.0 / 32.0) / 128.0, (1.0 / 4.0) / 128.0, (1.0 / 2.0) / 128.0]
         d.filter = self.filter

@@ -105,6 +105,41 @@ def test_self_correcting_predictor_full_tiles(gpu_ctx, oracle):
     _inverse_both(gpu_ctx, oracle, wl)
 
 
+@pytest.mark.parametrize("predictor", [6, 13, 5])
+@pytest.mark.parametrize("size", [(3, 40), (5, 300), (13, 7), (100, 90), (257, 130), (600, 700)])
+def test_lane_packed_subgrid_shapes(gpu_ctx, oracle, predictor, size):
+    """The lane-packed predictor kernel gives a subgrid P = pow2ceil(gw) / 4 lanes and lets a lane walk rows
+    k, k + P, ...: widths of 1-4 columns (P = 1: one lane does every row), non-power-of-two widths (idle columns
+    in a round), several subgrids per wave (edge tiles of 257 x 130), and with group_dim 512 subgrids of up to
+    512 x 512 (D = 8; more rows than the workgroup-per-subgrid kernel takes).  Random residuals, device against
+    oracle, i32 and i16 buffers."""
+    w, h = size
+    gd = 512 if w > 512 else 256
+    wl = ModularWorkload(w, h, kind="predictor", predictor=1, i16=False, seed=2, group_dim=gd)
+    rng = np.random.default_rng(w * 31 + h + predictor)
+    wl.buffers = [rng.integers(-40, 40, size=(h, w)).astype(np.int32) for _ in range(3)]
+    wl.residual_predictor, wl.residual_multiplier, wl.residual_offset = predictor, 2, 1
+    wl.expected = None
+    _inverse_both(gpu_ctx, oracle, wl)
+    wl.sample_type, wl.dtype = abi.SAMPLE_I16, np.int16
+    wl.buffers = [b.astype(np.int16) for b in wl.buffers]
+    _inverse_both(gpu_ctx, oracle, wl)
+
+
+def test_workgroup_per_subgrid_kernel_still_matches(oracle, monkeypatch):
+    """JXLGPU_PRED_WG routes every subgrid through the workgroup-per-subgrid kernel (the form that serves subgrids
+    wider than 512 columns)."""
+    from jxl_oxide_amd import runtime
+    monkeypatch.setenv("JXLGPU_PRED_WG", "1")
+    ctx = runtime.Context(0)
+    try:
+        for kw in (dict(kind="squeeze", lossy=True, residual=6), dict(kind="palette", residual=6)):
+            wl = ModularWorkload(300, 270, seed=4, **kw)
+            _inverse_both(ctx, oracle, wl)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("d_pred", [0, 1, 5, 6, 13])
 @pytest.mark.parametrize("i16", [True, False])
 def test_palette_with_delta_entries(gpu_ctx, oracle, d_pred, i16):
