@@ -552,10 +552,143 @@ __global__ __launch_bounds__(64) void squeeze_seg3_kernel(SegArgs3 g3) {
     else squeeze_v_seg_body<S>(g, i, blockIdx.y);
 }
 
+// Horizontal step, lane = SEGMENT (the default for 16-byte aligned rectangles).  In squeeze_h_seg_body a lane
+// walks its own row, so one wave instruction touches 64 different 128-byte lines and uses 16 bytes of each:
+// the step fetched 2.7x what it wrote (profiles/r02_modular_cfg3_pmc.txt).  Here adjacent lanes own adjacent
+// 2N-pair pieces of ONE row (N = samples per 16-byte vector: 16 pairs of i16), so every load and store of
+// the wave is a contiguous kilobyte; a lane starts 8 pairs early from a guessed `prev` as before, and the
+// links BETWEEN the lanes of a wave are settled in the kernel: lane l compares the `prev` it had reached at
+// its first own pair with the `prev` lane l - 1 ended with (one DPP shift) and redoes its piece from the true
+// value until no link of the wave is open (nearly always zero rounds; inputs and outputs stay in registers,
+// nothing is stored before the wave agrees).  Only the links between WAVES go through `chk` and
+// squeeze_check3_kernel: a "segment" there is a wave's 64 pieces.  Rows with fewer than 33 pieces share a
+// wave (lanes per row = pow2ceil(pieces)).
+template <typename S>
+__global__ __launch_bounds__(64) void squeeze_h_lanes_kernel(SegArgs3 g3) {
+    constexpr int N = 16 / sizeof(S);
+    constexpr int SP = 2 * N;   // pairs per lane
+    constexpr int OV = 8;       // run-in pairs (a multiple of N for both sample types)
+    using V = int4;
+    union Pack { V v; S s[N]; };
+    const SegArgs& g = g3.g[blockIdx.z];
+    const SqzArgs& a = g.a;
+    const uint32_t avg_w = (a.width + 1) / 2, pairs = a.width / 2;
+    const uint32_t nls = (pairs + SP - 1) / SP;                     // pieces per row
+    uint32_t lpr = 64;                                              // lanes per row
+    if (nls <= 32) { lpr = 1; while (lpr < nls) lpr <<= 1; }
+    const uint32_t rows_per_wave = 64 / lpr;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t y = blockIdx.y * rows_per_wave + lane / lpr;
+    const uint32_t in_row = lane & (lpr - 1);
+    const uint32_t ls = blockIdx.x * 64 + in_row;                   // blockIdx.x > 0 only when lpr == 64
+    if (blockIdx.x >= g.nseg || blockIdx.y * rows_per_wave >= a.height) return;   // wave-uniform
+    const bool active = y < a.height && ls < nls;
+    const uint32_t x_s = ls * SP;
+    const uint32_t npairs = active ? min((uint32_t)SP, pairs - x_s) : 0u;
+    const bool exact_start = ls == 0;                               // the row's first piece: prev = avg, no run-in
+    const bool runin = !exact_start && g.runin != 0;
+    const S* avgp = (const S*)a.avg + (size_t)(active ? y : 0) * a.avg_stride;
+    const S* resp = (const S*)a.res + (size_t)(active ? y : 0) * a.res_stride;
+    S* outp = (S*)a.out + (size_t)(active ? y : 0) * a.out_stride;
+
+    // inputs of pairs [x_s - OV, x_s + SP): av[i] = avg sample x_s - OV + i (one more for the last pair's next_avg)
+    S av[OV + SP + 1], rs[OV + SP];
+    const bool vec = active && x_s + SP + N <= avg_w;
+    if (vec) {
+#pragma unroll
+        for (int v = 0; v < (OV + SP) / N + 1; ++v) {
+            Pack pk;
+            pk.v = make_int4(0, 0, 0, 0);
+            if (v * N >= OV || runin) pk.v = *reinterpret_cast<const V*>(avgp + x_s - OV + v * N);
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+                if (v * N + k < OV + SP + 1) av[v * N + k] = pk.s[k];
+        }
+#pragma unroll
+        for (int v = 0; v < (OV + SP) / N; ++v) {
+            Pack pk;
+            pk.v = make_int4(0, 0, 0, 0);
+            if (v * N >= OV || runin) pk.v = *reinterpret_cast<const V*>(resp + x_s - OV + v * N);
+#pragma unroll
+            for (int k = 0; k < N; ++k) rs[v * N + k] = pk.s[k];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < OV + SP + 1; ++i) {
+            const uint32_t xi = x_s - OV + i;   // wraps below zero for the first piece: masked by `i >= OV || runin`
+            av[i] = (active && (i >= OV || runin) && xi < avg_w) ? avgp[xi] : (S)0;
+        }
+#pragma unroll
+        for (int i = 0; i < OV + SP; ++i) {
+            const uint32_t xi = x_s - OV + i;
+            rs[i] = (active && (i >= OV || runin) && xi < pairs) ? resp[xi] : (S)0;
+        }
+    }
+    S o[2 * SP];
+    // pairs [FROM, OV + npairs) of the piece from `prev`; returns the prev at the end, *at_start = the prev at pair OV
+    auto chain = [&](int from, S prev, S* at_start) __attribute__((always_inline)) -> S {
+        S avg = av[from];
+#pragma unroll
+        for (int p = 0; p < OV + SP; ++p) {
+            if (p < from) continue;
+            if (p == OV) *at_start = prev;
+            if ((uint32_t)(p - OV) < npairs || p < OV) {
+                const S next_avg = (x_s - OV + p + 1 < avg_w) ? av[p + 1] : avg;
+                S first, second;
+                squeeze_pair<S>(rs[p], next_avg, avg, prev, first, second);
+                if (p >= OV) { o[2 * (p - OV)] = first; o[2 * (p - OV) + 1] = second; }
+            }
+        }
+        return prev;
+    };
+    S start_prev = 0, end_prev = 0;
+    if (active) {
+        if (runin) {
+            // the previous pair's average; a run-in that starts at pair 0 (i32: the row's second piece) starts exactly
+            const S guess = x_s == (uint32_t)OV ? av[0] : (S)avgp[x_s - OV - 1];
+            end_prev = chain(0, guess, &start_prev);
+        } else {
+            const S p0 = exact_start ? av[OV] : (S)avgp[x_s - 1];  // runin == 0 (tests): a bare guess, the links settle it
+            end_prev = chain(OV, p0, &start_prev);
+        }
+    }
+    // settle the links inside the wave
+    for (;;) {
+        const S before = (S)__shfl_up((int)end_prev, 1);
+        const bool open = active && in_row > 0 && start_prev != before;
+        if (__builtin_amdgcn_ballot_w64(open) == 0) break;
+        if (open) {
+            S dummy;
+            end_prev = chain(OV, before, &dummy);
+            start_prev = before;
+        }
+    }
+    // links between waves: what this wave began with / ended with
+    if (active && g.nseg > 1) {
+        S* chk = (S*)g.chk;
+        if (in_row == 0) chk[((size_t)blockIdx.x * 2 + 0) * a.height + y] = start_prev;
+        if (in_row == 63 || ls + 1 == nls) chk[((size_t)blockIdx.x * 2 + 1) * a.height + y] = end_prev;
+    }
+    if (vec) {
+#pragma unroll
+        for (int v = 0; v < 2 * SP / N; ++v) {
+            Pack pk;
+#pragma unroll
+            for (int k = 0; k < N; ++k) pk.s[k] = o[v * N + k];
+            *reinterpret_cast<V*>(outp + 2 * x_s + v * N) = pk.v;
+        }
+    } else if (active) {
+#pragma unroll
+        for (int p = 0; p < SP; ++p)
+            if ((uint32_t)p < npairs) { outp[2 * (x_s + p)] = o[2 * p]; outp[2 * (x_s + p) + 1] = o[2 * p + 1]; }
+    }
+    if (active && ls + 1 == nls && (a.width & 1)) outp[a.width - 1] = avgp[avg_w - 1];
+}
+
 // One segment again, serially, from its true starting state (`prev` = what the segment before it
 // really ended with); returns the `prev` it ends with.  Pairs [p_s, p_e) of line i.
 template <typename S, bool HORIZONTAL>
-__device__ __forceinline__ S squeeze_redo_range(const SqzArgs& a, uint32_t i, uint32_t p_s, uint32_t p_e, S prev) {
+__device__ __forceinline__ S squeeze_redo_range(const SqzArgs& a, uint32_t i, uint32_t p_s, uint32_t p_e, S prev, S stored_end) {
     const uint32_t len = HORIZONTAL ? a.width : a.height;
     const uint32_t avg_n = (len + 1) / 2;
     const size_t as = HORIZONTAL ? 1 : a.avg_stride, rs = HORIZONTAL ? 1 : a.res_stride, os = HORIZONTAL ? 1 : a.out_stride;
@@ -567,8 +700,12 @@ __device__ __forceinline__ S squeeze_redo_range(const SqzArgs& a, uint32_t i, ui
         const S next_avg = (p + 1 < avg_n) ? avgp[(size_t)(p + 1) * as] : avg;
         S first, second;
         squeeze_pair<S>(resp[(size_t)p * rs], next_avg, avg, prev, first, second);
+        // the only state a pair hands on is `prev` = its second sample: once the redone chain reaches the sample
+        // the first pass stored there, everything behind it (and the segment's recorded end) already stands
+        const bool rejoined = outp[(size_t)(2 * p + 1) * os] == second;
         outp[(size_t)(2 * p) * os] = first;
         outp[(size_t)(2 * p + 1) * os] = second;
+        if (rejoined) return stored_end;
     }
     return prev;
 }
@@ -593,7 +730,7 @@ __global__ __launch_bounds__(64) void squeeze_check3_kernel(SegArgs3 g3, int* re
         }
         if (redo_count) atomicAdd(redo_count, 1);
         const uint32_t p_s = s * g.seg_pairs, p_e = (s + 1 == g.nseg) ? pairs : p_s + g.seg_pairs;
-        end_prev = squeeze_redo_range<S, HORIZONTAL>(g.a, i, p_s, p_e, end_prev);
+        end_prev = squeeze_redo_range<S, HORIZONTAL>(g.a, i, p_s, p_e, end_prev, chk[((size_t)s * 2 + 1) * lines + i]);
     }
 }
 
@@ -1575,8 +1712,8 @@ void launch_squeeze_step(hipStream_t s, const Tuning& tune, bool horizontal, con
     SegArgs3 g3;
     memset(&g3, 0, sizeof(g3));
     int nseg_ch = 0;
-    uint32_t max_lines = 0, max_nseg = 0;
-    bool all_vec = true;
+    uint32_t max_lines = 0, max_nseg = 0, max_grid_y = 0;
+    bool all_vec = true, all_lanes = true;
     const size_t chk_each = chk_bytes / 3;
     for (int k = 0; k < count; ++k) {
         const SqzArgs& ak = a[k];
@@ -1586,9 +1723,21 @@ void launch_squeeze_step(hipStream_t s, const Tuning& tune, bool horizontal, con
         // segment length: about an eighth of the chain, a multiple of 16, within [32, JXLGPU_SQZ_SEG]
         uint32_t L = (pairs / 8 + 15) / 16 * 16;
         L = std::min<uint32_t>(std::max<uint32_t>(L, 32u), std::max<uint32_t>(32u, (uint32_t)tune.sqz_seg / 16u * 16u));
-        const uint32_t nseg = pairs / L;
+        uint32_t nseg = pairs / L;
         const uint32_t avg_len = (len + 1) / 2;
-        const bool segmented = nseg >= 2 && (!horizontal || (vec && avg_len >= 2u * (16 / sizeof(S)))) && chk &&
+        // horizontal, aligned: lane = piece of 2N pairs (squeeze_h_lanes_kernel); a check segment is a wave's 64 pieces
+        constexpr uint32_t SP = 2 * (16 / sizeof(S));
+        const bool lanes = horizontal && vec && !tune.sqz_h_rows && pairs >= 64;
+        uint32_t grid_y = ceil_div(lines, 64);
+        if (lanes) {
+            const uint32_t nls = ceil_div(pairs, SP);
+            L = 64 * SP;
+            nseg = nls > 32 ? ceil_div(nls, 64u) : 1u;
+            uint32_t lpr = 64;
+            if (nls <= 32) { lpr = 1; while (lpr < nls) lpr <<= 1; }
+            grid_y = ceil_div(lines, 64 / lpr);
+        }
+        const bool segmented = (lanes || (nseg >= 2 && (!horizontal || (vec && avg_len >= 2u * (16 / sizeof(S)))))) && chk &&
                                (size_t)nseg * 2 * lines * sizeof(S) <= chk_each;
         if (segmented) {
             SegArgs& g = g3.g[nseg_ch];
@@ -1597,7 +1746,9 @@ void launch_squeeze_step(hipStream_t s, const Tuning& tune, bool horizontal, con
             ++nseg_ch;
             max_lines = std::max(max_lines, lines);
             max_nseg = std::max(max_nseg, nseg);
+            max_grid_y = std::max(max_grid_y, grid_y);
             all_vec &= vec;
+            all_lanes &= lanes;
         } else if ((uint64_t)pairs * lines <= (1u << 16) && plan.chain.n[chain_slot[k]] < (uint32_t)kChainMaxSteps) {
             const int c = chain_slot[k];
             const uint32_t i = plan.chain.n[c]++;
@@ -1617,8 +1768,10 @@ void launch_squeeze_step(hipStream_t s, const Tuning& tune, bool horizontal, con
     if (!nseg_ch) return;
     flush_chain<S>(s, plan);  // the segmented step reads what the small levels produced
     if (horizontal) {
-        squeeze_seg3_kernel<S, true><<<dim3(ceil_div(max_lines, 64), max_nseg, nseg_ch), 64, 0, s>>>(g3);
-        squeeze_check3_kernel<S, true><<<dim3(ceil_div(max_lines, 64), nseg_ch), 64, 0, s>>>(g3, redo_count);
+        // (the channels of a step are all aligned or all not: they are rectangles of one geometry)
+        if (all_lanes) squeeze_h_lanes_kernel<S><<<dim3(max_nseg, max_grid_y, nseg_ch), 64, 0, s>>>(g3);
+        else squeeze_seg3_kernel<S, true><<<dim3(ceil_div(max_lines, 64), max_nseg, nseg_ch), 64, 0, s>>>(g3);
+        if (max_nseg > 1) squeeze_check3_kernel<S, true><<<dim3(ceil_div(max_lines, 64), nseg_ch), 64, 0, s>>>(g3, redo_count);
     } else {
         constexpr uint32_t NC = 4 / sizeof(S);  // i16: two columns per lane; i32: the one-column kernel
         if (all_vec && NC > 1) {

@@ -225,7 +225,9 @@ from jxl_oxide_amd import runtime
 from jxl_oxide_amd.synth_modular import ModularWorkload
 from oracle import pyoracle
 ctx = runtime.Context(0)
-for (w, h, kind, i16) in [(700, 520, "squeeze", True), (520, 700, "squeeze", False), (640, 400, "raw", True)]:
+# (the two wide cases: horizontal steps of more than one wave of lane-pieces per row, so that links BETWEEN waves break too)
+for (w, h, kind, i16) in [(700, 520, "squeeze", True), (520, 700, "squeeze", False), (640, 400, "raw", True),
+                          (4400, 40, "squeeze", True), (2200, 72, "squeeze", False)]:
     wl = ModularWorkload(w, h, kind=kind, lossy=True, i16=i16, seed=w)
     d = wl.desc()
     exp = pyoracle.modular_inverse(d, wl.shapes(), wl.dtype)
