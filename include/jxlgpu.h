@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 14u
+#define JXLGPU_ABI_VERSION 15u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -422,6 +422,12 @@ typedef struct {
     uint32_t sample_type;        /* JXLGPU_SAMPLE_I16 / I32 (modular_16bit_buffers)                  */
     uint32_t bit_depth;          /* bits_per_sample (palette delta scaling, int->float)              */
     uint32_t num_channels;       /* colour channels first (1 or 3), then extra channels              */
+    /* frame_header.encoded_color_channels(): 3, or 1 for a grayscale image (then never XYB).  0 = 3.  The
+     * render of a grayscale frame follows jxl-render/src/render.rs:74-134: the gray channel is cloned into
+     * three for the Gabor-like filter and the EPF (which sums its distances over three channels) and the
+     * clones are dropped again — result plane 0 is the image, planes 1 and 2 are scratch; noise is not
+     * rendered on grayscale (render.rs:208-221).                                                        */
+    uint32_t num_color_channels;
     const JxlGpuModularChannel* channels;
     uint32_t num_meta_channels;  /* palette meta channels, in the order the inverse pops them         */
     const JxlGpuModularChannel* meta_channels;

@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -247,6 +247,7 @@ class ModularDesc(C.Structure):
         ("sample_type", C.c_uint32),
         ("bit_depth", C.c_uint32),
         ("num_channels", C.c_uint32),
+        ("num_color_channels", C.c_uint32),
         ("channels", C.POINTER(ModularChannel)),
         ("num_meta_channels", C.c_uint32),
         ("meta_channels", C.POINTER(ModularChannel)),

@@ -2159,6 +2159,11 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
     *out_frame = nullptr;
     if (d->abi != JXLGPU_ABI_VERSION) return fail(ctx, JXLGPU_ERR_ABI, "descriptor ABI version mismatch");
     if (d->num_channels == 0 || !d->channels) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "no channels");
+    if (d->num_color_channels != 0 && d->num_color_channels != 1 && d->num_color_channels != 3)
+        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "num_color_channels is 1 (grayscale) or 3");
+    if (d->num_color_channels == 1 && d->xyb_encoded) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "a grayscale frame cannot be XYB encoded");
+    if ((d->num_color_channels ? d->num_color_channels : 3u) > d->num_channels)
+        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "fewer channels than colour channels");
     if (d->residual_predictor != 0xFFFFFFFFu && d->residual_predictor > 13)
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "residual_predictor is neither 0xFFFFFFFF nor a Predictor (0..13)");
     if (d->xyb_encoded)
@@ -2274,7 +2279,7 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
     f->desc.color = d->color;
     if (!d->xyb_encoded) f->desc.color.enabled = 0;
     fill_color_args_public(f->desc.color, &f->color);
-    if (d->num_channels >= 3) {
+    {
         const size_t npix = (size_t)f->wr * f->hr;
         for (int c = 0; c < 3; ++c) {
             if ((rc = malloc_dev(ctx, f, &m->fpix[c], npix * 4))) return rc;
@@ -2330,9 +2335,11 @@ static int modular_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages
     if (!ctx || !f || f->kind_of_frame != 1) return JXLGPU_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ModularState* m = static_cast<ModularState*>(f->modular);
-    if (m->orig.size() < 3) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "grayscale Modular frames are not rendered on the device yet");
-    for (int c = 1; c < 3; ++c)
+    // grayscale (render.rs:74-134): the one colour channel feeds all three filter inputs; plane 0 is the result
+    const bool gray = m->desc.num_color_channels == 1;
+    for (int c = 1; c < 3 && !gray; ++c)
         if (m->cw[c] != m->cw[0] || m->ch[c] != m->ch[0]) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "subsampled colour channels");
+    if (gray) stages &= ~(uint32_t)JXLGPU_STAGE_NOISE;  // render.rs:208-221: "Cannot render noise on grayscale buffer; skipping"
     if (!(stages & JXLGPU_STAGE_MODULAR_TO_FLOAT)) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "render needs JXLGPU_STAGE_MODULAR_TO_FLOAT");
     ctx->prof_begin(PROF_MODULAR);
     int rc = run_inverse(ctx, f);
@@ -2340,8 +2347,9 @@ static int modular_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages
     if (rc) return rc;
     ToFloatArgs a;
     for (int c = 0; c < 3; ++c) {
-        a.in[c] = m->work[m->final_loc[c]][c];
-        a.in_stride[c] = m->cw[c];
+        const int src = gray ? 0 : c;
+        a.in[c] = m->work[m->final_loc[src]][src];
+        a.in_stride[c] = m->cw[src];
         a.out[c] = m->fpix[c];
         a.m[c] = m->desc.m_lf_unscaled[c];
     }

@@ -543,6 +543,18 @@ class ModularWorkload:
             self.residual_predictor = predictor
             self.residual_offset = pred_offset
             self.buffers = [rng.integers(-3, 4, size=(H, W)).astype(self.dtype) for _ in range(3)]
+        elif kind == "gray":
+            # grayscale image (encoded_color_channels == 1): one channel, default Squeeze (no chroma pre-steps), lossless
+            g = np.clip(base[0], 0, (1 << bit_depth) - 1)
+            self.expected = [g.astype(self.dtype)]
+            bufs = [g.copy()]
+            grids = [_Grid(0, 0, 0, W, H)]
+            forward_squeeze(bufs, grids, default_squeeze_params(grids), lambda level, res: res)
+            self.transforms.append(("squeeze", None))
+            if residual is not None:
+                residuals_in_place(bufs, [], grids, 0, group_dim, residual, pred_offset)
+                self.residual_predictor, self.residual_offset = residual, pred_offset
+            self.buffers = [b.astype(self.dtype) for b in bufs]
         elif kind == "raw":
             # arbitrary data straight into the inverse chain: wrapping arithmetic included
             info = np.iinfo(self.dtype)
@@ -585,6 +597,7 @@ class ModularWorkload:
             chans[i].data = b.ctypes.data
             chans[i].width, chans[i].height = b.shape[1], b.shape[0]
         d.num_channels = n
+        d.num_color_channels = 1 if self.kind == "gray" else 3
         d.channels = C.cast(chans, C.POINTER(abi.ModularChannel))
         metas = (abi.ModularChannel * max(1, len(self.meta)))()
         for i, m in enumerate(self.meta):

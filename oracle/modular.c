@@ -562,10 +562,16 @@ static float parse_integer_sample(const JxlGpuModularDesc* d, int32_t sample) {
  * (Modular order: for XYB that is Y, X, B; image.rs:148-189 swaps Y/X into framebuffer order). */
 int jxl_oracle_modular_render(const JxlGpuModularDesc* d, uint32_t stages, float* const out[3],
                               uint32_t out_stride) {
-    if (d->num_channels < 3) return JXLGPU_ERR_UNSUPPORTED;
+    /* grayscale (jxl-render/src/render.rs:74-134): `clone_gray` before the Gabor-like filter / the EPF, the clones
+     * dropped afterwards (:133-134) — the three filter inputs are the one channel, plane 0 is the image; without
+     * filters the channel passes through; noise is skipped on a grayscale buffer (:208-221) */
+    const int gray = d->num_color_channels == 1;
+    if (gray && d->xyb_encoded) return JXLGPU_ERR_INVALID_ARG;
+    if (d->num_channels < (gray ? 1u : 3u)) return JXLGPU_ERR_INVALID_ARG;
+    if (gray) stages &= ~(uint32_t)JXLGPU_STAGE_NOISE;
     size_t esz = d->sample_type == JXLGPU_SAMPLE_I16 ? 2 : 4;
     uint32_t W = d->channels[0].width, H = d->channels[0].height;
-    for (int c = 1; c < 3; ++c)
+    for (int c = 1; c < 3 && !gray; ++c)
         if (d->channels[c].width != W || d->channels[c].height != H) return JXLGPU_ERR_UNSUPPORTED;
     void** planes = (void**)calloc(d->num_channels, sizeof(void*));
     for (uint32_t c = 0; c < d->num_channels; ++c)
@@ -591,7 +597,7 @@ int jxl_oracle_modular_render(const JxlGpuModularDesc* d, uint32_t stages, float
             }
         } else {
             for (int c = 0; c < 3; ++c)
-                for (size_t i = 0; i < n; ++i) pix[c][i] = parse_integer_sample(d, SAMPLE(c, i));
+                for (size_t i = 0; i < n; ++i) pix[c][i] = parse_integer_sample(d, SAMPLE(gray ? 0 : c, i));
         }
 #undef SAMPLE
         if (!(stages & JXLGPU_STAGE_MODULAR_TO_FLOAT)) rc = JXLGPU_ERR_INVALID_ARG;

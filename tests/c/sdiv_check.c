@@ -1,6 +1,6 @@
 /* The arithmetic behind div3_shared (jxl-oxide_amd/csrc/post_pk.inc): a correctly rounded f32 quotient
  * n / d is what the chain  r = rcp(d); e = fma(-d, r, 1); r = fma(e, r, r); q0 = n * r;
- * e1 = fma(-d, q0, n); q1 = fma(e1, r, q0); e2 = fma(-d, q1, n); q = fma(e2, r, q1)  returns for ANY
+ * t1 = fma(d, q0, -n); q1 = fma(-t1, r, q0); t2 = fma(d, q1, -n); q = fma(-t2, r, q1)  returns for ANY
  * reciprocal estimate within 1 ulp of 1/d (the accuracy of v_rcp_f32), as long as 1 <= d <= 2^20 and
  * 2^-100 <= |n| <= 2^20 (no step leaves the normal range; this is what LLVM's own division expansion
  * computes between v_div_scale and v_div_fixup).  The program checks the chain against the host's
@@ -18,7 +18,7 @@ static uint64_t s=88172645463325252ull;
 static uint64_t rnd(){s^=s<<13;s^=s>>7;s^=s<<17;return s;}
 static float shared_div(float n,float d,float r0){
   float e=fmaf(-d,r0,1.0f); float r=fmaf(e,r0,r0);
-  float q0=n*r; float e1=fmaf(-d,q0,n); float q1=fmaf(e1,r,q0); float e2=fmaf(-d,q1,n); return fmaf(e2,r,q1);
+  float q0=n*r; float t1=fmaf(d,q0,-n); float q1=fmaf(-t1,r,q0); float t2=fmaf(d,q1,-n); return fmaf(-t2,r,q1);
 }
 int main(int argc, char** argv){
   long bad=0,tot=0;
@@ -36,6 +36,12 @@ int main(int argc, char** argv){
       ++tot;
       if (f2u(got)!=f2u(want)){ if(bad<10) printf("n=%a d=%a r0=%a got=%a want=%a\n",n,d,r0,got,want); ++bad; }
     }
+  }
+  /* exact zeros of either sign keep their sign (the residual is formed as -(d q - n)) */
+  for(int sgn=0;sgn<2;++sgn) for(int it=0;it<2000;++it){
+    uint32_t ed=127+(rnd()%21); float d=u2f((ed<<23)|(rnd()&0x7fffff)); float n=u2f((uint32_t)sgn<<31);
+    float rc=1.0f/d;
+    for(int k=-1;k<=1;++k){ float got=shared_div(n,d,u2f(f2u(rc)+k)); ++tot; if(f2u(got)!=f2u(n/d)){ if(bad<10) printf("zero: n=%a d=%a got=%a\n",n,d,got); ++bad; } }
   }
   printf("tested %ld, mismatches %ld\n",tot,bad);
   return bad!=0;

@@ -210,6 +210,40 @@ def test_render_rgb8_no_colour_transform(gpu_ctx, oracle):
     assert np.array_equal(got[0], wl.expected[0].astype(np.float32) / np.float32(255))
 
 
+@pytest.mark.parametrize("i16", [True, False])
+@pytest.mark.parametrize("case", [dict(), dict(gabor=True), dict(epf_iters=2), dict(gabor=True, epf_iters=3),
+                                  dict(epf_iters=1, residual=6), dict(gabor=True, epf_iters=2, up=2)])
+def test_grayscale_frames(gpu_ctx, oracle, case, i16):
+    """encoded_color_channels == 1 (jxl-render/src/render.rs:74-134): one colour channel through the inverse
+    transforms (Squeeze without the chroma pre-steps, optional predictor residuals), cloned into the three filter
+    inputs; plane 0 of the result is the image.  Integer result against the original, render against the oracle."""
+    case = dict(case)
+    up = case.pop("up", 1)
+    w, h = 300, 270
+    wl = ModularWorkload(w, h, kind="gray", i16=i16, seed=11, **case)
+    got_int = _inverse_both(gpu_ctx, oracle, wl)
+    assert np.array_equal(got_int[0], wl.expected[0])
+    d = wl.desc()
+    if up > 1:
+        from jxl_oxide_amd.synth import _load_up_weights
+        upw = _load_up_weights()
+        d.upsampling.factor = up
+        d.upsampling.up2_weight = upw[0].ctypes.data_as(abi.f32p)
+        d.upsampling.up4_weight = upw[1].ctypes.data_as(abi.f32p)
+        d.upsampling.up8_weight = upw[2].ctypes.data_as(abi.f32p)
+    stages = abi.STAGE_ALL | abi.STAGE_MODULAR_TO_FLOAT
+    exp = oracle.modular_render(d, stages, w * up, h * up)
+    f = gpu_ctx.modular_upload(d)
+    try:
+        got = gpu_ctx.modular_render(f, stages)
+        reg = (16, 40, 200, 96)
+        got_reg = gpu_ctx.modular_render_region(f, stages, reg)
+    finally:
+        f.free()
+    assert np.array_equal(got[0].view(np.uint32), exp[0].view(np.uint32))
+    assert np.array_equal(got_reg[0].view(np.uint32), exp[0][reg[1]:reg[1] + reg[3], reg[0]:reg[0] + reg[2]].view(np.uint32))
+
+
 def test_squeeze_fixup_path(oracle):
     """Without the run-in the guessed carries are usually wrong: the check kernel must catch every
     broken link and redo those lines serially.  Runs in a child process (the switches are read once

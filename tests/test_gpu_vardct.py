@@ -334,3 +334,31 @@ def test_device_output_formatting(gpu_ctx, oracle, fmt):
                 assert np.array_equal(got.view(np.uint8), exp.view(np.uint8)), f"{size} fmt {fmt} orientation {o}"
         finally:
             frame.free()
+
+
+def test_all_zero_channel_keeps_the_packed_division_path_exact(gpu_ctx, oracle):
+    """A gray image in XYB has an X plane of exact zeros of either sign (zero coefficients through the IDCT's
+    negative constants give -0).  The packed EPF kernel's shared-reciprocal quotient must return n / d bit for bit
+    for n = +-0 as well (csrc/post_pk.inc div3_shared: the residual is formed as -(d q - n)): EPF output planes
+    (no colour transform, so the sign of a zero is visible) against the oracle."""
+    wl = VardctWorkload(520, 300, seed=77)
+    wl.coeff[0] = 0                      # no X coefficients
+    wl.lfq[1][...] = 0                   # X of the LF image
+    wl.xfy[...] = 0                      # no chroma-from-luma into X (base_correlation_x is 0)
+    stages = abi.STAGE_LF | abi.STAGE_TRANSFORM | abi.STAGE_GABOR | abi.STAGE_EPF
+    d = wl.desc()
+    d.x_factor_lf = 128                  # CfL-LF factor 0 for X: ((128 - 128) / 128)
+    exp, _ = oracle.vardct_render(d, stages, wl.width, wl.height)
+    assert not exp[0].any(), "the X plane is expected to be all zeros"
+    d2 = wl.desc(coeff_transport="grouped")
+    d2.x_factor_lf = 128
+    f = gpu_ctx.vardct_upload(d2)
+    try:
+        got = gpu_ctx.vardct_render(f, stages)
+        gpu_ctx.vardct_render_batch([f], stages)
+        gpu_ctx.synchronize()
+        got_b = gpu_ctx.download_result(f, stages)
+    finally:
+        f.free()
+    for g, what in ((got, "single frame"), (got_b, "batch")):
+        assert np.array_equal(g.view(np.uint32), exp.view(np.uint32)), what
