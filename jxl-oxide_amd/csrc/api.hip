@@ -327,6 +327,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     }
     if (const char* v = getenv("JXLGPU_SQZ_RUNIN")) ctx->tune.sqz_runin = (uint32_t)atoi(v);
     ctx->tune.pred_wg = getenv("JXLGPU_PRED_WG") != nullptr;
+    ctx->tune.pred_wide = getenv("JXLGPU_PRED_WIDE") != nullptr;
     ctx->tune.sqz_h_rows = getenv("JXLGPU_SQZ_H_ROWS") != nullptr;
     if (const char* v = getenv("JXLGPU_UP2_VARIANT")) ctx->tune.up2_variant = atoi(v);
     if (const char* v = getenv("JXLGPU_UP2_ROWS")) ctx->tune.up2_rows = atoi(v);

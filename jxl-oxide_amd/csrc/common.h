@@ -211,6 +211,7 @@ struct Tuning {
     int sqz_seg = 64;            // JXLGPU_SQZ_SEG: pairs per inverse-Squeeze segment
     uint32_t sqz_runin = 1;      // JXLGPU_SQZ_RUNIN: 0 forces the Squeeze fix-up path (tests)
     bool sqz_h_rows = false;     // JXLGPU_SQZ_H_ROWS: horizontal Squeeze steps through the lane-per-row segment kernel
+    bool pred_wide = false;      // JXLGPU_PRED_WIDE: the self-correcting predictor in 64-bit arithmetic only
     bool pred_wg = false;        // JXLGPU_PRED_WG: predictor subgrids through the workgroup-per-subgrid kernel only
     int up2_variant = 0;         // JXLGPU_UP2_VARIANT: 1 = register-ring form of the 2x upsampling kernel (0: LDS ring)
     int up2_rows = 0;            // JXLGPU_UP2_ROWS: rows per wave segment of that kernel (0: one resident round)

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -893,12 +894,13 @@ constexpr uint32_t kPredMaxTileW = 1024;  // the self-correcting predictor's err
 constexpr uint32_t kPredLaneMaxW = 512;   // widest subgrid of the lane-packed kernel (row r - 2 is 2 D <= 16 ring columns ahead)
 constexpr int kRing = 16;                 // columns per row in the LDS rings (power of two, > 6 + look-ahead)
 struct PredTile {
-    void* base;              // first sample of the subgrid
-    uint32_t stride, gw, gh; // elements; gh <= 256
+    void* base;              // first sample of the subgrid: residuals in, samples out (in place)
+    uint32_t stride, gw, gh; // elements
     uint32_t packed;         // 1: handled by the lane-packed kernel (P lanes of a wave), 0: a workgroup of its own
 };
 struct PredArgs {
     const PredTile* tiles;
+    void* sink;              // 64 samples nobody reads: where off-grid lanes of the one-wave kernels store
     uint32_t err_w;          // columns of the error rows in dynamic LDS (>= the widest subgrid; 1 when unused)
     uint32_t predictor;
     int32_t mul, off;
@@ -1122,14 +1124,40 @@ __global__ __launch_bounds__(256) void predict_tiles_kernel(PredArgs a) {
 // first row to its last, a wave carries 64 / P subgrids, and there is no workgroup barrier: the rings belong to
 // the wave, whose LDS operations execute in order.  Same registers, same statements per sample as above
 // (predictor.rs:26-442, image.rs:716-949); only the schedule differs, and any number of rows is taken.
+// Step boundary of the one-wave kernels: the rings are private to the wave and LDS operations of one wave execute in
+// program order, so all that is needed is that the COMPILER keeps LDS accesses on their side of the boundary.  (A
+// wavefront-scope release / acquire fence pair does that too, but it is lowered to s_waitcnt vmcnt(0) lgkmcnt(0):
+// every step then waited for the residual it had just requested 16 columns ahead and for its own store — one HBM
+// round trip per step, 1.9 us of the 1.9 us a step took.)
+// A pointer read from a table in memory is a generic (flat) pointer to the compiler; flat loads count in lgkmcnt as
+// well as vmcnt, so every wait for an LDS read would also wait for the residual requested 16 columns ahead.
+template <typename T>
+using GlobalPtr = T __attribute__((address_space(1)))*;
+template <typename T>
+__device__ __forceinline__ GlobalPtr<T> as_global(T* p) { return (GlobalPtr<T>)p; }
+
+__device__ __forceinline__ void lds_step_boundary() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
 struct PredWave {
     uint32_t first, count;    // tiles[first .. first + count): the subgrids of this wave, P lanes each
     uint32_t log2p, log2dp;   // P lanes per subgrid; DP = D * P columns per round (>= every gw of the wave)
     uint32_t steps, pad[3];   // max over the wave's subgrids of gw + D (gh - 1)
 };
 
+struct PredSrc {
+    const void* src;   // residuals of the subgrid (same geometry as PredTile.base; == base when the pass runs in place)
+};
+
+// `srcs` / `wave_flags` non-null: the redo pass behind predict_lanes_narrow_kernel — only flagged waves run, and
+// they read the residuals from `srcs` (the narrow pass has written over `base`).
 template <typename S>
-__global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const PredWave* waves) {
+__global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const PredWave* waves, const PredSrc* srcs,
+                                                           const uint32_t* wave_flags) {
+    if (wave_flags && wave_flags[blockIdx.x] == 0) return;
     extern __shared__ int32_t s_err[];          // 5 x err_w words: true_err, sub_err[4]; a subgrid's columns start at slot * (err_w * P / 64)
     __shared__ uint32_t s_div[65];
     __shared__ int32_t s_out[64][kRing + 1];    // finished samples of the lane's current / previous rows, stream position & 15
@@ -1141,6 +1169,7 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
     const uint32_t slot = lane >> log2p, k = lane & (P - 1);
     const bool have_tile = slot < wv.count;
     PredTile t = a.tiles[wv.first + (have_tile ? slot : 0)];
+    const GlobalPtr<const S> src = as_global(srcs ? (const S*)srcs[wv.first + (have_tile ? slot : 0)].src : (const S*)t.base);
     const uint32_t gw = have_tile ? t.gw : 0, gh = have_tile ? t.gh : 0;
     const uint32_t ecol = slot * ((a.err_w << log2p) >> 6);   // this subgrid's first column in the error rows
     int32_t* s_true_err = s_err + ecol;
@@ -1177,12 +1206,18 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int32_t u = u0 + s0 + j;
-            {   // residual pipeline: park what arrived for position u + 8, request position u + 16
+            {   // residual pipeline: park what arrived for position u + 8, request position u + 16.  Every global access
+                // of the step is issued unconditionally (an off-grid lane reads the subgrid's first sample, parks it in a
+                // slot nobody reads and stores to `sink`): with a load or store under a branch the compiler cannot count
+                // the accesses in flight and waits for ALL of them (s_waitcnt vmcnt(0)) before it parks a residual
                 uint32_t rq, xq;
-                if (where(u + 8, &rq, &xq)) s_in[lane][(u + 8) & (kRing - 1)] = pf[j];
-                if (where(u + 16, &rq, &xq)) pf[j] = (int32_t)((const S*)t.base)[(size_t)rq * t.stride + xq];
+                s_in[lane][(u + 8) & (kRing - 1)] = pf[j];
+                const bool ahead = where(u + 16, &rq, &xq);
+                pf[j] = (int32_t)src[ahead ? (size_t)rq * t.stride + xq : (size_t)0];
             }
             uint32_t r, ux;
+            S st_value = 0;
+            GlobalPtr<S> st_ptr = as_global((S*)a.sink + lane);
             if (where(u, &r, &ux)) {
                 const int32_t x = (int32_t)ux;
                 const uint32_t round = (uint32_t)u >> log2dp;
@@ -1285,7 +1320,8 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
                 const S res = (S)s_in[lane][u & (kRing - 1)];
                 const S diff = Wrap<S>::add(Wrap<S>::mul(res, (S)a.mul), (S)a.off);
                 const S value = Wrap<S>::add(diff, (S)pred);
-                ((S*)t.base)[(size_t)r * t.stride + ux] = value;
+                st_value = value;
+                st_ptr = as_global((S*)t.base + (size_t)r * t.stride + ux);
                 const int32_t sample = (int32_t)value;
                 s_out[lane][(ob + ux) & (kRing - 1)] = sample;
 
@@ -1334,10 +1370,195 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
                     }
                 }
             }
-            // one wave: its LDS operations execute in program order, the step boundary is a compiler fence
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            *st_ptr = st_value;
+            lds_step_boundary();
+        }
+    }
+}
+
+// ---- the self-correcting predictor in 32-bit arithmetic (the default for predictor 6 in the lane-packed form).
+// The reference computes in i64 (predictor.rs:312-441) and the kernels above follow it: 20 v_mad_u64_u32, 40
+// carry pairs and a dozen 64-bit compares per sample, most of the ~320 instructions of a step.  With
+// |sample| < 2^17, |true_err| < 2^19 and the WpHeader fields in their coded ranges (p1, p2, p3a-e < 32,
+// w0-3 < 16; checked by the host) every intermediate fits 32 bits — |subpred| < 2^23, |sum| < 2^30; only
+// acc * DIV_LOOKUP[sum_weights] needs the high half of one product — so int32 arithmetic gives the same
+// numbers.  A lane that produces a sample or a true error outside those bounds raises its wave's flag and the
+// wave stops (the offending value is itself still exact: its inputs were in range); predict_lanes_kernel then
+// redoes exactly the flagged waves from the untouched residuals: the narrow kernel reads them from `src`
+// (the read-only upload) and writes `base`.  Nothing an 8- to 16-bit image produces comes near the bounds.
+// Besides the arithmetic: the step is straight-line code but for the row-start block (state that the next row
+// start overwrites anyway is updated unconditionally; the error rows are zero where the first row reads them),
+// and every LDS read that does not depend on this step's arithmetic is issued at its top.
+template <typename S>
+__global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, const PredWave* waves, const PredSrc* srcs,
+                                                                  uint32_t* wave_flags) {
+    extern __shared__ int32_t s_err[];
+    __shared__ uint32_t s_div[65];
+    __shared__ int32_t s_out[64][kRing + 1];
+    __shared__ int32_t s_in[64][kRing + 1];
+    const PredWave wv = waves[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t log2p = wv.log2p, log2dp = wv.log2dp, P = 1u << log2p, DPm1 = (1u << log2dp) - 1u;
+    const int32_t D = (int32_t)(1u << (log2dp - log2p));
+    const uint32_t slot = lane >> log2p, k = lane & (P - 1);
+    const bool have_tile = slot < wv.count;
+    const PredTile t = a.tiles[wv.first + (have_tile ? slot : 0)];
+    const GlobalPtr<const S> src = as_global((const S*)srcs[wv.first + (have_tile ? slot : 0)].src);
+    const uint32_t gw = have_tile ? t.gw : 0, gh = have_tile ? t.gh : 0;
+    const uint32_t ecol = slot * ((a.err_w << log2p) >> 6);
+    int32_t* s_true_err = s_err + ecol;
+    uint32_t* s_sub_err[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_sub_err[i] = reinterpret_cast<uint32_t*>(s_err) + (size_t)(i + 1) * a.err_w + ecol;
+    for (uint32_t i = lane; i < 5 * a.err_w; i += 64) s_err[i] = 0;
+    s_div[lane] = div_lookup_dev(lane);
+    if (lane == 0) { s_div[64] = div_lookup_dev(64); wave_flags[blockIdx.x] = 0; }
+    __syncthreads();
+    const uint32_t lane0 = lane & ~(P - 1);
+    uint32_t wrap1 = 0, wrap2 = 0;
+    int32_t q1 = (int32_t)k - 1, q2 = (int32_t)k - 2;
+    while (q1 < 0) { q1 += (int32_t)P; ++wrap1; }
+    while (q2 < 0) { q2 += (int32_t)P; ++wrap2; }
+    const int32_t* prev = s_out[lane0 + (uint32_t)q1];
+    const int32_t* prev2 = s_out[lane0 + (uint32_t)q2];
+    const int32_t wp0 = a.wp[0], wp1 = a.wp[1], wp2 = a.wp[2], wp3 = a.wp[3], wp4 = a.wp[4], wp5 = a.wp[5], wp6 = a.wp[6];
+    const uint32_t ww[4] = {(uint32_t)a.wp[7], (uint32_t)a.wp[8], (uint32_t)a.wp[9], (uint32_t)a.wp[10]};
+
+    int32_t w = 0, n = 0, nw = 0;
+    int32_t te_w = 0, te_nw = 0, te_n = 0, te_ne = 0;
+    uint32_t se_nw_ww[4] = {0, 0, 0, 0}, se_n_w[4] = {0, 0, 0, 0}, se_ne[4] = {0, 0, 0, 0};
+    uint32_t pb1 = 0, pb2 = 0;   // ring positions of column 0 of rows r - 1, r - 2 (set at the row start)
+    int32_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int32_t steps = (int32_t)wv.steps;
+    const int32_t u0 = -D * (int32_t)k;
+    auto where = [&](int32_t q, uint32_t* r, uint32_t* x) -> bool {
+        *r = k + (((uint32_t)q >> log2dp) << log2p);
+        *x = (uint32_t)q & DPm1;
+        return q >= 0 && *r < gh && *x < gw;
+    };
+    for (int32_t s0 = -16; s0 < steps; s0 += 8) {
+        bool out_of_range = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int32_t u = u0 + s0 + j;
+            {   // residual pipeline: park what arrived for position u + 8, request position u + 16.  Every global access
+                // of the step is issued unconditionally (an off-grid lane reads the subgrid's first sample, parks it in a
+                // slot nobody reads and stores to `sink`): with a load or store under a branch the compiler cannot count
+                // the accesses in flight and waits for ALL of them (s_waitcnt vmcnt(0)) before it parks a residual
+                uint32_t rq, xq;
+                s_in[lane][(u + 8) & (kRing - 1)] = pf[j];
+                const bool ahead = where(u + 16, &rq, &xq);
+                pf[j] = (int32_t)src[ahead ? (size_t)rq * t.stride + xq : (size_t)0];
+            }
+            uint32_t r, ux;
+            S st_value = 0;
+            GlobalPtr<S> st_ptr = as_global((S*)a.sink + lane);
+            if (where(u, &r, &ux)) {
+                const int32_t x = (int32_t)ux;
+                const int32_t gwi = (int32_t)gw;
+                if (x == 0) {
+                    const uint32_t round = (uint32_t)u >> log2dp;
+                    pb1 = ((round - wrap1) << log2dp) & (kRing - 1);
+                    pb2 = ((round - wrap2) << log2dp) & (kRing - 1);
+                    if (r == 0) {
+                        w = n = nw = 0;
+                    } else {
+                        w = n = nw = prev[pb1];
+                        te_w = 0;
+                        te_n = s_true_err[0];
+                        te_nw = te_n;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { se_n_w[i] = s_sub_err[i][0]; se_nw_ww[i] = se_n_w[i]; }
+                        const int e1 = gw <= 1 ? 0 : 1;
+                        te_ne = s_true_err[e1];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) se_ne[i] = s_sub_err[i][e1];
+                    }
+                }
+                // LDS reads that do not depend on this step's arithmetic
+                const int32_t res = s_in[lane][u & (kRing - 1)];
+                const int32_t p_ne = prev[(pb1 + ux + 1) & (kRing - 1)];
+                const int32_t p_nn = prev2[(pb2 + ux) & (kRing - 1)];
+                const int32_t x2 = min(x + 2, gwi - 1);
+                const int32_t l_te = s_true_err[x2];
+                uint32_t l_se[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) l_se[i] = s_sub_err[i][x2];
+
+                const int32_t ne = (r == 0 || x + 1 >= gwi) ? n : p_ne;
+                const int32_t nn = r >= 2 ? p_nn : n;
+                const int32_t n3 = n * 8, nw3 = nw * 8, ne3 = ne * 8, w3 = w * 8, nn3 = nn * 8;
+                int32_t subpred[4];
+                subpred[0] = w3 + ne3 - n3;
+                subpred[1] = n3 - (((te_w + te_n + te_ne) * wp0) >> 5);
+                subpred[2] = w3 - (((te_w + te_n + te_nw) * wp1) >> 5);
+                subpred[3] = n3 - ((te_nw * wp2 + te_n * wp3 + te_ne * wp4 + (nn3 - n3) * wp5 + (nw3 - w3) * wp6) >> 5);
+                uint32_t weight[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t err_sum = se_nw_ww[i] + se_n_w[i] + se_ne[i];
+                    const uint32_t tt = (err_sum + 1u) >> 5;
+                    const uint32_t shift = tt ? 31u - (uint32_t)__builtin_clz(tt) : 0u;
+                    weight[i] = 4u + ((ww[i] * s_div[(err_sum >> shift) + 1]) >> shift);
+                }
+                uint32_t sum_weights = weight[0] + weight[1] + weight[2] + weight[3];
+                const uint32_t log_weight = 31u - (uint32_t)__builtin_clz(sum_weights >> 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) weight[i] >>= log_weight;
+                sum_weights = weight[0] + weight[1] + weight[2] + weight[3];
+                int32_t acc = (int32_t)(sum_weights >> 1) - 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc += subpred[i] * (int32_t)weight[i];
+                int32_t prediction = (int32_t)(((int64_t)acc * (int64_t)(int32_t)s_div[sum_weights]) >> 24);
+                if (((te_n ^ te_w) | (te_n ^ te_nw)) <= 0) {
+                    const int32_t mn = min(min(n3, w3), ne3), mx = max(max(n3, w3), ne3);
+                    prediction = prediction < mn ? mn : (prediction > mx ? mx : prediction);
+                }
+                const int32_t pred = (prediction + 3) >> 3;
+                const S diff = Wrap<S>::add(Wrap<S>::mul((S)res, (S)a.mul), (S)a.off);
+                const S value = Wrap<S>::add(diff, (S)pred);
+                st_value = value;
+                st_ptr = as_global((S*)t.base + (size_t)r * t.stride + ux);
+                const int32_t sample = (int32_t)value;
+                s_out[lane][u & (kRing - 1)] = sample;
+
+                const int32_t s8 = sample * 8;
+                const int32_t true_err = prediction - s8;
+                out_of_range |= (uint32_t)true_err + (1u << 19) >= (1u << 20) || (uint32_t)sample + (1u << 17) >= (1u << 18);
+                uint32_t sub_err[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int32_t d = subpred[i] - s8;
+                    sub_err[i] = ((uint32_t)(d < 0 ? -d : d) + 3u) >> 3;
+                }
+                s_true_err[x] = true_err;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_sub_err[i][x] = sub_err[i];
+                // SelfCorrectingPredictor::record + Properties::record; at a row's last column this state is dead
+                // (the row start sets all of it), so the x + 1 < gw test of the reference is not needed
+                const bool last2 = x + 2 >= gwi;
+                te_w = true_err;
+                te_nw = te_n;
+                te_n = te_ne;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    se_nw_ww[i] = se_n_w[i];
+                    se_n_w[i] = se_ne[i] + sub_err[i];
+                }
+                // row 0 reads the zeros its error rows still hold two columns ahead: the same as keeping its zeros
+                te_ne = last2 ? te_n : l_te;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) se_ne[i] = last2 ? se_n_w[i] : l_se[i];
+                w = sample;
+                nw = r == 0 ? sample : n;
+                n = r == 0 ? sample : p_ne;
+            }
+            *st_ptr = st_value;
+            lds_step_boundary();
+        }
+        if (__builtin_amdgcn_ballot_w64(out_of_range) != 0) {
+            if (lane == 0) wave_flags[blockIdx.x] = 1;
+            return;
         }
     }
 }
@@ -1655,6 +1876,9 @@ struct ModularState {
     uint32_t n_pred_tiles = 0, pred_err_w = 1;   // ... of which the first n_pred_wide go through the workgroup-per-subgrid kernel
     uint32_t n_pred_wide = 0, n_pred_waves = 0, pred_lane_err_w = 256;
     PredWave* pred_waves = nullptr;            // lane-packed launch: one entry per wave
+    PredSrc* pred_srcs = nullptr;              // per subgrid: its residuals in the read-only upload
+    uint32_t* pred_flags = nullptr;            // per wave: left the 32-bit range (redone by the 64-bit kernel)
+    bool pred_narrow = false;
     float* fpix[3] = {};
 };
 
@@ -1797,12 +2021,6 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     // the in-place passes (predictor, RCT, palette) need a writable copy first.
     m->work[3] = m->orig;
     const bool predict = m->desc.residual_predictor <= 13;
-    if (predict) {
-        for (uint32_t c = 0; c < nch; ++c)
-            HIP_TRY(ctx, hipMemcpyAsync(m->work[0][c], m->orig[c], (size_t)m->cw[c] * m->ch[c] * esz, hipMemcpyDeviceToDevice, s));
-        for (size_t c = 0; c < m->meta.size(); ++c)
-            HIP_TRY(ctx, hipMemcpyAsync(m->meta_work[c], m->meta[c], (size_t)m->mw[c] * m->mh[c] * esz, hipMemcpyDeviceToDevice, s));
-    }
 
     // forward bookkeeping (transform_channel_info): which rectangle is which transformed channel
     std::vector<Grid> l;
@@ -1892,6 +2110,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
         //  decode_simple_grad: the same arithmetic as decode_one with Predictor::Gradient, one kernel here)
         bool global_phase = true;
         std::vector<PredTile> tiles;
+        std::unordered_map<const void*, const void*> tile_src;   // PredTile.base -> the subgrid in the read-only upload
         uint32_t max_w = 1;
         for (size_t i = 0; i < l.size() && !m->pred_tiles; ++i) {
             const Grid& g = l[i];
@@ -1919,6 +2138,9 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tile wider than 512 columns with more than 256 rows (or wider than 1024 with the self-correcting predictor)");
             uint32_t stride = 0;
             char* base = ptr(g, 0, &stride);
+            // the same rectangle in the read-only upload (what the narrow kernel reads)
+            const char* src_base = g.buf >= 0 ? (const char*)m->orig[g.buf] + ((size_t)g.y0 * stride + g.x0) * esz
+                                              : (const char*)m->meta[~g.buf];
             // into_groups_with_fixed_count (jxl-grid/src/mutable_subgrid.rs:480-515): subgrids past the channel are empty
             for (uint32_t gy = 0; gy < nrows; ++gy)
                 for (uint32_t gx = 0; gx < ncols; ++gx) {
@@ -1926,6 +2148,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     const uint32_t gw = std::min(tw, g.w - x0), gh = std::min(th, g.h - y0);
                     if (gw == 0 || gh == 0) continue;
                     tiles.push_back(PredTile{base + ((size_t)y0 * stride + x0) * esz, stride, gw, gh, lanes_ok ? 1u : 0u});
+                    tile_src[tiles.back().base] = src_base + ((size_t)y0 * stride + x0) * esz;
                     if (!lanes_ok) max_w = std::max(max_w, gw);
                 }
         }
@@ -1967,17 +2190,36 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             m->n_pred_waves = (uint32_t)waves.size();
             m->pred_err_w = m->desc.residual_predictor == 6 ? max_w : 1;
             m->pred_lane_err_w = m->desc.residual_predictor == 6 ? lane_err_w : 64;
+            // the 32-bit form of the self-correcting predictor: WpHeader fields in their coded ranges (5 / 4 bits)
+            bool wp_coded = true;
+            for (int k = 0; k < 11; ++k) wp_coded &= m->desc.wp_params[k] >= 0 && m->desc.wp_params[k] < (k < 7 ? 32 : 16);
+            m->pred_narrow = m->desc.residual_predictor == 6 && wp_coded && !ctx->tune.pred_wide && !waves.empty();
+            std::vector<PredSrc> srcs(tiles.size());
+            for (size_t i = 0; i < tiles.size(); ++i) srcs[i].src = tile_src[tiles[i].base];
             if (int rc = malloc_dev(ctx, f, &m->pred_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(PredTile))) return rc;
             if (int rc = malloc_dev(ctx, f, &m->pred_waves, std::max<size_t>(waves.size(), 1) * sizeof(PredWave))) return rc;
+            if (int rc = malloc_dev(ctx, f, &m->pred_srcs, std::max<size_t>(srcs.size(), 1) * sizeof(PredSrc))) return rc;
+            // (+ 64 words behind the flags: the store sink of off-grid lanes)
+            if (int rc = malloc_dev(ctx, f, &m->pred_flags, (std::max<size_t>(waves.size(), 1) + 64) * sizeof(uint32_t))) return rc;
             // blocking copies from the host vectors: the lists are built once per frame (the geometry never changes)
-            if (!tiles.empty())
+            if (!tiles.empty()) {
                 HIP_TRY(ctx, hipMemcpy(m->pred_tiles, tiles.data(), tiles.size() * sizeof(PredTile), hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMemcpy(m->pred_srcs, srcs.data(), srcs.size() * sizeof(PredSrc), hipMemcpyHostToDevice));
+            }
             if (!waves.empty())
                 HIP_TRY(ctx, hipMemcpy(m->pred_waves, waves.data(), waves.size() * sizeof(PredWave), hipMemcpyHostToDevice));
         }
+        // The in-place kernels work on a copy of the residuals; the narrow kernel reads the upload itself and writes the
+        // working copy, so when it serves every subgrid of the frame nothing is copied (200 MB for an 8K frame).
+        if (!(m->pred_narrow && m->n_pred_wide == 0)) {
+            for (uint32_t c = 0; c < nch; ++c)
+                HIP_TRY(ctx, hipMemcpyAsync(m->work[0][c], m->orig[c], (size_t)m->cw[c] * m->ch[c] * esz, hipMemcpyDeviceToDevice, s));
+            for (size_t c = 0; c < m->meta.size(); ++c)
+                HIP_TRY(ctx, hipMemcpyAsync(m->meta_work[c], m->meta[c], (size_t)m->mw[c] * m->mh[c] * esz, hipMemcpyDeviceToDevice, s));
+        }
         if (m->n_pred_tiles) {
             PredArgs pa;
-            pa.tiles = m->pred_tiles; pa.predictor = m->desc.residual_predictor;
+            pa.tiles = m->pred_tiles; pa.sink = m->pred_flags + std::max<uint32_t>(m->n_pred_waves, 1); pa.predictor = m->desc.residual_predictor;
             pa.mul = m->desc.residual_multiplier; pa.off = m->desc.residual_offset;
             for (int k = 0; k < 11; ++k) pa.wp[k] = m->desc.wp_params[k];
             if (m->n_pred_wide) {
@@ -1989,8 +2231,28 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             if (m->n_pred_waves) {
                 pa.err_w = m->pred_lane_err_w;
                 const size_t lds = (size_t)5 * m->pred_lane_err_w * 4;
-                if (i16) predict_lanes_kernel<int16_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves);
-                else predict_lanes_kernel<int32_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves);
+                if (m->pred_narrow) {
+                    // 32-bit pass over everything, then the 64-bit kernel for the waves that left the 32-bit range (none, for
+                    // images of up to 16 bits)
+                    if (i16) {
+                        predict_lanes_narrow_kernel<int16_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                        predict_lanes_kernel<int16_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                    } else {
+                        predict_lanes_narrow_kernel<int32_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                        predict_lanes_kernel<int32_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                    }
+                    if (ctx->tune.debug_sync) {
+                        std::vector<uint32_t> fl(m->n_pred_waves);
+                        HIP_TRY(ctx, hipStreamSynchronize(s));
+                        HIP_TRY(ctx, hipMemcpy(fl.data(), m->pred_flags, fl.size() * 4, hipMemcpyDeviceToHost));
+                        size_t nfl = 0;
+                        for (uint32_t v : fl) nfl += v != 0;
+                        fprintf(stderr, "predictor waves redone in 64-bit arithmetic: %zu of %u\n", nfl, m->n_pred_waves);
+                    }
+                } else {
+                    if (i16) predict_lanes_kernel<int16_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, nullptr, nullptr);
+                    else predict_lanes_kernel<int32_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, nullptr, nullptr);
+                }
             }
         }
     }

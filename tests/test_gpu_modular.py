@@ -126,11 +126,57 @@ def test_lane_packed_subgrid_shapes(gpu_ctx, oracle, predictor, size):
     _inverse_both(gpu_ctx, oracle, wl)
 
 
+@pytest.mark.parametrize("amp", [40, 1 << 15, 1 << 21])
+def test_self_correcting_predictor_leaves_the_32_bit_range(oracle, amp):
+    """The self-correcting predictor runs in 32-bit arithmetic while |sample| < 2^17 and |true_err| < 2^19 and is
+    redone in the reference's 64-bit arithmetic, from the untouched residuals, for every wave that leaves that range
+    (predict_lanes_narrow_kernel -> predict_lanes_kernel).  Residuals of +-40 never do, +-2^15 do in places, +-2^21
+    everywhere; i32 buffers, device against oracle.  Runs in a child process with JXLGPU_DEBUG_SYNC (which reports
+    the number of redone waves)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+from jxl_oxide_amd import runtime
+from jxl_oxide_amd.synth_modular import ModularWorkload
+from oracle import pyoracle
+amp = int(sys.argv[1])
+ctx = runtime.Context(0)
+wl = ModularWorkload(300, 270, kind="predictor", predictor=1, i16=False, seed=2)
+rng = np.random.default_rng(amp)
+wl.buffers = [rng.integers(-amp, amp + 1, size=(270, 300)).astype(np.int32) for _ in range(3)]
+wl.residual_predictor, wl.residual_multiplier, wl.residual_offset = 6, 1, 0
+d = wl.desc()
+exp = pyoracle.modular_inverse(d, wl.shapes(), wl.dtype)
+f = ctx.modular_upload(d)
+got = ctx.modular_inverse(f, wl.shapes(), wl.dtype)
+again = ctx.modular_inverse(f, wl.shapes(), wl.dtype)
+f.free()
+assert all(np.array_equal(g, e) for g, e in zip(got, exp))
+assert all(np.array_equal(g, e) for g, e in zip(again, exp))
+print("NARROW_OK")
+"""
+    env = dict(os.environ, JXLGPU_DEBUG_SYNC="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code, str(amp)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert "NARROW_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    redone = [int(l.split(":")[1].split("of")[0]) for l in r.stderr.splitlines() if "redone in 64-bit arithmetic" in l]
+    assert redone, r.stderr[-1000:]
+    if amp <= 40:
+        assert sum(redone) == 0
+    if amp >= 1 << 21:
+        assert sum(redone) > 0, "the test did not exercise the 64-bit redo"
+
+
 def test_workgroup_per_subgrid_kernel_still_matches(oracle, monkeypatch):
     """JXLGPU_PRED_WG routes every subgrid through the workgroup-per-subgrid kernel (the form that serves subgrids
     wider than 512 columns)."""
     from jxl_oxide_amd import runtime
     monkeypatch.setenv("JXLGPU_PRED_WG", "1")
+    monkeypatch.setenv("JXLGPU_PRED_WIDE", "1")
     ctx = runtime.Context(0)
     try:
         for kw in (dict(kind="squeeze", lossy=True, residual=6), dict(kind="palette", residual=6)):
