@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <new>
 #include <unordered_map>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -1145,7 +1146,8 @@ __device__ __forceinline__ void lds_step_boundary() {
 struct PredWave {
     uint32_t first, count;    // tiles[first .. first + count): the subgrids of this wave, P lanes each
     uint32_t log2p, log2dp;   // P lanes per subgrid; DP = D * P columns per round (>= every gw of the wave)
-    uint32_t steps, pad[3];   // max over the wave's subgrids of gw + D (gh - 1)
+    uint32_t steps;           // max over the wave's subgrids of gw + D (gh - 1)
+    uint32_t vec, pad[2];     // every subgrid of the wave takes four-sample accesses (alignment, gw % 4 == 0)
 };
 
 struct PredSrc {
@@ -1389,7 +1391,13 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
 // Besides the arithmetic: the step is straight-line code but for the row-start block (state that the next row
 // start overwrites anyway is updated unconditionally; the error rows are zero where the first row reads them),
 // and every LDS read that does not depend on this step's arithmetic is issued at its top.
-template <typename S>
+// VEC: a lane moves its residuals and samples four at a time (8- or 16-byte accesses; the subgrids of the wave are
+// aligned for it and their width is a multiple of four).  With one sample per lane per step every wave instruction
+// touched 64 different cache lines for 128 useful bytes, twice per step: the address path of the CU, not the
+// arithmetic, set the step time (same kernel without its global accesses: 0.8 instead of 2.0 ms per 8K frame).
+// A lane's stream position is congruent to the step index modulo 4 (D is a multiple of 4), so the group boundaries
+// are compile-time positions of the unrolled loop: request + park at steps 0 and 4, store at steps 3 and 7.
+template <typename S, bool VEC>
 __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, const PredWave* waves, const PredSrc* srcs,
                                                                   uint32_t* wave_flags) {
     extern __shared__ int32_t s_err[];
@@ -1429,6 +1437,13 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
     uint32_t se_nw_ww[4] = {0, 0, 0, 0}, se_n_w[4] = {0, 0, 0, 0}, se_ne[4] = {0, 0, 0, 0};
     uint32_t pb1 = 0, pb2 = 0;   // ring positions of column 0 of rows r - 1, r - 2 (set at the row start)
     int32_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    typedef uint32_t RawV2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t RawV4 __attribute__((ext_vector_type(4)));
+    using V4 = typename std::conditional<sizeof(S) == 2, RawV2, RawV4>::type;   // four samples (a plain vector type: usable through address-space pointers)
+    union Pack4 { V4 v; S s[4]; };
+    Pack4 pfv[2], sbuf;
+    pfv[0].v = pfv[1].v = V4{};
+    sbuf.v = V4{};
     const int32_t steps = (int32_t)wv.steps;
     const int32_t u0 = -D * (int32_t)k;
     auto where = [&](int32_t q, uint32_t* r, uint32_t* x) -> bool {
@@ -1441,7 +1456,17 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int32_t u = u0 + s0 + j;
-            {   // residual pipeline: park what arrived for position u + 8, request position u + 16.  Every global access
+            if constexpr (VEC) {
+                if ((j & 3) == 0) {
+                    // park the four residuals requested 8 steps ago (positions u + 8 .. u + 11: one row, contiguous ring
+                    // slots), request positions u + 16 .. u + 19; always issued (see the one-sample form below)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s_in[lane][(u + 8 + i) & (kRing - 1)] = (int32_t)pfv[j >> 2].s[i];
+                    uint32_t rq, xq;
+                    const bool ahead = where(u + 16, &rq, &xq);
+                    pfv[j >> 2].v = *reinterpret_cast<GlobalPtr<const V4>>(src + (ahead ? (size_t)rq * t.stride + xq : (size_t)0));
+                }
+            } else {   // residual pipeline: park what arrived for position u + 8, request position u + 16.  Every global access
                 // of the step is issued unconditionally (an off-grid lane reads the subgrid's first sample, parks it in a
                 // slot nobody reads and stores to `sink`): with a load or store under a branch the compiler cannot count
                 // the accesses in flight and waits for ALL of them (s_waitcnt vmcnt(0)) before it parks a residual
@@ -1452,7 +1477,7 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
             }
             uint32_t r, ux;
             S st_value = 0;
-            GlobalPtr<S> st_ptr = as_global((S*)a.sink + lane);
+            GlobalPtr<S> st_ptr = as_global((S*)a.sink + lane * 4 + 3);
             if (where(u, &r, &ux)) {
                 const int32_t x = (int32_t)ux;
                 const int32_t gwi = (int32_t)gw;
@@ -1553,7 +1578,16 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
                 nw = r == 0 ? sample : n;
                 n = r == 0 ? sample : p_ne;
             }
-            *st_ptr = st_value;
+            if constexpr (VEC) {
+                sbuf.s[j & 3] = st_value;
+                if ((j & 3) == 3) {
+                    // columns x - 3 .. x of one row (or the sink: a lane is on the grid for all four steps of a group or none)
+                    const GlobalPtr<S> g4 = st_ptr - 3;
+                    *reinterpret_cast<GlobalPtr<V4>>(g4) = sbuf.v;
+                }
+            } else {
+                *st_ptr = st_value;
+            }
             lds_step_boundary();
         }
         if (__builtin_amdgcn_ballot_w64(out_of_range) != 0) {
@@ -1878,6 +1912,8 @@ struct ModularState {
     PredWave* pred_waves = nullptr;            // lane-packed launch: one entry per wave
     PredSrc* pred_srcs = nullptr;              // per subgrid: its residuals in the read-only upload
     uint32_t* pred_flags = nullptr;            // per wave: left the 32-bit range (redone by the 64-bit kernel)
+    void* pred_sink = nullptr;                 // 1 KB nobody reads: where off-grid lanes store
+    uint32_t n_pred_vec_waves = 0;             // the first so many waves take four-sample accesses
     bool pred_narrow = false;
     float* fpix[3] = {};
 };
@@ -2159,10 +2195,16 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             auto lanes_of = [&](const PredTile& t) { return std::min(64u, std::max(1u, pow2ceil(t.gw) / 4)); };
             auto dp_of = [&](const PredTile& t) { return std::max(4 * lanes_of(t), pow2ceil(t.gw)); };
             auto steps_of = [&](const PredTile& t) { return t.packed ? t.gw + (dp_of(t) / lanes_of(t)) * (t.gh - 1) : t.gw + 3 * (t.gh - 1); };
-            // wide subgrids first (own launch), then the lane-packed ones by (P, DP), longest chains first inside a class
+            // four-sample accesses: both copies of the subgrid aligned to four samples, rows too, width a multiple of four
+            auto vec_of = [&](const PredTile& t) {
+                const uintptr_t al = 4 * esz;
+                return (uintptr_t)t.base % al == 0 && (uintptr_t)tile_src[t.base] % al == 0 && t.stride % 4 == 0 && t.gw % 4 == 0;
+            };
+            // wide subgrids first (own launch), then the lane-packed ones by (vec, P, DP), longest chains first inside a class
             std::stable_sort(tiles.begin(), tiles.end(), [&](const PredTile& x, const PredTile& y) {
                 if (x.packed != y.packed) return x.packed < y.packed;
                 if (x.packed) {
+                    if (vec_of(x) != vec_of(y)) return vec_of(x) > vec_of(y);
                     if (lanes_of(x) != lanes_of(y)) return lanes_of(x) > lanes_of(y);
                     if (dp_of(x) != dp_of(y)) return dp_of(x) > dp_of(y);
                 }
@@ -2175,16 +2217,22 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             for (uint32_t i = n_wide; i < tiles.size();) {
                 const uint32_t P = lanes_of(tiles[i]), DP = dp_of(tiles[i]), T = 64 / P;
                 PredWave w{};
-                w.first = i; w.log2p = log2u(P); w.log2dp = log2u(DP);
-                while (i < tiles.size() && w.count < T && lanes_of(tiles[i]) == P && dp_of(tiles[i]) == DP) {
+                w.first = i; w.log2p = log2u(P); w.log2dp = log2u(DP); w.vec = vec_of(tiles[i]) ? 1u : 0u;
+                while (i < tiles.size() && w.count < T && lanes_of(tiles[i]) == P && dp_of(tiles[i]) == DP &&
+                       (vec_of(tiles[i]) ? 1u : 0u) == w.vec) {
                     w.steps = std::max(w.steps, steps_of(tiles[i]));
                     ++w.count; ++i;
                 }
                 if (DP > 256) lane_err_w = 512;
                 waves.push_back(w);
             }
-            // longest waves first
-            std::stable_sort(waves.begin(), waves.end(), [](const PredWave& x, const PredWave& y) { return x.steps > y.steps; });
+            // the four-sample waves first (a launch of their own), longest waves first inside each part
+            std::stable_sort(waves.begin(), waves.end(), [](const PredWave& x, const PredWave& y) {
+                if (x.vec != y.vec) return x.vec > y.vec;
+                return x.steps > y.steps;
+            });
+            m->n_pred_vec_waves = 0;
+            for (const PredWave& w : waves) m->n_pred_vec_waves += w.vec;
             m->n_pred_tiles = (uint32_t)tiles.size();
             m->n_pred_wide = n_wide;
             m->n_pred_waves = (uint32_t)waves.size();
@@ -2199,8 +2247,8 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             if (int rc = malloc_dev(ctx, f, &m->pred_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(PredTile))) return rc;
             if (int rc = malloc_dev(ctx, f, &m->pred_waves, std::max<size_t>(waves.size(), 1) * sizeof(PredWave))) return rc;
             if (int rc = malloc_dev(ctx, f, &m->pred_srcs, std::max<size_t>(srcs.size(), 1) * sizeof(PredSrc))) return rc;
-            // (+ 64 words behind the flags: the store sink of off-grid lanes)
-            if (int rc = malloc_dev(ctx, f, &m->pred_flags, (std::max<size_t>(waves.size(), 1) + 64) * sizeof(uint32_t))) return rc;
+            if (int rc = malloc_dev(ctx, f, &m->pred_flags, std::max<size_t>(waves.size(), 1) * sizeof(uint32_t))) return rc;
+            if (int rc = malloc_dev(ctx, f, &m->pred_sink, 1024)) return rc;
             // blocking copies from the host vectors: the lists are built once per frame (the geometry never changes)
             if (!tiles.empty()) {
                 HIP_TRY(ctx, hipMemcpy(m->pred_tiles, tiles.data(), tiles.size() * sizeof(PredTile), hipMemcpyHostToDevice));
@@ -2219,7 +2267,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
         }
         if (m->n_pred_tiles) {
             PredArgs pa;
-            pa.tiles = m->pred_tiles; pa.sink = m->pred_flags + std::max<uint32_t>(m->n_pred_waves, 1); pa.predictor = m->desc.residual_predictor;
+            pa.tiles = m->pred_tiles; pa.sink = m->pred_sink; pa.predictor = m->desc.residual_predictor;
             pa.mul = m->desc.residual_multiplier; pa.off = m->desc.residual_offset;
             for (int k = 0; k < 11; ++k) pa.wp[k] = m->desc.wp_params[k];
             if (m->n_pred_wide) {
@@ -2234,11 +2282,14 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 if (m->pred_narrow) {
                     // 32-bit pass over everything, then the 64-bit kernel for the waves that left the 32-bit range (none, for
                     // images of up to 16 bits)
+                    const uint32_t nv = m->n_pred_vec_waves, ns = m->n_pred_waves - nv;
                     if (i16) {
-                        predict_lanes_narrow_kernel<int16_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                        if (nv) predict_lanes_narrow_kernel<int16_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                        if (ns) predict_lanes_narrow_kernel<int16_t, false><<<ns, 64, lds, s>>>(pa, m->pred_waves + nv, m->pred_srcs, m->pred_flags + nv);
                         predict_lanes_kernel<int16_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
                     } else {
-                        predict_lanes_narrow_kernel<int32_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                        if (nv) predict_lanes_narrow_kernel<int32_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                        if (ns) predict_lanes_narrow_kernel<int32_t, false><<<ns, 64, lds, s>>>(pa, m->pred_waves + nv, m->pred_srcs, m->pred_flags + nv);
                         predict_lanes_kernel<int32_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
                     }
                     if (ctx->tune.debug_sync) {
