@@ -333,7 +333,9 @@ def make_job(config, distinct, transport="grouped"):
 
     def pmc_traffic(pattern_names):
         def fn(dominant, frames_per_launch):
-            src = os.path.join("profiles", "r02_pmc_hbm_traffic.json")
+            src = os.path.join("profiles", "r03_pmc_hbm_traffic.json")
+            if not os.path.exists(os.path.join(ROOT, src)):
+                src = os.path.join("profiles", "r02_pmc_hbm_traffic.json")
             try:
                 pmc = json.load(open(os.path.join(ROOT, src)))
                 kb = 0.0

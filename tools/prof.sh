@@ -1,5 +1,5 @@
 #!/bin/bash
-# The rocprofv3 invocations behind profiles/r02_* (run on the GPU box from the repo root, e.g. through
+# The rocprofv3 invocations behind profiles/r02_* / r03_* (run on the GPU box from the repo root, e.g. through
 # gpurun).  Counters are collected in their own passes with --kernel-trace only.
 #   tools/prof.sh stats   -> per-kernel durations of the headline bench (the driver's command)
 #   tools/prof.sh hbm     -> FETCH_SIZE / WRITE_SIZE (two passes) of the bench (8 frames) AND of
@@ -18,6 +18,8 @@ case "$1" in
          timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/probe_fetch" -- $R/tools/_mem_probe
          timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/probe_write" -- $R/tools/_mem_probe ;;
   sq)    timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d "$OUT" -- $BENCH_SHORT ;;
-  *) echo "usage: $0 stats|hbm|sq"; exit 2 ;;
+  clk)   # GRBM_GUI_ACTIVE = cycles the GPU was busy during the dispatch: / duration = the clock the kernel really ran at
+         timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-trace --output-format csv -d "$OUT" -- $BENCH_SHORT ;;
+  *) echo "usage: $0 stats|hbm|sq|clk"; exit 2 ;;
 esac
 find "$OUT" -name "*.csv" | head -3
