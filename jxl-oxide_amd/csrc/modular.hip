@@ -2283,15 +2283,27 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     // 32-bit pass over everything, then the 64-bit kernel for the waves that left the 32-bit range (none, for
                     // images of up to 16 bits)
                     const uint32_t nv = m->n_pred_vec_waves, ns = m->n_pred_waves - nv;
-                    if (i16) {
-                        if (nv) predict_lanes_narrow_kernel<int16_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
-                        if (ns) predict_lanes_narrow_kernel<int16_t, false><<<ns, 64, lds, s>>>(pa, m->pred_waves + nv, m->pred_srcs, m->pred_flags + nv);
-                        predict_lanes_kernel<int16_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
-                    } else {
-                        if (nv) predict_lanes_narrow_kernel<int32_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
-                        if (ns) predict_lanes_narrow_kernel<int32_t, false><<<ns, 64, lds, s>>>(pa, m->pred_waves + nv, m->pred_srcs, m->pred_flags + nv);
-                        predict_lanes_kernel<int32_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                    // the few waves of misaligned subgrids (deep Squeeze levels: long chains, three waves of an 8K frame)
+                    // run beside the others on the side stream instead of behind them
+                    const bool side = nv && ns;
+                    hipStream_t s2 = side ? ctx->stream2 : s;
+                    if (side) {
+                        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+                        HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
                     }
+                    if (i16) {
+                        if (ns) predict_lanes_narrow_kernel<int16_t, false><<<ns, 64, lds, s2>>>(pa, m->pred_waves + nv, m->pred_srcs, m->pred_flags + nv);
+                        if (nv) predict_lanes_narrow_kernel<int16_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                    } else {
+                        if (ns) predict_lanes_narrow_kernel<int32_t, false><<<ns, 64, lds, s2>>>(pa, m->pred_waves + nv, m->pred_srcs, m->pred_flags + nv);
+                        if (nv) predict_lanes_narrow_kernel<int32_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                    }
+                    if (side) {
+                        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, s2));
+                        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+                    }
+                    if (i16) predict_lanes_kernel<int16_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                    else predict_lanes_kernel<int32_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
                     if (ctx->tune.debug_sync) {
                         std::vector<uint32_t> fl(m->n_pred_waves);
                         HIP_TRY(ctx, hipStreamSynchronize(s));
