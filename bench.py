@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GINSTR = 614.4    # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 f32 instruction (profiles/r01_pk_probe.txt)
 # static VALU count of one row step of the streaming post kernel and its strip width (tools/isa_blocks.sh):
 # packed kernel (two columns per lane, the default) / scalar kernel (JXLGPU_NO_PK)
-POST_VALU_PER_ROW, POST_STRIP = (354, 56) if os.environ.get("JXLGPU_NO_PK") else (424, 120)
+POST_VALU_PER_ROW, POST_STRIP = (354, 56) if os.environ.get("JXLGPU_NO_PK") else (428, 120)
 POST_ROWS_PER_SEG, POST_HALO_ROWS = int(os.environ.get("JXLGPU_BATCH_STREAM_ROWS", "96")), 8
 
 
