@@ -1156,7 +1156,8 @@ struct PredSrc {
 
 // `srcs` / `wave_flags` non-null: the redo pass behind predict_lanes_narrow_kernel — only flagged waves run, and
 // they read the residuals from `srcs` (the narrow pass has written over `base`).
-template <typename S>
+// VEC: four-sample global accesses, as in predict_lanes_narrow_kernel below.
+template <typename S, bool VEC>
 __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const PredWave* waves, const PredSrc* srcs,
                                                            const uint32_t* wave_flags) {
     if (wave_flags && wave_flags[blockIdx.x] == 0) return;
@@ -1196,6 +1197,13 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
     int32_t te_w = 0, te_nw = 0, te_n = 0, te_ne = 0;
     uint32_t se_nw_ww[4] = {0, 0, 0, 0}, se_n_w[4] = {0, 0, 0, 0}, se_ne[4] = {0, 0, 0, 0};
     int32_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    typedef uint32_t RawV2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t RawV4 __attribute__((ext_vector_type(4)));
+    using V4 = typename std::conditional<sizeof(S) == 2, RawV2, RawV4>::type;
+    union Pack4 { V4 v; S s[4]; };
+    Pack4 pfv[2], sbuf;
+    pfv[0].v = pfv[1].v = V4{};
+    sbuf.v = V4{};
     const int32_t steps = (int32_t)wv.steps;
     const int32_t u0 = -D * (int32_t)k;
     // the element at stream position q: round q >> log2dp, column q & (DP - 1); inside the subgrid?
@@ -1208,7 +1216,15 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int32_t u = u0 + s0 + j;
-            {   // residual pipeline: park what arrived for position u + 8, request position u + 16.  Every global access
+            if constexpr (VEC) {
+                if ((j & 3) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s_in[lane][(u + 8 + i) & (kRing - 1)] = (int32_t)pfv[j >> 2].s[i];
+                    uint32_t rq, xq;
+                    const bool ahead = where(u + 16, &rq, &xq);
+                    pfv[j >> 2].v = *reinterpret_cast<GlobalPtr<const V4>>(src + (ahead ? (size_t)rq * t.stride + xq : (size_t)0));
+                }
+            } else {   // residual pipeline: park what arrived for position u + 8, request position u + 16.  Every global access
                 // of the step is issued unconditionally (an off-grid lane reads the subgrid's first sample, parks it in a
                 // slot nobody reads and stores to `sink`): with a load or store under a branch the compiler cannot count
                 // the accesses in flight and waits for ALL of them (s_waitcnt vmcnt(0)) before it parks a residual
@@ -1219,7 +1235,7 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
             }
             uint32_t r, ux;
             S st_value = 0;
-            GlobalPtr<S> st_ptr = as_global((S*)a.sink + lane);
+            GlobalPtr<S> st_ptr = as_global((S*)a.sink + lane * 4 + 3);
             if (where(u, &r, &ux)) {
                 const int32_t x = (int32_t)ux;
                 const uint32_t round = (uint32_t)u >> log2dp;
@@ -1372,7 +1388,15 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
                     }
                 }
             }
-            *st_ptr = st_value;
+            if constexpr (VEC) {
+                sbuf.s[j & 3] = st_value;
+                if ((j & 3) == 3) {
+                    const GlobalPtr<S> g4 = st_ptr - 3;
+                    *reinterpret_cast<GlobalPtr<V4>>(g4) = sbuf.v;
+                }
+            } else {
+                *st_ptr = st_value;
+            }
             lds_step_boundary();
         }
     }
@@ -2302,8 +2326,14 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                         HIP_TRY(ctx, hipEventRecord(ctx->ev_join, s2));
                         HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
                     }
-                    if (i16) predict_lanes_kernel<int16_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
-                    else predict_lanes_kernel<int32_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                    // the 64-bit kernel for the waves that left the 32-bit range (none, for images of up to 16 bits)
+                    if (i16) {
+                        if (nv) predict_lanes_kernel<int16_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                        if (ns) predict_lanes_kernel<int16_t, false><<<ns, 64, lds, s>>>(pa, m->pred_waves + nv, m->pred_srcs, m->pred_flags + nv);
+                    } else {
+                        if (nv) predict_lanes_kernel<int32_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                        if (ns) predict_lanes_kernel<int32_t, false><<<ns, 64, lds, s>>>(pa, m->pred_waves + nv, m->pred_srcs, m->pred_flags + nv);
+                    }
                     if (ctx->tune.debug_sync) {
                         std::vector<uint32_t> fl(m->n_pred_waves);
                         HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -2313,8 +2343,15 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                         fprintf(stderr, "predictor waves redone in 64-bit arithmetic: %zu of %u\n", nfl, m->n_pred_waves);
                     }
                 } else {
-                    if (i16) predict_lanes_kernel<int16_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, nullptr, nullptr);
-                    else predict_lanes_kernel<int32_t><<<m->n_pred_waves, 64, lds, s>>>(pa, m->pred_waves, nullptr, nullptr);
+                    // any other predictor (or JXLGPU_PRED_WIDE): in place on the working copy
+                    const uint32_t nv = m->n_pred_vec_waves, ns = m->n_pred_waves - nv;
+                    if (i16) {
+                        if (nv) predict_lanes_kernel<int16_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, nullptr, nullptr);
+                        if (ns) predict_lanes_kernel<int16_t, false><<<ns, 64, lds, s>>>(pa, m->pred_waves + nv, nullptr, nullptr);
+                    } else {
+                        if (nv) predict_lanes_kernel<int32_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, nullptr, nullptr);
+                        if (ns) predict_lanes_kernel<int32_t, false><<<ns, 64, lds, s>>>(pa, m->pred_waves + nv, nullptr, nullptr);
+                    }
                 }
             }
         }
