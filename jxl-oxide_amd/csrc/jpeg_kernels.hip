@@ -15,10 +15,13 @@ struct UpJpegArgs {
     float* out;
     uint32_t in_w8, c, in_w, in_h, out_stride, width, height;
     int hshift, vshift;
+    uint32_t in_row_stride;   // > 0: `in` is a row-major plane of this stride (Modular frames) instead of the tiled transform output
 };
 
 __device__ __forceinline__ float h_value(const UpJpegArgs& a, uint32_t x, uint32_t row) {
-    auto r = [&](uint32_t xi) { return a.in[coeff_tiled_index(xi, row, a.c, a.in_w8)]; };
+    auto r = [&](uint32_t xi) {
+        return a.in_row_stride ? a.in[(size_t)row * a.in_row_stride + xi] : a.in[coeff_tiled_index(xi, row, a.c, a.in_w8)];
+    };
     if (!a.hshift) return r(x);
     const uint32_t i = x >> 1;
     const float curr = r(i);
@@ -54,6 +57,13 @@ __global__ __launch_bounds__(256) void upsample_jpeg_kernel(UpJpegArgs a) {
 
 void launch_upsample_jpeg(hipStream_t s, const float* in_tiled, uint32_t in_w8, uint32_t c, uint32_t in_w, uint32_t in_h,
                           int hshift, int vshift, float* out, uint32_t out_stride, uint32_t width, uint32_t height) {
-    UpJpegArgs a{in_tiled, out, in_w8, c, in_w, in_h, out_stride, width, height, hshift, vshift};
+    UpJpegArgs a{in_tiled, out, in_w8, c, in_w, in_h, out_stride, width, height, hshift, vshift, 0u};
+    hipLaunchKernelGGL(upsample_jpeg_kernel, dim3((width + 255) / 256, height), dim3(256), 0, s, a);
+}
+
+// The same for a row-major input plane (chroma-subsampled Modular frames).
+void launch_upsample_jpeg_rows(hipStream_t s, const float* in, uint32_t in_stride, uint32_t in_w, uint32_t in_h, int hshift, int vshift,
+                               float* out, uint32_t out_stride, uint32_t width, uint32_t height) {
+    UpJpegArgs a{in, out, 0u, 0u, in_w, in_h, out_stride, width, height, hshift, vshift, in_stride};
     hipLaunchKernelGGL(upsample_jpeg_kernel, dim3((width + 255) / 256, height), dim3(256), 0, s, a);
 }

@@ -35,6 +35,8 @@ int finish_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stri
 int upload_post_params(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuUpsampling& up);
 void fill_color_args_public(const JxlGpuColorParams& cp, ColorArgs* c);
 const char* color_params_unsupported(const JxlGpuColorParams& cp);
+void launch_upsample_jpeg_rows(hipStream_t s, const float* in, uint32_t in_stride, uint32_t in_w, uint32_t in_h, int hshift, int vshift,
+                               float* out, uint32_t out_stride, uint32_t width, uint32_t height);
 
 namespace {
 
@@ -1845,6 +1847,7 @@ struct ToFloatArgs {
     const void* in[3];
     float* out[3];
     uint32_t in_stride[3], out_stride, width, height;
+    uint32_t cw[3], ch[3];   // per-channel sizes (chroma-subsampled frames: smaller than width x height)
     uint32_t xyb, is_i16, bit_depth, float_sample, exp_bits;
     float m[3];
 };
@@ -1855,10 +1858,12 @@ __global__ __launch_bounds__(256) void to_float_kernel(ToFloatArgs a) {
     uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= a.width) return;
     int32_t v[3];
+    bool in_c[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
+        in_c[c] = x < a.cw[c] && y < a.ch[c];
         size_t i = (size_t)y * a.in_stride[c] + x;
-        v[c] = a.is_i16 ? (int32_t)((const int16_t*)a.in[c])[i] : ((const int32_t*)a.in[c])[i];
+        v[c] = !in_c[c] ? 0 : (a.is_i16 ? (int32_t)((const int16_t*)a.in[c])[i] : ((const int32_t*)a.in[c])[i]);
     }
     size_t o = (size_t)y * a.out_stride + x;
     if (a.xyb) {
@@ -1892,7 +1897,7 @@ __global__ __launch_bounds__(256) void to_float_kernel(ToFloatArgs a) {
                 else if (mantissa_bits > 23) mantissa >>= (mantissa_bits - 23);
                 r = __uint_as_float((is_signed << 31) | ((uint32_t)(exp + 127) << 23) | mantissa);
             }
-            a.out[c][o] = r;
+            if (in_c[c]) a.out[c][o] = r;
         }
     }
 }
@@ -2625,8 +2630,13 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
     }
 
     // geometry of the colour image for the float tail
+    // the colour channels of a chroma-subsampled frame (do_ycbcr + jpeg_upsampling) differ in size: the frame is the largest
     f->width = d->channels[0].width;
     f->height = d->channels[0].height;
+    for (uint32_t c = 1; c < std::min<uint32_t>(d->num_color_channels == 1 ? 1u : 3u, d->num_channels); ++c) {
+        f->width = std::max(f->width, d->channels[c].width);
+        f->height = std::max(f->height, d->channels[c].height);
+    }
     // several per-row kernels launch one grid row per image row (HIP: grid.y <= 65535)
     if ((uint64_t)f->height * (d->upsampling.factor ? d->upsampling.factor : 1) > 65535u)
         return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "output taller than 65535 rows");
@@ -2699,8 +2709,20 @@ static int modular_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages
     ModularState* m = static_cast<ModularState*>(f->modular);
     // grayscale (render.rs:74-134): the one colour channel feeds all three filter inputs; plane 0 is the result
     const bool gray = m->desc.num_color_channels == 1;
-    for (int c = 1; c < 3 && !gray; ++c)
-        if (m->cw[c] != m->cw[0] || m->ch[c] != m->ch[0]) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "subsampled colour channels");
+    // chroma-subsampled colour channels (frame_header.do_ycbcr + jpeg_upsampling on a Modular frame): int -> float per
+    // channel at its own size, then ImageWithRegion::upsample_jpeg (image.rs:448-485) as for the VarDCT JPEG path
+    int hs[3] = {0, 0, 0}, vs[3] = {0, 0, 0};
+    bool subsampled = false;
+    for (int c = 0; c < 3 && !gray; ++c) {
+        if (m->cw[c] == f->width && m->ch[c] == f->height) continue;
+        hs[c] = m->cw[c] != f->width; vs[c] = m->ch[c] != f->height;
+        if ((hs[c] && m->cw[c] != (f->width + 1) / 2) || (vs[c] && m->ch[c] != (f->height + 1) / 2))
+            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "colour channel size is neither the frame's nor half of it");
+        subsampled = true;
+    }
+    if (subsampled && (m->desc.xyb_encoded || !m->desc.color.ycbcr))
+        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "subsampled colour channels need a YCbCr frame (color.ycbcr, not XYB)");
+    if (subsampled && region_in) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "region render of a chroma-subsampled Modular frame");
     if (gray) stages &= ~(uint32_t)JXLGPU_STAGE_NOISE;  // render.rs:208-221: "Cannot render noise on grayscale buffer; skipping"
     if (!(stages & JXLGPU_STAGE_MODULAR_TO_FLOAT)) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "render needs JXLGPU_STAGE_MODULAR_TO_FLOAT");
     ctx->prof_begin(PROF_MODULAR);
@@ -2712,13 +2734,17 @@ static int modular_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages
         const int src = gray ? 0 : c;
         a.in[c] = m->work[m->final_loc[src]][src];
         a.in_stride[c] = m->cw[src];
-        a.out[c] = m->fpix[c];
+        a.cw[c] = m->cw[src]; a.ch[c] = m->ch[src];
+        a.out[c] = (hs[c] || vs[c]) ? f->buf_a[c] : m->fpix[c];   // a subsampled channel is upsampled into fpix below
         a.m[c] = m->desc.m_lf_unscaled[c];
     }
     a.out_stride = f->wr; a.width = f->width; a.height = f->height;
     a.xyb = m->desc.xyb_encoded; a.is_i16 = m->desc.sample_type == JXLGPU_SAMPLE_I16;
     a.bit_depth = m->desc.bit_depth; a.float_sample = m->desc.float_sample; a.exp_bits = m->desc.exp_bits;
     to_float_kernel<<<dim3(ceil_div(f->width, 256), f->height), 256, 0, ctx->stream>>>(a);
+    for (int c = 0; c < 3 && subsampled; ++c)
+        if (hs[c] || vs[c])
+            launch_upsample_jpeg_rows(ctx->stream, f->buf_a[c], f->wr, m->cw[c], m->ch[c], hs[c], vs[c], m->fpix[c], f->wr, f->width, f->height);
     float* cur[3] = {m->fpix[0], m->fpix[1], m->fpix[2]};
     uint32_t stride = f->wr, ow = f->width, oh = f->height;
     ctx->prof_begin(PROF_POST);

@@ -555,6 +555,16 @@ class ModularWorkload:
                 residuals_in_place(bufs, [], grids, 0, group_dim, residual, pred_offset)
                 self.residual_predictor, self.residual_offset = residual, pred_offset
             self.buffers = [b.astype(self.dtype) for b in bufs]
+        elif kind in ("ycbcr420", "ycbcr422", "ycbcr440", "ycbcr444"):
+            # frame_header.do_ycbcr on a Modular frame with jpeg_upsampling: channels Cb, Y, Cr, chroma subsampled;
+            # plain 8-bit samples (centred chroma), no transforms
+            sh = {"ycbcr420": (1, 1), "ycbcr422": (1, 0), "ycbcr440": (0, 1), "ycbcr444": (0, 0)}[kind]
+            cw, ch = (W + 1) // 2 if sh[0] else W, (H + 1) // 2 if sh[1] else H
+            yv = np.clip(base[0], 0, 255) - 128
+            cb = (np.clip(base[1], 0, 255) - 128)[:ch, :cw]
+            cr = (np.clip(base[2], 0, 255) - 128)[:ch, :cw]
+            self.buffers = [np.ascontiguousarray(cb.astype(self.dtype)), yv.astype(self.dtype), np.ascontiguousarray(cr.astype(self.dtype))]
+            self.ycbcr = True
         elif kind == "raw":
             # arbitrary data straight into the inverse chain: wrapping arithmetic included
             info = np.iinfo(self.dtype)
@@ -631,6 +641,8 @@ class ModularWorkload:
         d.filter = self.filter
         d.upsampling.factor = 1
         d.color = self.color
+        if getattr(self, "ycbcr", False):
+            d.color.ycbcr = 1
         d.noise = getattr(self, "noise", abi.NoiseParams())
         self._keep = [chans, metas, trs]
         return d

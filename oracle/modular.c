@@ -557,6 +557,9 @@ static float parse_integer_sample(const JxlGpuModularDesc* d, int32_t sample) {
     return f;
 }
 
+void orc_upsample_jpeg(const float* in, size_t in_stride, size_t in_w, size_t in_h, int hshift, int vshift,
+                       float* out, size_t target_width, size_t target_height);
+
 /* Whole Modular render: inverse transforms, int -> float (image.rs:93-189), then the shared
  * Gabor / EPF / upsampling / colour tail.  The first three channels are the colour channels
  * (Modular order: for XYB that is Y, X, B; image.rs:148-189 swaps Y/X into framebuffer order). */
@@ -571,8 +574,19 @@ int jxl_oracle_modular_render(const JxlGpuModularDesc* d, uint32_t stages, float
     if (gray) stages &= ~(uint32_t)JXLGPU_STAGE_NOISE;
     size_t esz = d->sample_type == JXLGPU_SAMPLE_I16 ? 2 : 4;
     uint32_t W = d->channels[0].width, H = d->channels[0].height;
-    for (int c = 1; c < 3 && !gray; ++c)
-        if (d->channels[c].width != W || d->channels[c].height != H) return JXLGPU_ERR_UNSUPPORTED;
+    /* chroma-subsampled colour channels (do_ycbcr + jpeg_upsampling): the frame is the largest channel; the others are
+     * converted at their own size and go through upsample_jpeg (jxl-render/src/image.rs:448-485, render.rs:70-72) */
+    int hs[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, subsampled = 0;
+    for (int c = 1; c < 3 && !gray; ++c) {
+        if (d->channels[c].width > W) W = d->channels[c].width;
+        if (d->channels[c].height > H) H = d->channels[c].height;
+    }
+    for (int c = 0; c < 3 && !gray; ++c) {
+        hs[c] = d->channels[c].width != W; vs[c] = d->channels[c].height != H;
+        if ((hs[c] && d->channels[c].width != (W + 1) / 2) || (vs[c] && d->channels[c].height != (H + 1) / 2)) return JXLGPU_ERR_INVALID_ARG;
+        subsampled |= hs[c] | vs[c];
+    }
+    if (subsampled && (d->xyb_encoded || !d->color.ycbcr)) return JXLGPU_ERR_INVALID_ARG;
     void** planes = (void**)calloc(d->num_channels, sizeof(void*));
     for (uint32_t c = 0; c < d->num_channels; ++c)
         planes[c] = malloc((size_t)d->channels[c].width * d->channels[c].height * esz);
@@ -596,8 +610,18 @@ int jxl_oracle_modular_render(const JxlGpuModularDesc* d, uint32_t stages, float
                 pix[2][i] = pb * d->m_lf_unscaled[2];
             }
         } else {
-            for (int c = 0; c < 3; ++c)
-                for (size_t i = 0; i < n; ++i) pix[c][i] = parse_integer_sample(d, SAMPLE(gray ? 0 : c, i));
+            for (int c = 0; c < 3; ++c) {
+                const int sc = gray ? 0 : c;
+                const size_t cw = d->channels[sc].width, chh = d->channels[sc].height;
+                if (!(hs[c] || vs[c])) {
+                    for (size_t i = 0; i < n; ++i) pix[c][i] = parse_integer_sample(d, SAMPLE(sc, i));
+                } else {
+                    float* small = (float*)malloc(sizeof(float) * cw * chh);
+                    for (size_t i = 0; i < cw * chh; ++i) small[i] = parse_integer_sample(d, SAMPLE(sc, i));
+                    orc_upsample_jpeg(small, cw, cw, chh, hs[c], vs[c], pix[c], W, H);
+                    free(small);
+                }
+            }
         }
 #undef SAMPLE
         if (!(stages & JXLGPU_STAGE_MODULAR_TO_FLOAT)) rc = JXLGPU_ERR_INVALID_ARG;

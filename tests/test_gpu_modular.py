@@ -290,6 +290,25 @@ def test_grayscale_frames(gpu_ctx, oracle, case, i16):
     assert np.array_equal(got_reg[0].view(np.uint32), exp[0][reg[1]:reg[1] + reg[3], reg[0]:reg[0] + reg[2]].view(np.uint32))
 
 
+@pytest.mark.parametrize("kind", ["ycbcr420", "ycbcr422", "ycbcr440", "ycbcr444"])
+@pytest.mark.parametrize("case", [dict(), dict(gabor=True, epf_iters=2)])
+@pytest.mark.parametrize("size", [(300, 270), (301, 271)])
+def test_chroma_subsampled_ycbcr_frames(gpu_ctx, oracle, kind, case, size):
+    """do_ycbcr Modular frames with jpeg_upsampling (jxl-render/src/render.rs:70-72, image.rs:448-485): colour channels
+    Cb, Y, Cr of different sizes — int -> float per channel at its own size, upsample_jpeg, filters, ycbcr_to_rgb."""
+    w, h = size
+    wl = ModularWorkload(w, h, kind=kind, i16=True, seed=5, xyb=False, **case)
+    d = wl.desc()
+    stages = abi.STAGE_ALL | abi.STAGE_MODULAR_TO_FLOAT
+    exp = oracle.modular_render(d, stages, w, h)
+    f = gpu_ctx.modular_upload(d)
+    try:
+        got = gpu_ctx.modular_render(f, stages)
+    finally:
+        f.free()
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
 def test_squeeze_fixup_path(oracle):
     """Without the run-in the guessed carries are usually wrong: the check kernel must catch every
     broken link and redo those lines serially.  Runs in a child process (the switches are read once

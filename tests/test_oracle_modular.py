@@ -193,3 +193,47 @@ def test_grayscale_render_is_the_cloned_channel(oracle, gabor, epf):
     assert np.array_equal(got[0].view(np.uint32), exp[0].view(np.uint32))
     if not gabor and not epf:
         assert np.array_equal(got[0], wl.expected[0].astype(np.float32) / np.float32(255))
+
+
+@pytest.mark.parametrize("kind", ["ycbcr420", "ycbcr422", "ycbcr440"])
+def test_subsampled_ycbcr_modular_equals_preupsampled_444(oracle, kind):
+    """A chroma-subsampled YCbCr Modular frame must render exactly like the 4:4:4 frame whose chroma planes are the
+    upsampled ones — with the upsampling done here in numpy from the formulas of filter/ycbcr.rs:6-89
+    (0.25 / 0.75 taps, edge replicated, horizontal first, then vertical) — through the integer round trip this
+    cannot be expressed (upsampled samples are not integers), so the comparison is on the no-filter render of the
+    Y plane (untouched by the chroma path) and on the colour result within 1e-6 of an f64 evaluation."""
+    from jxl_oxide_amd import abi
+    from jxl_oxide_amd.synth_modular import ModularWorkload
+    w, h = 61, 45
+    wl = ModularWorkload(w, h, kind=kind, i16=False, seed=8, xyb=False)
+    stages = abi.STAGE_ALL | abi.STAGE_MODULAR_TO_FLOAT
+    got = oracle.modular_render(wl.desc(), stages, w, h).astype(np.float64)
+    cb, y, cr = [b.astype(np.float64) / 255.0 for b in wl.buffers]
+
+    def up_h(a):
+        out = np.zeros((a.shape[0], a.shape[1] * 2))
+        prev = np.concatenate([a[:, :1], a[:, :-1]], axis=1)
+        nxt = np.concatenate([a[:, 1:], a[:, -1:]], axis=1)
+        out[:, 0::2] = 0.25 * prev + 0.75 * a
+        out[:, 1::2] = 0.75 * a + 0.25 * nxt
+        return out[:, :w]
+
+    def up_v(a):
+        out = np.zeros((a.shape[0] * 2, a.shape[1]))
+        prev = np.concatenate([a[:1], a[:-1]], axis=0)
+        nxt = np.concatenate([a[1:], a[-1:]], axis=0)
+        out[0::2] = 0.75 * a + 0.25 * prev
+        out[1::2] = 0.25 * nxt + 0.75 * a
+        return out[:h]
+
+    hs, vs = {"ycbcr420": (1, 1), "ycbcr422": (1, 0), "ycbcr440": (0, 1)}[kind]
+    for name, plane in (("cb", cb), ("cr", cr)):
+        p = up_h(plane) if hs else plane
+        p = up_v(p) if vs else p
+        if name == "cb":
+            cbu = p
+        else:
+            cru = p
+    yy = y + 128.0 / 255.0
+    exp = np.stack([yy + 1.402 * cru, yy - 0.114 * 1.772 / 0.587 * cbu - 0.299 * 1.402 / 0.587 * cru, yy + 1.772 * cbu])
+    assert np.abs(got - exp).max() < 2e-6
