@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Randomised geometry sweep, device against oracle, for the kernels whose work decomposition depends on the frame's
+shape (lane-packed predictor pass, lane-per-piece Squeeze, region renders, list-fed transforms): sizes, sample type,
+transform chain, predictor, filters drawn at random; every mismatch is printed with the parameters that reproduce it.
+
+    python tests/tools/fuzz_parity.py SECONDS [SEED]          (on an MI355X; uses the oracle: test infrastructure)
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+from jxl_oxide_amd import abi, runtime  # noqa: E402
+from jxl_oxide_amd.synth import VardctWorkload  # noqa: E402
+from jxl_oxide_amd.synth_modular import ModularWorkload  # noqa: E402
+from oracle import pyoracle  # noqa: E402
+
+
+def modular_case(rng):
+    kind = rng.choice(["squeeze", "squeeze", "squeeze", "palette", "gray", "raw", "lossless_rgb8", "ycbcr420", "ycbcr422"])
+    w = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 1100)]))
+    h = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 700)]))
+    kw = dict(kind=str(kind), i16=bool(rng.integers(0, 2)), seed=int(rng.integers(0, 1000)))
+    if kind == "squeeze":
+        kw["lossy"] = bool(rng.integers(0, 2))
+        kw["xyb"] = kw["lossy"]
+        if rng.random() < 0.6:
+            kw["residual"] = int(rng.choice([0, 1, 4, 5, 6, 6, 6, 7, 9, 12, 13]))
+    if kind in ("palette", "gray") and rng.random() < 0.5:
+        kw["residual"] = int(rng.choice([5, 6, 13]))
+    if kind.startswith("ycbcr"):
+        kw["xyb"] = False
+        w, h = max(w, 2), max(h, 2)
+    if kind == "raw":
+        w, h = max(w, 9), max(h, 9)
+    return w, h, kw
+
+
+def run_modular(ctx, rng):
+    w, h, kw = modular_case(rng)
+    wl = ModularWorkload(w, h, **kw)
+    d = wl.desc()
+    if kw["kind"].startswith("ycbcr"):
+        stages = abi.STAGE_ALL | abi.STAGE_MODULAR_TO_FLOAT
+        exp = pyoracle.modular_render(d, stages, w, h)
+        f = ctx.modular_upload(d)
+        try:
+            got = ctx.modular_render(f, stages)
+        finally:
+            f.free()
+        ok = np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    else:
+        exp = pyoracle.modular_inverse(d, wl.shapes(), wl.dtype)
+        f = ctx.modular_upload(d)
+        try:
+            got = ctx.modular_inverse(f, wl.shapes(), wl.dtype)
+        finally:
+            f.free()
+        ok = all(np.array_equal(g, e) for g, e in zip(got, exp))
+    return ok, ("modular", w, h, kw)
+
+
+def run_vardct(ctx, rng):
+    w = int(rng.integers(8, 900))
+    h = int(rng.integers(8, 600))
+    kw = dict(seed=int(rng.integers(0, 1000)), epf_iters=int(rng.integers(0, 4)), gabor=bool(rng.integers(0, 2)),
+              zero_fraction=float(rng.choice([0.0, 0.5, 0.85, 0.97])))
+    if rng.random() < 0.25:
+        kw["upsampling"] = int(rng.choice([2, 4, 8]))
+        w, h = min(w, 300), min(h, 200)
+    wl = VardctWorkload(w, h, **kw)
+    stages = abi.STAGE_ALL
+    ow, oh = wl.out_size(stages)
+    exp, _ = pyoracle.vardct_render(wl.desc(), stages, ow, oh)
+    transport = str(rng.choice(["grouped", "grouped", "dense_i32", "sparse_i16"]))
+    f = ctx.vardct_upload(wl.desc(coeff_transport=transport))
+    try:
+        got = ctx.vardct_render(f, stages)
+        ok = np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+        rx, ry = int(rng.integers(0, ow)), int(rng.integers(0, oh))
+        rw, rh = int(rng.integers(1, ow - rx + 1)), int(rng.integers(1, oh - ry + 1))
+        reg = ctx.vardct_render_region(f, stages, (rx, ry, rw, rh))
+        ok_r = np.array_equal(reg.view(np.uint32), np.ascontiguousarray(exp[:, ry:ry + rh, rx:rx + rw]).view(np.uint32))
+    finally:
+        f.free()
+    return ok and ok_r, ("vardct", w, h, dict(kw, transport=transport, region=(rx, ry, rw, rh), full_ok=bool(ok)))
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) & 0xFFFF
+    rng = np.random.default_rng(seed)
+    runtime.prime_gpu()
+    ctx = runtime.Context(0)
+    t_end = time.time() + seconds
+    n, bad = {"modular": 0, "vardct": 0}, []
+    while time.time() < t_end:
+        fn = run_modular if rng.random() < 0.65 else run_vardct
+        try:
+            ok, what = fn(ctx, rng)
+        except runtime.JxlGpuError as e:
+            # descriptors the library refuses are fine (the synthetic generator may draw them); anything else is a finding
+            if e.code == abi.ERR_UNSUPPORTED:
+                continue
+            ok, what = False, ("error", str(e))
+        n[what[0]] = n.get(what[0], 0) + 1
+        if not ok:
+            bad.append(what)
+            print("MISMATCH", what, flush=True)
+    ctx.close()
+    print(f"fuzz seed {seed}: {n} cases, {len(bad)} mismatches", flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
