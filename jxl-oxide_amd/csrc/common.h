@@ -176,7 +176,10 @@ struct FrameDev {
     FusedArgs post;
     uint32_t n_ring_tiles;
 };
-constexpr int JXLGPU_MAX_BATCH = 32;
+#ifndef JXLGPU_MAX_BATCH_N
+#define JXLGPU_MAX_BATCH_N 32
+#endif
+constexpr int JXLGPU_MAX_BATCH = JXLGPU_MAX_BATCH_N;
 struct FrameBatch {
     const FrameDev* f[JXLGPU_MAX_BATCH];
 };
