@@ -445,7 +445,9 @@ typedef struct {
      * pass-group tiles, or LF-group tiles once both shifts reach 3.  The channel buffers and the meta
      * channels hold the residuals of those transformed channels, carved as described above.  6 =
      * SelfCorrecting with `wp_params`.  MA trees with more than one leaf choose the entropy-coding
-     * context from the neighbours, so they stay with the entropy decoder on the host.  All channels
+     * context from the neighbours, so they stay with the entropy decoder on the host (a `SimpleMaTable`
+     * tree, image.rs:951-1166, whose one decision property is static — channel, stream, y, x — has one
+     * predictor / multiplier / offset for all leaves and IS a single leaf here).  All channels
      * have ChannelShift 0 (no extra-channel upsampling shifts).                                     */
     uint32_t residual_predictor;
     int32_t residual_multiplier; /* MaTreeLeafClustered.multiplier (1 for a default leaf)            */
