@@ -141,6 +141,145 @@ __global__ __launch_bounds__(256) void upsample2_stream_kernel(UpStreamArgs a) {
     }
 }
 
+
+// ---- packed colour chain for the HDR op list of config 5: XybToMixedLms -> Matrix -> GamutMap -> Matrix -> PQ
+// (color_pixel with gamut_map == JXLGPU_GAMUT_MAP, has_matrix2, no tone map, tf == PQ, not YCbCr).  The two output
+// pixels xm = 0, 1 of an input sample are the halves of every value: a multiplication, addition or mul_add of the
+// scalar chain becomes ONE v_pk_{mul,add,fma}_f32 on the pair — the same operation per half, each rounded once —
+// while divisions, square roots, comparisons and selects stay per element (the compiler's IEEE expansions), so the
+// result is color_pixel's, bit for bit.  The ~50 constants of the chain are packed operands: they sit as {c, c}
+// pairs in LDS (the compiler's own one-SGPR `op_sel_hi` broadcast is the form that read a stale half, DESIGN §2;
+// 100 SGPRs of real pairs do not fit) and are fetched next to their use.
+typedef float cf2 __attribute__((ext_vector_type(2)));
+enum {
+    HC_CBRT = 0,      // 3: cbrt_opsin_bias
+    HC_BIAS = 3,      // 3: opsin_bias
+    HC_ITS = 6,       // itscale
+    HC_M = 7,         // 9: matrix
+    HC_LUM = 16,      // 3: gamut luminances
+    HC_SAT = 19,      // gamut saturation factor
+    HC_M2 = 20,       // 9: matrix2
+    HC_YMULT = 29,    // intensity_target / 10000
+    HC_P = 30, HC_Q = 35, HC_PS = 40, HC_QS = 45,   // 5 each: linear_to_pq's rational polynomials
+    HC_COUNT = 50
+};
+
+__device__ __forceinline__ void hdr_consts_fill(cf2* tab, const ColorArgs& cp, int lane) {
+    // jxl-color/src/tf/pq.rs:26-35 (the tables of linear_to_pq_dev)
+    const float P[5] = {1.351392e-2f, -1.095778f, 5.522776e1f, 1.492516e2f, 4.838434e1f};
+    const float Q[5] = {1.012416f, 2.016708e1f, 9.26371e1f, 1.120607e2f, 2.590418e1f};
+    const float PS[5] = {9.863406e-6f, 3.881234e-1f, 1.352821e2f, 6.889862e4f, -2.864824e5f};
+    const float QS[5] = {3.371868e1f, 1.477719e3f, 1.608477e4f, -4.389884e4f, -2.072546e5f};
+    float v = 0.0f;
+#pragma unroll
+    for (int i = 0; i < HC_COUNT; ++i) {
+        float c;
+        if (i < 3) c = cp.cbrt_opsin_bias[i];
+        else if (i < 6) c = cp.opsin_bias[i - 3];
+        else if (i == 6) c = cp.itscale;
+        else if (i < 16) c = cp.matrix[i - 7];
+        else if (i < 19) c = cp.gamut_lum[i - 16];
+        else if (i == 19) c = cp.gamut_sat;
+        else if (i < 29) c = cp.matrix2[i - 20];
+        else if (i == 29) c = cp.intensity_target / 10000.0f;
+        else if (i < 35) c = P[i - 30];
+        else if (i < 40) c = Q[i - 35];
+        else if (i < 45) c = PS[i - 40];
+        else c = QS[i - 45];
+        v = lane == i ? c : v;
+    }
+    if (lane < HC_COUNT) tab[lane] = cf2{v, v};
+}
+
+__device__ __forceinline__ cf2 pk_fma(cf2 a, cf2 b, cf2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ cf2 sel2(bool cx, bool cy, cf2 a, cf2 b) { return cf2{cx ? a.x : b.x, cy ? a.y : b.y}; }
+
+// matmul3vec_dev on pairs (ciexyz.rs:81-87): (a0 b0 + a1 b1) + a2 b2, no contraction
+__device__ __forceinline__ void matmul3_pair(const cf2* m, cf2 (&v)[3]) {
+    const cf2 b0 = v[0], b1 = v[1], b2 = v[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) v[r] = m[3 * r] * b0 + m[3 * r + 1] * b1 + m[3 * r + 2] * b2;
+}
+
+// map_gamut_dev on pairs (gamut.rs:4-46)
+__device__ __forceinline__ void map_gamut_pair(const cf2* k, cf2 (&rgb)[3]) {
+    const cf2 y = rgb[0] * k[HC_LUM] + rgb[1] * k[HC_LUM + 1] + rgb[2] * k[HC_LUM + 2];
+    cf2 gray_saturation = {0.0f, 0.0f}, gray_luminance = {0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const cf2 v = rgb[i];
+        const cf2 v_sub_y = v - y;
+        const cf2 inv = {1.0f / (v_sub_y.x == 0.0f ? 1.0f : v_sub_y.x), 1.0f / (v_sub_y.y == 0.0f ? 1.0f : v_sub_y.y)};
+        const cf2 v_over = v * inv;
+        const cf2 new_sat = sel2(v_sub_y.x >= 0.0f, v_sub_y.y >= 0.0f, gray_saturation,
+                                 cf2{fmaxf(gray_saturation.x, v_over.x), fmaxf(gray_saturation.y, v_over.y)});
+        const cf2 lum_cand = sel2(v_sub_y.x <= 0.0f, v_sub_y.y <= 0.0f, new_sat, v_over - inv);
+        gray_luminance = cf2{fmaxf(lum_cand.x, gray_luminance.x), fmaxf(lum_cand.y, gray_luminance.y)};
+        gray_saturation = new_sat;
+    }
+    cf2 gray_mix = k[HC_SAT] * (gray_saturation - gray_luminance) + gray_luminance;
+    gray_mix = cf2{gray_mix.x < 0.0f ? 0.0f : gray_mix.x, gray_mix.y < 0.0f ? 0.0f : gray_mix.y};
+    gray_mix = cf2{gray_mix.x > 1.0f ? 1.0f : gray_mix.x, gray_mix.y > 1.0f ? 1.0f : gray_mix.y};
+    cf2 mixed[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mixed[i] = gray_mix * (y - rgb[i]) + rgb[i];
+    cf2 max_color_val = {1.0f, 1.0f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) max_color_val = cf2{fmaxf(rgb[i].x, max_color_val.x), fmaxf(rgb[i].y, max_color_val.y)};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rgb[i] = cf2{mixed[i].x / max_color_val.x, mixed[i].y / max_color_val.y};
+}
+
+// rational_poly5_dev's numerator / denominator on pairs (fastmath/rational_poly.rs:2-6)
+__device__ __forceinline__ cf2 horner5_pair(cf2 x, const cf2* p) {
+    cf2 yv = p[4];
+#pragma unroll
+    for (int i = 3; i >= 0; --i) yv = yv * x + p[i];
+    return yv;
+}
+
+// linear_to_pq_dev on a pair (tf/pq.rs:127-142)
+__device__ __forceinline__ cf2 linear_to_pq_pair(cf2 s, const cf2* k) {
+    const cf2 a = {fabsf(s.x), fabsf(s.y)};
+    const cf2 a_scaled = a * k[HC_YMULT];
+    const cf2 a_1_4 = {sqrtf(sqrtf(a_scaled.x)), sqrtf(sqrtf(a_scaled.y))};
+    const bool sx = a.x < 1e-4f, sy = a.y < 1e-4f;
+    cf2 yp = horner5_pair(a_1_4, k + HC_P), yq = horner5_pair(a_1_4, k + HC_Q);
+    if (__builtin_amdgcn_ballot_w64(sx || sy) != 0) {   // dark samples: the other pair of polynomials (wave-uniform test)
+        const cf2 yps = horner5_pair(a_1_4, k + HC_PS), yqs = horner5_pair(a_1_4, k + HC_QS);
+        yp = sel2(sx, sy, yps, yp);
+        yq = sel2(sx, sy, yqs, yq);
+    }
+    return cf2{copysignf(yp.x / yq.x, s.x), copysignf(yp.y / yq.y, s.y)};
+}
+
+__device__ __forceinline__ void color_pair_hdr(const cf2* k, cf2 (&v)[3]) {
+    const cf2 x = v[0], y = v[1], b = v[2];
+    cf2 g_l = y + x, g_m = y - x, g_s = b;
+    g_l = g_l - k[HC_CBRT];
+    g_m = g_m - k[HC_CBRT + 1];
+    g_s = g_s - k[HC_CBRT + 2];
+    v[0] = pk_fma(g_l * g_l, g_l, k[HC_BIAS]) * k[HC_ITS];
+    v[1] = pk_fma(g_m * g_m, g_m, k[HC_BIAS + 1]) * k[HC_ITS];
+    v[2] = pk_fma(g_s * g_s, g_s, k[HC_BIAS + 2]) * k[HC_ITS];
+    asm volatile("" ::: "memory");   // (phase boundaries: keeps the compiler from fetching every constant pair up front)
+    matmul3_pair(k + HC_M, v);
+    asm volatile("" ::: "memory");
+    map_gamut_pair(k, v);
+    asm volatile("" ::: "memory");
+    matmul3_pair(k + HC_M2, v);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        asm volatile("" ::: "memory");
+        v[c] = linear_to_pq_pair(v[c], k);
+    }
+}
+
+// Is the colour op list the one color_pair_hdr evaluates?
+static bool is_hdr_pq_list(const ColorArgs& c) {
+    return !c.ycbcr && c.gamut_map == JXLGPU_GAMUT_MAP && c.has_matrix2 && !c.tone_map && c.tf == JXLGPU_TF_PQ;
+}
+
 // ---- LDS-ring form (the default).  The register ring above holds 75 window samples + 30 cached extrema
 // per lane (183 VGPRs: two waves per SIMD), and a dependent VALU instruction of one wave issues only every
 // ~6th slot on gfx950 (tools/pk_probe.hip), so two resident waves of mostly serial arithmetic (25-term sums,
@@ -154,9 +293,14 @@ __global__ __launch_bounds__(256) void upsample2_stream_kernel(UpStreamArgs a) {
 typedef float uf2 __attribute__((ext_vector_type(2)));
 constexpr int RING_STRIDE = 68;  // floats per (slot, channel) row: 2 pad + 64 lanes + 2 pad
 
-template <bool COLOR, int WAVES_PER_SIMD>
+template <int COLOR, int WAVES_PER_SIMD>   // COLOR: 0 none, 1 the general op list (color_pixel), 2 the packed HDR chain
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void upsample2_lds_kernel(UpStreamArgs a) {
     __shared__ float ring_all[4][5][3][RING_STRIDE];
+    __shared__ cf2 hdr_tab[COLOR == 2 ? HC_COUNT : 1];
+    if constexpr (COLOR == 2) {
+        if (threadIdx.x < 64) hdr_consts_fill(hdr_tab, a.color, (int)threadIdx.x);
+        __syncthreads();
+    }
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wave = blockIdx.x * 4 + wib;
     const int lane = threadIdx.x & 63;
@@ -242,9 +386,14 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void upsample2_lds_kernel(UpSt
             float p0[3], p1[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) { p0[c] = ym ? o[1][0][c] : o[0][0][c]; p1[c] = ym ? o[1][1][c] : o[0][1][c]; }
-            if constexpr (COLOR) {
+            if constexpr (COLOR == 1) {
                 color_pixel(a.color, p0);
                 color_pixel(a.color, p1);
+            } else if constexpr (COLOR == 2) {
+                cf2 pv[3] = {cf2{p0[0], p1[0]}, cf2{p0[1], p1[1]}, cf2{p0[2], p1[2]}};
+                color_pair_hdr(hdr_tab, pv);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { p0[c] = pv[c].x; p1[c] = pv[c].y; }
             }
             if (store_lane) {
                 const size_t orow = (size_t)(uint32_t)(2 * r + ym) * a.out_stride;  // uniform
@@ -263,7 +412,8 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void upsample2_lds_kernel(UpSt
 // 2x upsampling of three planes (+ the colour transform when `color` is non-null) in one launch.
 // Returns false when the streaming form does not apply (tiny frames: the reference's padding has
 // its own behaviour below 2 samples, kept by the stage-at-a-time kernel).
-// `variant`: 0 = LDS-ring kernel, 1 = register-ring kernel; `rows`: rows per wave segment, 0 = sized from the
+// `variant`: 0 = LDS-ring kernel (packed colour chain for the HDR PQ op list), 1 = register-ring kernel, 2 = LDS-ring kernel
+// with the general colour code only; `rows`: rows per wave segment, 0 = sized from the
 // chip's resident wave slots (a fixed 64 rows made a 4K input 2176 waves on the 2048 slots of the register-ring
 // kernel: a second, nearly empty round doubled the launch time).
 bool launch_upsample2_stream(hipStream_t s, const float* const in[3], uint32_t in_stride, uint32_t w, uint32_t h,
@@ -305,8 +455,9 @@ bool launch_upsample2_stream(hipStream_t s, const float* const in[3], uint32_t i
         if (color) upsample2_stream_kernel<true><<<grid, 256, 0, s>>>(a);
         else upsample2_stream_kernel<false><<<grid, 256, 0, s>>>(a);
     } else {
-        if (color) upsample2_lds_kernel<true, 4><<<grid, 256, 0, s>>>(a);
-        else upsample2_lds_kernel<false, 5><<<grid, 256, 0, s>>>(a);
+        if (color && variant != 2 && is_hdr_pq_list(a.color)) upsample2_lds_kernel<2, 4><<<grid, 256, 0, s>>>(a);
+        else if (color) upsample2_lds_kernel<1, 4><<<grid, 256, 0, s>>>(a);
+        else upsample2_lds_kernel<0, 5><<<grid, 256, 0, s>>>(a);
     }
     return true;
 }

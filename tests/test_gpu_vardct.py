@@ -362,3 +362,27 @@ def test_all_zero_channel_keeps_the_packed_division_path_exact(gpu_ctx, oracle):
         f.free()
     for g, what in ((got, "single frame"), (got_b, "batch")):
         assert np.array_equal(g.view(np.uint32), exp.view(np.uint32)), what
+
+
+@pytest.mark.parametrize("dark", [False, True])
+def test_upsampled_hdr_pq_packed_colour_chain(gpu_ctx, oracle, dark):
+    """2x upsampling with the HDR op list (XybToMixedLms -> Matrix -> GamutMap -> Matrix -> PQ) takes the packed colour
+    chain of upsample2_lds_kernel<2>: pixel pairs as packed f32, constants as pairs in LDS.  `dark`: an image around
+    black (zero LF, small coefficients) so that samples fall below linear_to_pq's 1e-4 threshold (the second pair of
+    rational polynomials, chosen per element under a wave-uniform test) and on both sides of zero (copysign).  The
+    general colour code (JXLGPU_UP2_VARIANT=2) must give the same bits — checked through the oracle."""
+    wl = VardctWorkload(264, 200, seed=61, epf_iters=1, upsampling=2, intensity_target=4000.0, hdr_pq=True)
+    if dark:
+        for p in wl.lfq:
+            p[...] = 0
+        wl.coeff //= 8
+    exp, _ = oracle.vardct_render(wl.desc(), abi.STAGE_ALL, 528, 400)
+    if dark:
+        lin = np.abs(exp)
+        assert (lin < 0.2).mean() > 0.5, "the dark case is expected to be dark"
+    f = gpu_ctx.vardct_upload(wl.desc(coeff_transport="grouped"))
+    try:
+        got = gpu_ctx.vardct_render(f, abi.STAGE_ALL)
+    finally:
+        f.free()
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
