@@ -417,7 +417,7 @@ def make_job(config, distinct, transport="grouped"):
             "make": lambda d: VardctWorkload(W4K, H4K, seed=5000 + d, epf_iters=3, upsampling=2, intensity_target=4000.0, hdr_pq=True),
             "upload": lambda ctx, wl: ctx.vardct_upload(wl.desc(coeff_transport=transport)),
             "render": render, "groups": (1, 2),
-            "group_names": {1: "transform: V4-V8", 2: "post: fused_post_kernel<true,4> (Gabor + EPF step 0) + post_pk_kernel (steps 1, 2) + upsample2_stream_kernel (2x + PQ)"},
+            "group_names": {1: "transform: V4-V8", 2: "post: fused_post_kernel<true,4> (Gabor + EPF step 0) + post_pk_kernel (steps 1, 2) + upsample2_lds_kernel (2x + PQ, packed colour chain)"},
             "alg_bytes": lambda f, g: W4K * H4K * 12 + 4 * W4K * H4K * 12,  # 12 B per coded px in, 12 B per output px out
             "verify": verify, "traffic": lambda d, n: (None, None),
         }

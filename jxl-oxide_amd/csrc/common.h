@@ -216,7 +216,8 @@ struct Tuning {
     bool sqz_h_rows = false;     // JXLGPU_SQZ_H_ROWS: horizontal Squeeze steps through the lane-per-row segment kernel
     bool pred_wide = false;      // JXLGPU_PRED_WIDE: the self-correcting predictor in 64-bit arithmetic only
     bool pred_wg = false;        // JXLGPU_PRED_WG: predictor subgrids through the workgroup-per-subgrid kernel only
-    int up2_variant = 0;         // JXLGPU_UP2_VARIANT: 1 = register-ring form of the 2x upsampling kernel (0: LDS ring)
+    int up2_variant = 0;         // JXLGPU_UP2_VARIANT: 1 = register-ring form of the 2x upsampling kernel, 2 = LDS ring with the
+                                 // general colour code only (0: LDS ring, packed colour chain for the HDR PQ op list)
     int up2_rows = 0;            // JXLGPU_UP2_ROWS: rows per wave segment of that kernel (0: one resident round)
 };
 
