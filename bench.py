@@ -477,12 +477,22 @@ def cpu_baseline(config, seconds):
         thr = max(1, min(16, ncpu // procs))
         if procs * thr <= ncpu and (procs, thr) not in splits:
             splits.append((procs, thr))
+    # many single-frame workers with one or two threads each: the scalar port scales better across frames than inside
+    # one (OpenMP fork / join per stage); bounded by the free memory of the box (a worker holds ~1.5 GB of a 4K frame)
+    try:
+        import psutil
+        free_gb = psutil.virtual_memory().available / 2**30
+    except Exception:
+        free_gb = 64.0
+    for procs, thr in ((64, 1), (64, 2), (128, 1)):
+        if procs * thr <= ncpu and procs * 2.0 <= free_gb * 0.5 and (procs, thr) not in splits:
+            splits.append((procs, thr))
     table, best = [], None
     for procs, thr in splits:
         try:
             r = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--config", str(config), "--procs", str(procs),
                                 "--threads", str(thr), "--seconds", str(seconds)], cwd=ROOT, capture_output=True, text=True,
-                               timeout=240)
+                               timeout=300)
             j = json.loads(r.stdout.strip().splitlines()[-1])
             table.append(j)
             if best is None or j["MP_per_s"] > best["MP_per_s"]:
