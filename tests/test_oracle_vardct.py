@@ -225,3 +225,73 @@ def test_truncated_groups_keep_their_lf(oracle):
     part, _ = oracle.vardct_render(wl.desc(partial={1: 0}), S, 768, 256)
     assert np.array_equal(full[:, :, :256], part[:, :, :256]) and np.array_equal(full[:, :, 512:], part[:, :, 512:])
     assert not np.array_equal(full[:, :, 256:512], part[:, :, 256:512])
+
+
+def test_scale_f_table_is_its_closed_form():
+    """SCALE_F (vardct/dct_common.rs:77-114; pinned textually by tests/test_reference_tables.py) is
+    cos(c pi / 512) cos(c pi / 256) cos(c pi / 128): the low-frequency resampling scale of the specification —
+    so the table the oracle and the kernels carry is the right table, not merely the same table."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_tables.json")))["tables"]
+    key = [k for k in gold if "SCALE_F" in k.upper()]
+    assert key, list(gold)[:10]
+    tab = np.array([float(v) for v in gold[key[0]]], dtype=np.float64)
+    c = np.arange(tab.size, dtype=np.float64)
+    closed = np.cos(c * math.pi / 512) * np.cos(c * math.pi / 256) * np.cos(c * math.pi / 128)
+    assert np.abs(tab - closed).max() < 1e-7
+
+
+def test_whole_transform_stage_matches_an_independent_f64_pipeline(oracle):
+    """V4 - V8 of a whole frame (square DCT8 / DCT16 / DCT32 varblocks) against numpy f64 written from the formulas,
+    not from the oracle: HF dequantisation (vardct/mod.rs:527-537), chroma-from-luma on the coefficients per 64x64
+    tile (:589-600), the lowest frequencies from the LF image (forward DCT of the bw x bh LF samples divided by the
+    scale_f products, transform_common.rs:40-66), orthonormal-cosine IDCT as matrices."""
+    w, h = 264, 200
+    wl = VardctWorkload(w, h, seed=12, types=[0, 4, 5], zero_fraction=0.5)
+    S = abi.STAGE_LF | abi.STAGE_TRANSFORM
+    got, lf = oracle.vardct_render(wl.desc(), S, w, h, want_lf=True, w8=wl.w8, h8=wl.h8)
+    d = wl.desc()
+    gs, cf = float(d.global_scale), float(d.colour_factor)
+    qb, qbn = [float(x) for x in d.quant_bias], float(d.quant_bias_numerator)
+    qm = [0.8 ** (int(d.x_qm_scale) - 2), 1.0, 0.8 ** (int(d.b_qm_scale) - 2)]
+    hr, wr = wl.coeff.shape[1:]
+    deq = np.zeros((3, hr, wr))
+    ys, xs = np.nonzero(wl.kind <= 26)
+    for cy, cx in zip(ys, xs):
+        t = int(wl.kind[cy, cx])
+        bw, bh = abi.DCT_SELECT_SIZE[t]
+        W, H = 8 * bw, 8 * bh
+        for c in range(3):
+            q = wl.coeff[c, cy * 8:cy * 8 + H, cx * 8:cx * 8 + W].astype(np.float64)
+            v = np.where(np.abs(q) <= 1.0, q * qb[c], q - qbn / np.where(q == 0, 1.0, q))
+            v = v * wl.mats[t][c].astype(np.float64).reshape(H, W) * (65536.0 / (gs * float(wl.hf_mul[cy, cx])) * qm[c])
+            deq[c, cy * 8:cy * 8 + H, cx * 8:cx * 8 + W] = v
+    # chroma from luma on coefficients: the factor of the 64x64 tile the coefficient SAMPLE lies in
+    ty, tx = np.arange(hr) // 64, np.arange(wr) // 64
+    kx = float(d.base_correlation_x) + wl.xfy.astype(np.float64)[np.minimum(ty, wl.xfy.shape[0] - 1)][:, np.minimum(tx, wl.xfy.shape[1] - 1)] / cf
+    kb = float(d.base_correlation_b) + wl.bfy.astype(np.float64)[np.minimum(ty, wl.bfy.shape[0] - 1)][:, np.minimum(tx, wl.bfy.shape[1] - 1)] / cf
+    deq[0] += kx * deq[1]
+    deq[2] += kb * deq[1]
+    scale_f = lambda c: math.cos(c * math.pi / 512) * math.cos(c * math.pi / 256) * math.cos(c * math.pi / 128)
+    exp = np.zeros((3, hr, wr))
+    for cy, cx in zip(ys, xs):
+        t = int(wl.kind[cy, cx])
+        bw, bh = abi.DCT_SELECT_SIZE[t]
+        W, H = 8 * bw, 8 * bh
+        MH, MW = _idct_mat(H), _idct_mat(W)
+        for c in range(3):
+            blk = deq[c, cy * 8:cy * 8 + H, cx * 8:cx * 8 + W].copy()
+            lfb = lf[c, cy:cy + bh, cx:cx + bw].astype(np.float64)
+            if bw * bh == 1:
+                llf = lfb
+            else:
+                mh, mw = _idct_mat(bh), _idct_mat(bw)
+                llf = (mh.T @ lfb @ mw) / (bh * bw)          # forward DCT = inverse of x = M c
+                sy = np.array([scale_f(y << (5 - int(math.log2(bh)))) for y in range(bh)])
+                sx = np.array([scale_f(x << (5 - int(math.log2(bw)))) for x in range(bw)])
+                llf = llf / np.outer(sy, sx)
+            blk[:bh, :bw] = llf
+            exp[c, cy * 8:cy * 8 + H, cx * 8:cx * 8 + W] = MH @ blk @ MW.T
+    err = np.abs(got.astype(np.float64) - exp[:, :h, :w]).max()
+    assert err < 5e-5 * max(1.0, np.abs(exp).max()), err
