@@ -295,3 +295,25 @@ def test_whole_transform_stage_matches_an_independent_f64_pipeline(oracle):
             exp[c, cy * 8:cy * 8 + H, cx * 8:cx * 8 + W] = MH @ blk @ MW.T
     err = np.abs(got.astype(np.float64) - exp[:, :h, :w]).max()
     assert err < 5e-5 * max(1.0, np.abs(exp).max()), err
+
+
+@pytest.mark.parametrize("t", [0, 1, 2, 3, 12, 13, 14, 15, 16, 17])
+def test_small_transforms_have_orthogonal_full_rank_bases(oracle, t):
+    """Every 8x8 transform of the specification but Hornuss (DCT8, DCT2, DCT4, DCT4x8, DCT8x4, AFV0-3) maps its 64
+    coefficients onto 64 mutually ORTHOGONAL pixel patterns (cosine, Haar-like and AFV bases are orthogonal sets;
+    Hornuss codes differences from a block average: full rank, not orthogonal — checked for rank only):
+    the 64 x 64 matrix of the oracle's transform, built from unit coefficient blocks, must have a diagonal Gram
+    matrix with no vanishing entry.  An indexing slip in a special transform (a swapped quadrant, a wrong
+    interleave) breaks this even where linearity and the DC response still hold."""
+    T = np.zeros((64, 64))
+    for i in range(64):
+        c = np.zeros((8, 8), dtype=np.float32)
+        c[i // 8, i % 8] = 1.0
+        T[:, i] = oracle.transform_block(c, t).astype(np.float64).reshape(-1)
+    G = T.T @ T
+    if t == 1:
+        assert np.linalg.cond(T) < 100.0
+        return
+    off = G - np.diag(np.diag(G))
+    assert np.abs(off).max() < 2e-5 * np.abs(np.diag(G)).max(), np.abs(off).max()
+    assert np.diag(G).min() > 1e-3
