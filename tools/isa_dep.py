@@ -12,6 +12,13 @@ which its wave's previous instruction has issued and its operands are ready.  Tr
 rsq, exp, log) occupy 4 slots.  LDS reads are ready 16 slots later, global loads are not modelled (the
 kernels prefetch them rows ahead).  Output per block: VALU count, slots needed, issue efficiency, and the
 histogram of producer distances (in VALU instructions of the same wave).
+
+What the model is good for, as measured in round 3 (profiles/r03_experiments.txt): spotting kernels made of
+short, serial basic blocks at two waves per SIMD (it put the register-ring upsampling kernel at 0.42 issue
+efficiency; the LDS-ring rewrite at 4 waves measured 2x).  What it is NOT: a predictor of what a different
+instruction schedule buys — it rated the `max-ilp` scheduler strategy +30 % on the packed post kernel and +66 % on
+the predictor step, and neither moved on the hardware (the post kernel already issues ~98 % of its resident time;
+the predictor step was bound by its memory accesses).  Use the counters for that question.
 """
 import argparse
 import collections
