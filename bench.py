@@ -86,7 +86,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP library is the thing measured (no CPU fallback)")
     if rank == 0:
-        runtime.prime_gpu()  # disposable first GPU process (see runtime.prime_gpu)
+        canary = runtime.gpu_canary(quiet=True)  # pure-HIP program first: a faulting box shows up here, by name
+        print(f"CANARY {canary}", file=sys.stderr, flush=True)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

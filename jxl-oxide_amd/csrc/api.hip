@@ -14,8 +14,78 @@
 #include "common.h"
 #include "pixel_device.h"  // linear_to_pq_dev (host+device) for the tone-map constants
 
+// JXLGPU_GUARD (debug): every device buffer gets its own virtual-memory mapping with an unmapped
+// granule on each side, so that an access outside the buffer is a GPU page fault with the kernel's
+// name on it (AMD_LOG_LEVEL=3) instead of a silent read of a neighbour.  Mode 1: the buffer ENDS at
+// the end of the mapping (bytes rounded up to 16: the kernels' widest access) — overruns fault;
+// mode 2: it STARTS at the start of the mapping — underruns fault.  No pooling: a freed buffer is
+// unmapped at once, so a use-after-free faults too.
+static hipError_t guard_malloc(jxlgpu_ctx* ctx, void** out, size_t bytes) {
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof(prop));
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    if (!ctx->guard_gran) {
+        size_t g = 0;
+        hipError_t e = hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityMinimum);
+        if (e != hipSuccess) return e;
+        ctx->guard_gran = g ? g : 4096;
+    }
+    const size_t gran = ctx->guard_gran;
+    const size_t user = (bytes + 15) & ~(size_t)15;
+    GuardRec r;
+    r.mapped = (user + gran - 1) / gran * gran;
+    r.reserved = r.mapped + 2 * gran;
+    hipError_t e = hipMemAddressReserve(&r.base, r.reserved, gran, nullptr, 0);
+    if (e != hipSuccess) return e;
+    e = hipMemCreate(&r.handle, r.mapped, &prop, 0);
+    if (e != hipSuccess) { (void)hipMemAddressFree(r.base, r.reserved); return e; }
+    char* at = static_cast<char*>(r.base) + gran;
+    e = hipMemMap(at, r.mapped, 0, r.handle, 0);
+    if (e == hipSuccess) {
+        hipMemAccessDesc ad;
+        memset(&ad, 0, sizeof(ad));
+        ad.location = prop.location;
+        ad.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(at, r.mapped, &ad, 1);
+        if (e != hipSuccess) (void)hipMemUnmap(at, r.mapped);
+    }
+    if (e != hipSuccess) {
+        (void)hipMemRelease(r.handle);
+        (void)hipMemAddressFree(r.base, r.reserved);
+        return e;
+    }
+    // poison: a kernel that reads slack inside the mapping (mode 2: behind the buffer) sees NaNs, not zeros
+    // (device-wide sync: hipMemset on device memory may return before the fill has run, and the ctx streams
+    //  are non-blocking — they do not order behind the null stream)
+    const int seq = ctx->guard_seq++;
+    const bool zero = ctx->guard_zero == -2 || ctx->guard_zero == seq;   // bisecting reads of uninitialised memory
+    (void)hipMemset(at, zero ? 0x00 : 0xff, r.mapped);
+    (void)hipDeviceSynchronize();
+    if (ctx->guard_log) fprintf(stderr, "[jxlgpu guard] alloc #%d: %zu bytes%s\n", seq, bytes, zero ? " (zero-filled)" : "");
+    *out = ctx->guard_mode == 2 ? at : at + (r.mapped - user);
+    ctx->guard_live[*out] = r;
+    return hipSuccess;
+}
+
+static void guard_free(jxlgpu_ctx* ctx, void* p) {
+    auto it = ctx->guard_live.find(p);
+    if (it == ctx->guard_live.end()) return;
+    const GuardRec r = it->second;
+    ctx->guard_live.erase(it);
+    char* at = static_cast<char*>(r.base) + ctx->guard_gran;
+    (void)hipMemUnmap(at, r.mapped);
+    (void)hipMemRelease(r.handle);
+    // The address range is NOT given back: on this runtime (ROCm 7.2) a range that is freed, reserved again and
+    // mapped to new memory serves stale translations — tools/vmm_churn.hip, a pure-HIP program, gets hundreds of
+    // millions of wrong words with hipMemAddressFree in its loop and none without it (profiles/r04_fault_hunt.md).
+    // Never recycling a range also keeps every freed buffer's addresses unmapped for good: a use-after-free faults.
+}
+
 hipError_t ctx_dev_malloc(jxlgpu_ctx* ctx, void** out, size_t bytes) {
     bytes = std::max<size_t>(bytes, 16);
+    if (ctx->guard_mode) return guard_malloc(ctx, out, bytes);
     auto it = ctx->pool.find(bytes);
     if (it != ctx->pool.end()) {
         *out = it->second;
@@ -39,6 +109,7 @@ hipError_t ctx_dev_malloc(jxlgpu_ctx* ctx, void** out, size_t bytes) {
 // The caller guarantees that no queued work still touches `p` (frame_free synchronises first).
 void ctx_dev_release(jxlgpu_ctx* ctx, void* p) {
     if (!p) return;
+    if (ctx->guard_mode) { guard_free(ctx, p); return; }
     auto it = ctx->live.find(p);
     if (it == ctx->live.end()) { (void)hipFree(p); return; }
     const size_t bytes = it->second;
@@ -315,6 +386,12 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     ctx->tune.no_fused = getenv("JXLGPU_NO_FUSED") != nullptr;
     ctx->tune.no_sparse_tr = getenv("JXLGPU_NO_SPARSE_TR") != nullptr;
     ctx->tune.debug_sync = getenv("JXLGPU_DEBUG_SYNC") != nullptr;
+    if (const char* v = getenv("JXLGPU_GUARD")) {
+        const int m = atoi(v);
+        if (m == 1 || m == 2) ctx->guard_mode = m;
+    }
+    if (const char* v = getenv("JXLGPU_GUARD_ZERO")) ctx->guard_zero = strcmp(v, "all") == 0 ? -2 : atoi(v);
+    ctx->guard_log = getenv("JXLGPU_GUARD_LOG") != nullptr;
     if (const char* v = getenv("JXLGPU_TR_WGS_PER_CU")) {
         int t[4];
         if (sscanf(v, "%d,%d,%d,%d", &t[0], &t[1], &t[2], &t[3]) == 4)
@@ -367,8 +444,9 @@ void jxlgpu_destroy(jxlgpu_ctx* ctx) {
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (hipEvent_t e : ctx->ev_d2h) if (e) (void)hipEventDestroy(e);
-    if (ctx->noise_jump) (void)hipFree(ctx->noise_jump);
+    if (ctx->noise_jump) ctx_dev_release(ctx, ctx->noise_jump);
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
+    while (!ctx->guard_live.empty()) guard_free(ctx, ctx->guard_live.begin()->first);
     for (auto& e : ctx->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete ctx;
 }
@@ -925,7 +1003,7 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
         if (noise_geometry_unsupported(*oh, f->noise_group_dim))
             return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "noise on a frame whose last group row is one sample high (the reference panics there)");
         if (!ctx->noise_jump) {
-            HIP_TRY(ctx, hipMalloc(&ctx->noise_jump, noise_jump_table_bytes()));
+            HIP_TRY(ctx, ctx_dev_malloc(ctx, &ctx->noise_jump, noise_jump_table_bytes()));
             HIP_TRY(ctx, hipMemcpy(ctx->noise_jump, noise_jump_table_host(), noise_jump_table_bytes(), hipMemcpyHostToDevice));
         }
         if (!f->noise_raw[0] || f->noise_w != *ow || f->noise_h != *oh) {

@@ -221,6 +221,13 @@ struct Tuning {
     int up2_rows = 0;            // JXLGPU_UP2_ROWS: rows per wave segment of that kernel (0: one resident round)
 };
 
+// One guarded device buffer (JXLGPU_GUARD, api.hip guard_malloc)
+struct GuardRec {
+    void* base = nullptr;       // reserved range: [guard granule][mapping][guard granule]
+    size_t reserved = 0, mapped = 0;
+    hipMemGenericAllocationHandle_t handle = {};
+};
+
 struct jxlgpu_ctx {
     int device = 0;
     uint32_t num_cus = 256;     // hipDeviceProp_t::multiProcessorCount (persistent grids are sized from it)
@@ -236,6 +243,11 @@ struct jxlgpu_ctx {
     std::unordered_map<void*, size_t> live;
     std::multimap<size_t, void*> pool;
     size_t pool_bytes = 0, pool_cap = (size_t)8 << 30;
+    int guard_mode = 0;         // JXLGPU_GUARD: 1 = buffers end at an unmapped page, 2 = start after one
+    size_t guard_gran = 0;
+    int guard_seq = 0, guard_zero = -1;   // JXLGPU_GUARD_ZERO=k|all: allocation #k (all) is zero-filled instead of poisoned
+    bool guard_log = false;               // JXLGPU_GUARD_LOG: one stderr line per allocation
+    std::unordered_map<void*, GuardRec> guard_live;
 #ifdef JXL_TR_PROFILE
     unsigned long long* tr_prof = nullptr;
 #endif

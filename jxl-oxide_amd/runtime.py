@@ -7,20 +7,42 @@ import numpy as np
 from . import abi
 
 
-def prime_gpu(timeout=240):
-    """First GPU touch in a throw-away child process.  On a freshly provisioned box the very first
-    process that initialises the HIP runtime occasionally dies with "Memory access fault by GPU
-    node" before any kernel of ours has been launched (seen 3x in ~35 sessions, always the first
-    GPU process of a fresh box, never later ones); letting a disposable child take that hit keeps
-    tests / smoke / bench deterministic.  Returns True if the child ran clean."""
+def canary_path():
+    import os
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "_bin", "canary")
+
+
+def gpu_canary(attempts=3, timeout=120, quiet=False):
+    """Box or library?  Runs tests/c/canary.hip (built by __graft_entry__.build() into tools/_bin/canary): a pure-HIP
+    program — no libjxlgpu.so, no torch — that uses the runtime the way the library does (small exact-size
+    hipMallocs, non-blocking streams, blocking / async / 2-D copies, pinned staging, > 64 KiB dynamic LDS) with
+    trivially in-bounds kernels.  If THAT dies with "Memory access fault by GPU node", the box is at fault: nothing
+    of ours was loaded.  Up to `attempts` fresh processes; every attempt is printed ("CANARY attempt k: ...") so
+    that the driver's log says which it was.  Returns "ok" (first attempt clean), "ok-after-fault" (an earlier
+    attempt died, a later one ran clean: the first-process fault of some fresh boxes), "fault" (every attempt
+    died), "nodevice" or "missing" (binary not built)."""
+    import os
     import subprocess
-    import sys
-    code = "import torch; torch.cuda.init(); x = torch.ones(64, device='cuda'); print(float(x.sum()))"
-    try:
-        r = subprocess.run([sys.executable, "-c", code], timeout=timeout, capture_output=True)
-        return r.returncode == 0
-    except Exception:
-        return False
+    exe = canary_path()
+    if not os.path.exists(exe):
+        if not quiet:
+            print("CANARY missing: tools/_bin/canary not built (run __graft_entry__.build())", flush=True)
+        return "missing"
+    seen_fault = False
+    for k in range(attempts):
+        try:
+            r = subprocess.run([exe], timeout=timeout, capture_output=True, text=True)
+            rc, out, err = r.returncode, r.stdout.strip(), r.stderr.strip()
+        except subprocess.TimeoutExpired:
+            rc, out, err = -999, "", "timeout"
+        if not quiet:
+            print(f"CANARY attempt {k + 1}: rc={rc} {out} {err[:300]}".rstrip(), flush=True)
+        if rc == 0 and out.endswith("CANARY ok"):
+            return "ok-after-fault" if seen_fault else "ok"
+        if rc == 3:
+            return "nodevice"
+        seen_fault = True
+    return "fault"
 
 
 class JxlGpuError(RuntimeError):

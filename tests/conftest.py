@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The box canary (tests/test_gpu_canary.py) runs before any other GPU test: with `-x`, a box whose GPU kills
+    even a pure-HIP program stops the session THERE, with "BOX FAULT" in the record, instead of at whichever
+    library test happened to come first."""
+    first = [it for it in items if it.nodeid.startswith("tests/test_gpu_canary.py") or "/test_gpu_canary.py" in it.nodeid]
+    if first:
+        rest = [it for it in items if it not in first]
+        items[:] = first + rest
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import pyoracle
@@ -27,7 +37,6 @@ def oracle():
 def gpu_ctx():
     """One jxlgpu context on device 0 through the C ABI.  Fails loudly without the HIP library."""
     from jxl_oxide_amd import runtime
-    runtime.prime_gpu()
     ctx = runtime.Context(0)
     yield ctx
     ctx.close()

@@ -121,7 +121,16 @@ def test_c_caller_renders_on_the_gpu(tmp_path):
     import subprocess
     exe = _build_c_caller(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)
+    if r.returncode != 0:
+        # diagnosis for the record: is the box alive (pure-HIP canary), and which kernel was the last one dispatched
+        from jxl_oxide_amd import runtime
+        canary = runtime.gpu_canary(attempts=1, quiet=True)
+        t = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, AMD_LOG_LEVEL="3", AMD_SERIALIZE_KERNEL="3", JXLGPU_DEBUG_SYNC="1"))
+        tail = [l for l in t.stderr.splitlines() if "ShaderName" in l or "fault" in l.lower()][-6:]
+        raise AssertionError(f"C caller rc={r.returncode} stderr={r.stderr[-400:]!r}; canary now: {canary}; traced re-run rc={t.returncode}, "
+                             f"last dispatches: {tail}")
+    assert r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)
 
 
 def test_shared_reciprocal_division_is_exact(tmp_path):

@@ -1,0 +1,55 @@
+"""Box or library?  The first GPU test of a session (conftest.py orders it first): tools/_bin/canary is a pure-HIP
+program (tests/c/canary.hip: no libjxlgpu.so, no torch) that uses the HIP runtime the way the library does.  Round 3's
+driver run died with "Memory access fault by GPU node" in a 40-line C caller AND in smoke(), on one box, while the same
+snapshot ran clean on others; profiles/r04_fault_hunt.md holds what was done about it (240 fresh processes of those two
+shapes, the whole suite under the guard-page allocator in both modes: no fault, no out-of-bounds access).  This test
+makes the record say which it is the next time."""
+import os
+import subprocess
+
+import pytest
+
+from jxl_oxide_amd import runtime
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_box_canary_pure_hip_program_runs(capsys):
+    with capsys.disabled():
+        verdict = runtime.gpu_canary(attempts=3)
+        print(f"CANARY verdict: {verdict}", flush=True)
+    assert verdict != "missing", "tools/_bin/canary is not built: run __graft_entry__.build()"
+    assert verdict != "fault", ("BOX FAULT: the pure-HIP canary (no libjxlgpu.so, no torch) died in three fresh processes on this "
+                                "box - the GPU / driver of this lease is at fault, not the library")
+    assert verdict in ("ok", "ok-after-fault")
+
+
+def test_library_under_the_guard_page_allocator(tmp_path):
+    """Regression gate for out-of-bounds accesses: the C caller (16x8 dense), the smoke frame (264x200, every stage,
+    single and batched launches) and one Modular chain in fresh processes under JXLGPU_GUARD=1 and =2 — every device
+    buffer in its own mapping, unmapped pages on both sides, 0xff-filled.  A kernel that reads or writes outside a
+    buffer dies here with a GPU memory fault; one that depends on uninitialised memory returns wrong samples."""
+    import sys
+    from test_abi import _build_c_caller
+    exe = _build_c_caller(tmp_path)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import numpy as np\n"
+            "import __graft_entry__ as e\n"
+            "from jxl_oxide_amd import runtime\n"
+            "runtime.gpu_canary = lambda *a, **k: 'skipped'\n"
+            "e.smoke()\n"
+            "from jxl_oxide_amd.synth_modular import ModularWorkload\n"
+            "from oracle import pyoracle\n"
+            "ctx = runtime.Context(0)\n"
+            "for kw in (dict(kind='squeeze', lossy=False, xyb=False, i16=True, seed=3), dict(kind='squeeze', lossy=True, i16=False, seed=4)):\n"
+            "    wl = ModularWorkload(333, 200, **kw); d = wl.desc()\n"
+            "    exp = pyoracle.modular_inverse(d, wl.shapes(), wl.dtype)\n"
+            "    f = ctx.modular_upload(d); got = ctx.modular_inverse(f, wl.shapes(), wl.dtype); f.free()\n"
+            "    assert all(np.array_equal(g, x) for g, x in zip(got, exp))\n"
+            "ctx.close(); print('guarded ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    for mode in ("1", "2"):
+        env = dict(os.environ, JXLGPU_GUARD=mode)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and r.stdout.strip() == "ok", (mode, r.returncode, r.stdout, r.stderr[-600:])
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "guarded ok" in r.stdout, (mode, r.returncode, r.stdout[-300:], r.stderr[-600:])

@@ -95,7 +95,7 @@ def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) & 0xFFFF
     rng = np.random.default_rng(seed)
-    runtime.prime_gpu()
+    print("CANARY", runtime.gpu_canary())
     ctx = runtime.Context(0)
     t_end = time.time() + seconds
     n, bad = {"modular": 0, "vardct": 0}, []

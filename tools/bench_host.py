@@ -25,7 +25,7 @@ def main():
     from jxl_oxide_amd import abi, runtime
     from jxl_oxide_amd.synth import VardctWorkload
 
-    runtime.prime_gpu()
+    runtime.gpu_canary()
     ctx = runtime.Context(0)
     wl = VardctWorkload(args.width, args.height, seed=2000)
     mp = args.width * args.height / 1e6

@@ -11,7 +11,7 @@ from jxl_oxide_amd import abi, runtime
 from jxl_oxide_amd.synth_modular import ModularWorkload
 
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (7680, 4320)
-runtime.prime_gpu()
+runtime.gpu_canary()
 ctx = runtime.Context(0)
 stages = abi.STAGE_ALL | abi.STAGE_MODULAR_TO_FLOAT
 wl = ModularWorkload(W, H, kind="squeeze", lossy=True, i16=True, epf_iters=2, seed=3)

@@ -16,7 +16,7 @@ def main():
     variants = sys.argv[1:] or [""]
     from jxl_oxide_amd import abi, runtime
     from jxl_oxide_amd.synth import VardctWorkload
-    runtime.prime_gpu()
+    runtime.gpu_canary()
     wl = VardctWorkload(3840, 2160, seed=2000)
     d = wl.desc()
     stages = abi.STAGE_LF | abi.STAGE_TRANSFORM
