@@ -17,9 +17,15 @@
  * JXLGPU_OK (0) or a negative error code and never throw or abort across the boundary
  * (the reference's convention is `Result<T, jxl_render::Error>`, jxl-render/src/error.rs).
  *
- * Threading: a `jxlgpu_ctx` owns one HIP stream and may be used from one thread at a time; create
- * one ctx per rendering thread (the reference renders keyframes from arbitrary rayon workers,
- * jxl-oxide-cli/src/decode.rs:293-304).  There is no global state.
+ * Threading: a `jxlgpu_ctx` owns its HIP streams (render, upload, download) and may be used from one
+ * thread at a time; create one ctx per rendering thread (the reference renders keyframes from arbitrary
+ * rayon workers, jxl-oxide-cli/src/decode.rs:293-304).  There is no global state.  A ctx keeps a few host
+ * worker threads of its own for the per-frame work-list build of an upload (JXLGPU_HOST_THREADS=n, 0 = none).
+ *
+ * Asynchrony: jxlgpu_vardct_upload (grouped transport), a render with out == NULL and
+ * jxlgpu_frame_format_output into JXLGPU_MEM_HOST_PINNED memory return without waiting for the device; the
+ * operations of one frame run in the order they were called, transfers of one frame overlap the kernels of
+ * another.  jxlgpu_frame_wait / jxlgpu_synchronize wait.  jxlgpu_frame_free never blocks.
  */
 #ifndef JXLGPU_H_
 #define JXLGPU_H_
@@ -31,7 +37,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 15u
+#define JXLGPU_ABI_VERSION 16u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -164,7 +170,10 @@ typedef struct {
 /* One pass group's HF coefficients exactly as the decode loop of `write_hf_coeff` produces them
  * (jxl-vardct/src/hf_coeff.rs:97-254), before they would be stored into the coefficient grid:
  * for every `BlockInfo::Data` cell of the group in raster order (:97-106), for c in [Y, X, B]
- * (:138-140): the `non_zeros` count read at :188 and then that many (dx, dy, coeff) triples, where
+ * (:138-140): the number of coefficients actually decoded for it — the `non_zeros` value read at :188
+ * MINUS what was left of it when the loop ended early (the coefficient order ran out, or with `allow_partial`
+ * the bitstream ended inside the varblock: whatever was stored before that is kept, :207-244) — and then that
+ * many (dx, dy, coeff) triples, where
  * (dx, dy) is the coefficient's position inside the varblock after the need_transpose swap
  * (:236-241) and coeff = unpack_signed(ucoeff) << coeff_shift (:235).  The device transform
  * consumes these lists directly (no dense coefficient plane is ever built): the shim replaces the
@@ -256,6 +265,7 @@ typedef struct {
  * whether the pointers are host or device memory.                                               */
 #define JXLGPU_MEM_HOST 0u
 #define JXLGPU_MEM_DEVICE 1u
+#define JXLGPU_MEM_HOST_PINNED 2u /* host memory from jxlgpu_host_alloc: the DMA engine writes it directly */
 typedef struct {
     float* planes[3];
     uint32_t stride;
@@ -269,8 +279,19 @@ const char* jxlgpu_last_error(const jxlgpu_ctx* ctx);
 uint32_t jxlgpu_abi_version(void);
 /* Block until everything queued on the ctx's stream has finished. */
 int jxlgpu_synchronize(jxlgpu_ctx* ctx);
-/* The ctx's hipStream_t (so callers can record HIP events around launches). */
+/* The ctx's render hipStream_t (so callers can record HIP events around launches). */
 void* jxlgpu_stream(jxlgpu_ctx* ctx);
+/* Block until everything queued for `frame` (upload, renders, asynchronous output copies) has finished. */
+int jxlgpu_frame_wait(jxlgpu_ctx* ctx, jxlgpu_frame* frame);
+/* Pinned (page-locked) host memory, for output buffers the DMA engine writes directly (JXLGPU_MEM_HOST_PINNED):
+ * what a `Vec<u8>` output buffer of `ImageStream::write_to_buffer` (jxl-oxide/src/fb.rs:309-397) becomes when
+ * the caller wants the copy off its thread.  Free with jxlgpu_host_free.                                      */
+int jxlgpu_host_alloc(jxlgpu_ctx* ctx, size_t bytes, void** out);
+void jxlgpu_host_free(jxlgpu_ctx* ctx, void* p);
+/* Measurement hook: where the host time of the ctx's last jxlgpu_vardct_upload went, in milliseconds —
+ * ms[0] work-list / side-plane build (worker threads), ms[1] reserved (0), ms[2] device allocations + enqueueing
+ * the copies, ms[3] the whole call, ms[4] the arena's H2D copy on the device (HIP events; waits for it).      */
+int jxlgpu_upload_split(jxlgpu_ctx* ctx, double ms[5]);
 
 /* Measurement hook (no reference counterpart: the reference only has wall-clock MP/s in its CLI,
  * jxl-oxide-cli/src/decode.rs:164-209).  Brackets every launch group of the selected kind with
@@ -282,9 +303,11 @@ int jxlgpu_profile_select(jxlgpu_ctx* ctx, int group);
 int jxlgpu_profile_read(jxlgpu_ctx* ctx, double* total_ms, uint64_t* brackets);
 
 /* ---- VarDCT ---- */
-/* Copy one frame's decoded state to the device (H2D on the ctx stream, asynchronous for pinned
- * sources) and build the device-side tables.  The descriptor and everything it points to may be
- * released as soon as the call returns.                                                          */
+/* Copy one frame's decoded state to the device and build the device-side tables: the host builds every
+ * table into one pinned staging arena (worker threads), one asynchronous H2D copy on the ctx's upload stream
+ * moves it, the render stream waits for that copy by event.  The descriptor and everything it points to may
+ * be released as soon as the call returns (it has been copied); the call does not wait for the device, except
+ * with the dense / sparse coefficient transports and an LF frame, whose planes are copied synchronously.   */
 int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* desc, jxlgpu_frame** out_frame);
 /* Run the selected stages on the device.  `out` may be NULL (results stay in the frame's device
  * buffers, e.g. for benchmarking); otherwise the result of the last selected stage is written to
@@ -326,6 +349,7 @@ int jxlgpu_frame_result_size(const jxlgpu_frame* frame, uint32_t* width, uint32_
 /* upload + render(stages) + free in one call: the drop-in for `render_vardct` + filters + colour. */
 int jxlgpu_vardct_render_host(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* desc, uint32_t stages,
                               const JxlGpuOut* out);
+/* Never blocks: the frame's device memory is recycled once the work queued so far has finished. */
 void jxlgpu_frame_free(jxlgpu_ctx* ctx, jxlgpu_frame* frame);
 /* Dimensions of the output of `stages` for this frame (upsampling changes them). */
 int jxlgpu_frame_out_size(const jxlgpu_frame* frame, uint32_t stages, uint32_t* width, uint32_t* height);
@@ -378,7 +402,9 @@ typedef struct {
     uint32_t orientation;     /* ImageMetadata.orientation, 1..8 (EXIF numbering)                 */
 } JxlGpuFormatDesc;
 /* Writes out_w*out_h*3 samples (out_w/out_h swap for orientations 5..8) to `out` (host memory when
- * out_mem == JXLGPU_MEM_HOST, else a device pointer).  Needs a completed render on `frame`.       */
+ * out_mem == JXLGPU_MEM_HOST, a device pointer for JXLGPU_MEM_DEVICE).  Needs a render queued on `frame`.
+ * JXLGPU_MEM_HOST_PINNED (`out` from jxlgpu_host_alloc): asynchronous — the call returns once the kernel and the
+ * copy are queued, `out` is complete after jxlgpu_frame_wait(frame).                                          */
 int jxlgpu_frame_format_output(jxlgpu_ctx* ctx, jxlgpu_frame* frame, const JxlGpuFormatDesc* fmt,
                                void* out, uint32_t out_mem, uint32_t* out_w, uint32_t* out_h);
 

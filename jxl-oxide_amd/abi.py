@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -40,6 +40,7 @@ FMT_F32, FMT_U16, FMT_U8 = 0, 1, 2
 
 MEM_HOST = 0
 MEM_DEVICE = 1
+MEM_HOST_PINNED = 2
 
 TR_RCT, TR_PALETTE, TR_SQUEEZE = 0, 1, 2
 
@@ -277,6 +278,10 @@ _SYMBOLS = [
     ("jxlgpu_abi_version", C.c_uint32, []),
     ("jxlgpu_synchronize", C.c_int, [C.c_void_p]),
     ("jxlgpu_stream", C.c_void_p, [C.c_void_p]),
+    ("jxlgpu_frame_wait", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("jxlgpu_host_alloc", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("jxlgpu_host_free", None, [C.c_void_p, C.c_void_p]),
+    ("jxlgpu_upload_split", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("jxlgpu_profile_select", C.c_int, [C.c_void_p, C.c_int]),
     ("jxlgpu_profile_read", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("jxlgpu_vardct_upload", C.c_int, [C.c_void_p, C.POINTER(VardctDesc), C.POINTER(C.c_void_p)]),

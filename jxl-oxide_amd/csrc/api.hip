@@ -8,6 +8,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <new>
 #include <thread>
 
@@ -95,8 +99,9 @@ hipError_t ctx_dev_malloc(jxlgpu_ctx* ctx, void** out, size_t bytes) {
         return hipSuccess;
     }
     hipError_t e = hipMalloc(out, bytes);
-    if (e == hipErrorOutOfMemory && !ctx->pool.empty()) {  // give the pooled memory back and retry
+    if (e == hipErrorOutOfMemory) {  // wait for the frames being freed, give the pooled memory back and retry
         (void)hipGetLastError();
+        ctx_reap(ctx, true);
         for (auto& kv : ctx->pool) (void)hipFree(kv.second);
         ctx->pool.clear();
         ctx->pool_bytes = 0;
@@ -120,6 +125,120 @@ void ctx_dev_release(jxlgpu_ctx* ctx, void* p) {
     } else {
         (void)hipFree(p);
     }
+}
+
+// ---- host worker threads (one pool per context; the calling thread takes part)
+struct WorkerPool {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(uint32_t)>* fn = nullptr;
+    uint32_t n_tasks = 0, active = 0;
+    std::atomic<uint32_t> next{0};
+    uint64_t gen = 0;
+    bool stop = false;
+    explicit WorkerPool(unsigned n) {
+        for (unsigned i = 0; i < n; ++i) threads.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv_work.notify_all();
+        for (auto& t : threads) t.join();
+    }
+    void drain(const std::function<void(uint32_t)>& f) {
+        for (;;) {
+            const uint32_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_tasks) break;
+            f(i);
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m);
+            cv_work.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            const std::function<void(uint32_t)>* f = fn;
+            lk.unlock();
+            drain(*f);
+            lk.lock();
+            if (--active == 0) cv_done.notify_one();
+        }
+    }
+    // f(0) ... f(n - 1), each exactly once, on the pool + the caller; returns when all are done
+    void run(uint32_t n, const std::function<void(uint32_t)>& f) {
+        if (threads.empty() || n <= 1) {
+            for (uint32_t i = 0; i < n; ++i) f(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            fn = &f; n_tasks = n; next.store(0); active = (uint32_t)threads.size(); ++gen;
+        }
+        cv_work.notify_all();
+        drain(f);
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return active == 0; });
+    }
+};
+
+void ctx_host_parallel(jxlgpu_ctx* ctx, uint32_t n, const std::function<void(uint32_t)>& f) {
+    if (!ctx->workers && ctx->host_threads != 0 && n > 1) {
+        unsigned want = ctx->host_threads > 0 ? (unsigned)ctx->host_threads : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        ctx->workers = new (std::nothrow) WorkerPool(want > 1 ? want - 1 : 0);
+    }
+    if (ctx->workers) ctx->workers->run(n, f);
+    else for (uint32_t i = 0; i < n; ++i) f(i);
+}
+
+static hipEvent_t ctx_event(jxlgpu_ctx* ctx) {
+    if (!ctx->ev_spare.empty()) { hipEvent_t e = ctx->ev_spare.back(); ctx->ev_spare.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    return e;
+}
+
+void ctx_reap(jxlgpu_ctx* ctx, bool wait) {
+    while (!ctx->deferred.empty()) {
+        Deferred& d = ctx->deferred.front();
+        bool done = true;
+        for (hipEvent_t e : d.ev) {
+            if (!e) continue;
+            if (wait) (void)hipEventSynchronize(e);
+            else if (hipEventQuery(e) != hipSuccess) { done = false; break; }
+        }
+        if (!done) { (void)hipGetLastError(); break; }  // hipErrorNotReady is not an error of ours; entries complete in order
+        for (void* p : d.ptrs) ctx_dev_release(ctx, p);
+        if (d.modular && d.modular_free) d.modular_free(d.modular);
+        for (hipEvent_t e : d.ev) if (e) ctx->ev_spare.push_back(e);
+        ctx->deferred.pop_front();
+    }
+}
+
+void ctx_defer_release(jxlgpu_ctx* ctx, std::vector<void*>&& ptrs, void* modular, void (*modular_free)(void*)) {
+    if (ptrs.empty() && !modular) return;
+    Deferred d;
+    d.ptrs = std::move(ptrs);
+    d.modular = modular; d.modular_free = modular_free;
+    hipStream_t st[4] = {ctx->stream, ctx->stream2, ctx->stream_up, ctx->stream_down};
+    bool ok = true;
+    for (int i = 0; i < 4; ++i) {
+        d.ev[i] = ctx_event(ctx);
+        ok = ok && d.ev[i] && hipEventRecord(d.ev[i], st[i]) == hipSuccess;
+    }
+    if (!ok) {  // cannot track: fall back to draining the device
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        for (hipEvent_t& e : d.ev) { if (e) ctx->ev_spare.push_back(e); e = nullptr; }
+    }
+    ctx->deferred.push_back(std::move(d));
+    ctx_reap(ctx, false);
+}
+
+void frame_mark(jxlgpu_ctx* ctx, jxlgpu_frame* f, hipStream_t s) {
+    if (!f->ev_last && hipEventCreateWithFlags(&f->ev_last, hipEventDisableTiming) != hipSuccess) { f->ev_last = nullptr; return; }
+    f->ev_last_set = hipEventRecord(f->ev_last, s) == hipSuccess;
 }
 
 hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const in[3], uint32_t in_stride,
@@ -199,15 +318,12 @@ int dev_upload(jxlgpu_ctx* ctx, jxlgpu_frame* f, T** out, const std::vector<T>& 
     return JXLGPU_OK;
 }
 
-// temporaries of the upload (freed when it returns, after a stream sync)
+// temporaries of the upload: released once the work queued by the upload has finished (never blocks)
 struct Scratch {
     jxlgpu_ctx* ctx = nullptr;
     std::vector<void*> ptrs;
     ~Scratch() {
-        if (ptrs.empty()) return;
-        (void)hipStreamSynchronize(ctx->stream);  // error paths may leave kernels reading these
-        (void)hipStreamSynchronize(ctx->stream2);
-        for (void* p : ptrs) ctx_dev_release(ctx, p);
+        if (!ptrs.empty()) ctx_defer_release(ctx, std::move(ptrs));
     }
     int alloc(jxlgpu_ctx* c, void** out, size_t bytes) {
         ctx = c;
@@ -408,9 +524,12 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     ctx->tune.sqz_h_rows = getenv("JXLGPU_SQZ_H_ROWS") != nullptr;
     if (const char* v = getenv("JXLGPU_UP2_VARIANT")) ctx->tune.up2_variant = atoi(v);
     if (const char* v = getenv("JXLGPU_UP2_ROWS")) ctx->tune.up2_rows = atoi(v);
+    if (const char* v = getenv("JXLGPU_HOST_THREADS")) ctx->host_threads = std::max(0, atoi(v));
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream_down, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
@@ -438,12 +557,26 @@ void jxlgpu_destroy(jxlgpu_ctx* ctx) {
         (void)hipFree(ctx->tr_prof);
     }
 #endif
+    for (hipStream_t st : {ctx->stream, ctx->stream2, ctx->stream_up, ctx->stream_down})
+        if (st) (void)hipStreamSynchronize(st);
+    ctx_reap(ctx, true);
+    delete ctx->workers;
+    ctx->workers = nullptr;
+    for (StageBuf& sb : ctx->stage) {
+        if (sb.p) (void)hipHostFree(sb.p);
+        if (sb.ev) (void)hipEventDestroy(sb.ev);
+    }
+    for (hipEvent_t e : ctx->ev_spare) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_h2d) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream_up) (void)hipStreamDestroy(ctx->stream_up);
+    if (ctx->stream_down) (void)hipStreamDestroy(ctx->stream_down);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (hipEvent_t e : ctx->ev_d2h) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_slice) if (e) (void)hipEventDestroy(e);
     if (ctx->noise_jump) ctx_dev_release(ctx, ctx->noise_jump);
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     while (!ctx->guard_live.empty()) guard_free(ctx, ctx->guard_live.begin()->first);
@@ -456,7 +589,49 @@ const char* jxlgpu_last_error(const jxlgpu_ctx* ctx) { return ctx ? ctx->last_er
 int jxlgpu_synchronize(jxlgpu_ctx* ctx) {
     if (!ctx) return JXLGPU_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_up));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_down));
+    ctx_reap(ctx, false);
+    return JXLGPU_OK;
+}
+
+int jxlgpu_frame_wait(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
+    if (!ctx || !f) return JXLGPU_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (f->ev_last && f->ev_last_set) {
+        HIP_TRY(ctx, hipEventSynchronize(f->ev_last));
+        return JXLGPU_OK;
+    }
+    return jxlgpu_synchronize(ctx);
+}
+
+int jxlgpu_host_alloc(jxlgpu_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out || !bytes) return JXLGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return JXLGPU_OK;
+}
+
+void jxlgpu_host_free(jxlgpu_ctx* ctx, void* p) {
+    if (!p) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipHostFree(p);
+}
+
+int jxlgpu_upload_split(jxlgpu_ctx* ctx, double ms[5]) {
+    if (!ctx || !ms) return JXLGPU_ERR_INVALID_ARG;
+    for (int i = 0; i < 4; ++i) ms[i] = ctx->up_split[i];
+    ms[4] = 0.0;
+    if (ctx->h2d_timed && ctx->ev_h2d[0] && ctx->ev_h2d[1]) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_h2d[1]));
+        float t = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->ev_h2d[0], ctx->ev_h2d[1]));
+        ms[4] = t;
+    }
     return JXLGPU_OK;
 }
 
@@ -485,22 +660,36 @@ int jxlgpu_profile_read(jxlgpu_ctx* ctx, double* total_ms, uint64_t* brackets) {
     return JXLGPU_OK;
 }
 
+// Never blocks: the frame's device buffers go back to the pool once everything that was queued on the ctx's
+// streams at this moment has finished (ctx_defer_release); the handle is dead when the call returns.
+static void frame_collect(jxlgpu_frame* f, std::vector<void*>* ptrs, std::vector<std::pair<void*, void (*)(void*)>>* mods) {
+    for (auto& sub : f->subs)
+        if (sub.child) frame_collect(sub.child, ptrs, mods);
+    ptrs->insert(ptrs->end(), f->allocs.begin(), f->allocs.end());
+    if (f->modular && f->modular_free) mods->emplace_back(f->modular, f->modular_free);
+    if (f->ev_last) (void)hipEventDestroy(f->ev_last);
+    delete f;
+}
+
 void jxlgpu_frame_free(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     if (!f) return;
-    if (ctx) {
-        (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
-        // the side stream too: an error return between a fork and its join (batched render) leaves
-        // kernels there that the main stream never waited for
-        (void)hipStreamSynchronize(ctx->stream2);
+    std::vector<void*> ptrs;
+    std::vector<std::pair<void*, void (*)(void*)>> mods;
+    if (!ctx) {
+        (void)hipDeviceSynchronize();
+        frame_collect(f, &ptrs, &mods);
+        for (void* p : ptrs) (void)hipFree(p);
+        for (auto& m : mods) m.second(m.first);
+        return;
     }
-    for (auto& sub : f->subs) jxlgpu_frame_free(ctx, sub.child);
-    for (void* p : f->allocs) {
-        if (ctx) ctx_dev_release(ctx, p);
-        else (void)hipFree(p);
+    (void)hipSetDevice(ctx->device);
+    frame_collect(f, &ptrs, &mods);
+    if (mods.empty()) {
+        ctx_defer_release(ctx, std::move(ptrs));
+    } else {
+        ctx_defer_release(ctx, std::move(ptrs), mods[0].first, mods[0].second);
+        for (size_t i = 1; i < mods.size(); ++i) ctx_defer_release(ctx, {}, mods[i].first, mods[i].second);
     }
-    if (f->modular && f->modular_free) f->modular_free(f->modular);
-    delete f;
 }
 
 int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_frame** out_frame) {
@@ -511,10 +700,71 @@ int jxlgpu_vardct_upload(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, jxlgpu_fram
     return vardct_upload_impl(ctx, d, UploadOpts{}, out_frame);
 }
 
+}  // extern "C" (reopened below)
+
 // One frame geometry: every channel has the same size.  `o` lets upload_subsampled build the
 // per-geometry children of a chroma-subsampled frame from derived descriptors.
+//
+// Host side of an upload, per frame (the reference's equivalent is the serial `for_each_varblocks` scan,
+// jxl-render/src/vardct/mod.rs:693-730, once per group inside the rayon loop):
+//   phase 1 (worker threads): the LF groups' grids are copied into frame-level planes; every pass group's
+//            varblocks are validated and counted per work-list slot; the groups' non-zero lists are copied;
+//   prefix : where each (group, slot) run starts in the entry array;
+//   phase 2 (worker threads): the entries are written.
+// Everything lands in ONE pinned staging arena, crosses PCIe as ONE hipMemcpyAsync on the ctx's upload stream
+// into ONE device allocation, and the render stream waits for that copy by event: the call returns without
+// waiting for the device (except for the dense / sparse transports, whose caller-owned planes are copied
+// with blocking hipMemcpy's, and the LF-frame planes).
+namespace {
+
+// Work-list slots: the shape classes in launch order, the special 8x8 family split by transform type (its kernel
+// wants runs of one type).  Slot order == order of the entry array.
+constexpr int kNumSlots = CLS_COUNT + 8;
+int slot_of(int t) {
+    switch (t) {
+        case JXLGPU_DCT8: return 0;
+        case JXLGPU_HORNUSS: return 1;
+        case JXLGPU_DCT2: return 2;
+        case JXLGPU_DCT4: return 3;
+        case JXLGPU_DCT4X8: return 4;
+        case JXLGPU_DCT8X4: return 5;
+        case JXLGPU_AFV0: return 6;
+        case JXLGPU_AFV1: return 7;
+        case JXLGPU_AFV2: return 8;
+        case JXLGPU_AFV3: return 9;
+        default: return class_of(t) + 8;  // CLS_16x16 (2) -> 10 ... CLS_BIG (13) -> 21
+    }
+}
+int class_of_slot(int s) { return s == 0 ? CLS_DCT8 : (s <= 9 ? CLS_SPECIAL8 : s - 8); }
+
+struct ArenaItem { size_t off, bytes; void** dev; };
+struct Arena {
+    std::vector<ArenaItem> items;
+    size_t total = 0;
+    // reserves `bytes` (256-byte aligned); *dev receives the device address once the arena is placed
+    size_t add(size_t bytes, void** dev) {
+        const size_t off = total;
+        items.push_back({off, bytes, dev});
+        total += (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
+        return off;
+    }
+};
+
+size_t pool_bucket(size_t bytes) {  // sizes that differ by a few per cent share a pool bucket
+    if (bytes <= 4096) return 4096;
+    size_t step = (size_t)1 << 12;
+    while (step * 16 < bytes) step <<= 1;
+    return (bytes + step - 1) / step * step;
+}
+
+}  // namespace
+
 int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadOpts& o, jxlgpu_frame** out_frame) {
     *out_frame = nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+    };
     if (d->jpeg_upsampling[0] | d->jpeg_upsampling[1] | d->jpeg_upsampling[2])
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "internal: subsampled descriptor in the single-geometry upload");
     if (d->group_dim != 256) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "only group_dim == 256 is supported");
@@ -540,6 +790,7 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     }
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx_reap(ctx, false);
     jxlgpu_frame* f = new (std::nothrow) jxlgpu_frame();
     if (!f) return JXLGPU_ERR_OOM;
     struct Guard {
@@ -574,19 +825,12 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     const size_t npix = (size_t)f->wr * f->hr;
     const bool i16 = d->lf_sample_type == JXLGPU_SAMPLE_I16;
     f->lf_is_i16 = i16;
-
-    // ---- assemble frame-level side planes from the per-LF-group grids
-    std::vector<uint8_t> kind(ncell, JXLGPU_BLOCK_UNINIT);
-    std::vector<int32_t> hf_mul(ncell, 0);
-    std::vector<float> sigma(ncell, d->filter.epf_sigma_for_modular);
-    std::vector<float> kx_map(ntile, 0.0f), kb_map(ntile, 0.0f);
-    std::vector<float> lf_scale((size_t)f->num_lf_groups * 3, 0.0f);
-    std::vector<uint8_t> lfq_host[3];
     const size_t lf_elem = i16 ? 2 : 4;
-    for (int c = 0; c < 3; ++c) lfq_host[c].assign(ncell * lf_elem, 0);
-    std::vector<uint8_t> has_meta(f->num_lf_groups, 0);
+    const uint32_t w8 = f->w8, w64 = f->w64;
 
+    // ---- serial checks of the LF groups (cheap: a handful per frame); everything per cell runs on the workers
     const uint64_t scale_inv = (uint64_t)d->global_scale * (uint64_t)d->quant_lf;
+    std::vector<uint8_t> has_meta(f->num_lf_groups, 0);
     for (uint32_t g = 0; g < f->num_lf_groups; ++g) {
         const JxlGpuLfGroup& lg = d->lf_groups[g];
         const uint32_t gx = g % f->lf_groups_per_row, gy = g / f->lf_groups_per_row;
@@ -594,156 +838,377 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
         if (lg.width_px != exp_w || lg.height_px != exp_h)
             return fail(ctx, JXLGPU_ERR_INVALID_ARG, "LF group size does not match the frame geometry");
         if (lg.extra_precision > 3) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "extra_precision > 3");
-        const uint32_t bw = ceil_div(lg.width_px, 8), bh = ceil_div(lg.height_px, 8);
-        const uint32_t cw = ceil_div(lg.width_px, 64), ch = ceil_div(lg.height_px, 64);
-        const size_t cell0 = (size_t)gy * f->lfg_cells_y * f->w8 + (size_t)gx * f->lfg_cells_x;
-        // copy_lf_dequant scale (vardct/mod.rs:398-400), f64 on the host exactly as the reference
-        const int32_t precision_scale = 1 << (9 - lg.extra_precision);
-        for (int c = 0; c < 3; ++c)
-            lf_scale[(size_t)g * 3 + c] = (float)((double)d->m_lf[c] * (double)precision_scale / (double)scale_inv);
-        // util.rs:275-298: lf_x <- channel 1, lf_y <- channel 0, lf_b <- channel 2
-        static const int SRC[3] = {1, 0, 2};
-        for (int c = 0; c < 3 && !use_lf_frame; ++c) {
-            const uint8_t* src = static_cast<const uint8_t*>(lg.lf_quant[SRC[c]]);
-            if (!src) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null lf_quant");
-            for (uint32_t y = 0; y < bh; ++y)
-                memcpy(&lfq_host[c][(cell0 + (size_t)y * f->w8) * lf_elem], src + (size_t)y * bw * lf_elem, bw * lf_elem);
-        }
+        if (!use_lf_frame && (!lg.lf_quant[0] || !lg.lf_quant[1] || !lg.lf_quant[2]))
+            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null lf_quant");
         if (!lg.has_hf_meta) continue;
         if (!lg.block_kind || !lg.hf_mul || !lg.x_from_y || !lg.b_from_y)
             return fail(ctx, JXLGPU_ERR_INVALID_ARG, "HfMetadata pointers missing");
         has_meta[g] = 1;
-        for (uint32_t y = 0; y < bh; ++y)
-            for (uint32_t x = 0; x < bw; ++x) {
-                const size_t o = cell0 + (size_t)y * f->w8 + x;
-                kind[o] = lg.block_kind[(size_t)y * bw + x];
-                hf_mul[o] = lg.hf_mul[(size_t)y * bw + x];
-                if (lg.epf_sigma) sigma[o] = lg.epf_sigma[(size_t)y * bw + x];
-            }
-        const size_t t0 = (size_t)gy * (lf_px_y / 64) * f->w64 + (size_t)gx * (lf_px_x / 64);
-        if (o.no_cfl) continue;  // vardct/mod.rs:355: no chroma-from-luma on subsampled frames
-        for (uint32_t y = 0; y < ch; ++y)
-            for (uint32_t x = 0; x < cw; ++x) {
-                // chroma_from_luma_hf_grouped, vardct/mod.rs:590-593
-                kx_map[t0 + (size_t)y * f->w64 + x] =
-                    d->base_correlation_x + ((float)lg.x_from_y[(size_t)y * cw + x] / (float)d->colour_factor);
-                kb_map[t0 + (size_t)y * f->w64 + x] =
-                    d->base_correlation_b + ((float)lg.b_from_y[(size_t)y * cw + x] / (float)d->colour_factor);
-            }
     }
-
-    // ---- varblock work lists, one per shape class, ordered by 256x256 group then raster
-    struct VbEntry { uint4 e; uint32_t cyx; };   // cyx: non-zero counts Y | X << 16 (grouped transport)
-    std::vector<VbEntry> lists[CLS_COUNT];
-    std::vector<uint32_t> nometa;
     const uint32_t gcells = d->group_dim / 8;
     const uint32_t groups_x = ceil_div(d->width, d->group_dim), groups_y = ceil_div(d->height, d->group_dim);
-    if (grouped && (d->num_hf_groups != groups_x * groups_y || !d->hf_groups))
+    const uint32_t n_groups = groups_x * groups_y;
+    if (grouped && (d->num_hf_groups != n_groups || !d->hf_groups))
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "num_hf_groups does not match the frame size");
-    uint64_t nz_total = 0;  // list words in front of the current group
-    for (uint32_t gy = 0; gy < groups_y; ++gy)
-        for (uint32_t gx = 0; gx < groups_x; ++gx) {
-            const uint32_t lfg = (gy * gcells / f->lfg_cells_y) * f->lf_groups_per_row + gx * gcells / f->lfg_cells_x;
-            const JxlGpuHfGroup* hg = grouped ? &d->hf_groups[gy * groups_x + gx] : nullptr;
-            if (hg && ((hg->num_varblocks && !hg->nz_count) || (hg->num_nz && !hg->nz)))
+    std::vector<uint64_t> nz_base(n_groups + 1, 0);  // list words in front of each group
+    if (grouped) {
+        for (uint32_t g = 0; g < n_groups; ++g) {
+            const JxlGpuHfGroup& hg = d->hf_groups[g];
+            if ((hg.num_varblocks && !hg.nz_count) || (hg.num_nz && !hg.nz))
                 return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null list pointers in an HF group");
-            uint32_t vb_k = 0;      // varblocks of this group seen so far (decode order)
-            uint64_t nz_k = 0;      // their list words
-            if (!has_meta[lfg]) {
-                if (hg && (hg->num_varblocks || hg->num_nz))
-                    return fail(ctx, JXLGPU_ERR_INVALID_ARG, "HF lists for a group without HfMetadata");
-                nometa.push_back(gy * groups_x + gx);
-                continue;
-            }
-            const uint32_t x1 = std::min(f->w8, (gx + 1) * gcells), y1 = std::min(f->h8, (gy + 1) * gcells);
-            for (uint32_t y = gy * gcells; y < y1; ++y)
-                for (uint32_t x = gx * gcells; x < x1; ++x) {
-                    const uint8_t t = kind[(size_t)y * f->w8 + x];
-                    if (t > 26) continue;
-                    const uint32_t bw = kSize[t][0], bh = kSize[t][1];
-                    // hf_metadata.rs:144-158: a varblock never crosses a group; keep the device safe
-                    if (x + bw > x1 || y + bh > y1) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "varblock crosses a group border");
-                    if (hf_mul[(size_t)y * f->w8 + x] <= 0) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "non-positive HfMul");
-                    if (!d->dequant[t][0] || !d->dequant[t][1] || !d->dequant[t][2])
-                        return fail(ctx, JXLGPU_ERR_INVALID_ARG, "missing dequant matrix for a used transform");
-                    VbEntry v{make_uint4(x | (y << 16), t, (uint32_t)hf_mul[(size_t)y * f->w8 + x], 0), 0};
-                    if (hg) {
-                        static const uint16_t kNone[3] = {0, 0, 0};
-                        if (vb_k >= hg->num_varblocks && !d->allow_partial)
-                            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "fewer nz_count entries than varblocks in a group");
-                        // allow_partial: the group's decode stopped before this varblock — no HF coefficients
-                        const uint16_t* cnt = vb_k < hg->num_varblocks ? hg->nz_count + 3 * (size_t)vb_k : kNone;  // decode order: Y, X, B
-                        const uint32_t max_nz = 63u * bw * bh;                 // hf_coeff.rs:193
-                        if (cnt[0] > max_nz || cnt[1] > max_nz || cnt[2] > max_nz)
-                            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "non_zeros too large");
-                        v.e.w = (uint32_t)(nz_total + nz_k);
-                        v.e.y |= (uint32_t)cnt[2] << 16;
-                        v.cyx = (uint32_t)cnt[0] | (uint32_t)cnt[1] << 16;
-                        nz_k += (uint64_t)cnt[0] + cnt[1] + cnt[2];
-                        ++vb_k;
-                    }
-                    lists[class_of(t)].push_back(v);
-                }
-            if (hg) {
-                if ((vb_k != hg->num_varblocks && !(d->allow_partial && vb_k > hg->num_varblocks)) || nz_k != hg->num_nz)
-                    return fail(ctx, JXLGPU_ERR_INVALID_ARG, "HF group lists do not match the block map");
-                nz_total += nz_k;
-                if (nz_total >= (1ull << 32)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "more than 2^32 non-zero coefficients");
-            }
+            nz_base[g + 1] = nz_base[g] + hg.num_nz;
         }
+        if (nz_base[n_groups] >= (1ull << 32)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "more than 2^32 non-zero coefficients");
+    }
+    const uint64_t nz_total = nz_base[n_groups];
 
-    // ---- dequant matrices (only the types that appear), flat, 16-byte aligned offsets
-    std::vector<float> deq;
-    std::vector<uint32_t> deq_off(27 * 3, 0);
-    {
-        bool used[27] = {};
-        for (size_t i = 0; i < ncell; ++i)
-            if (kind[i] <= 26) used[kind[i]] = true;
-        for (int t = 0; t < 27; ++t) {
-            if (!used[t]) continue;
-            const size_t n = (size_t)kSize[t][0] * 8 * kSize[t][1] * 8;
-            for (int c = 0; c < 3; ++c) {
-                deq_off[t * 3 + c] = (uint32_t)deq.size();
-                deq.insert(deq.end(), d->dequant[t][c], d->dequant[t][c] + n);
-                f->deq_off_host[t][c] = deq_off[t * 3 + c];
+    // ---- the arena: fixed-size items first, the lists (upper bounds) behind them
+    Arena ar;
+    void* lfq_dev[3] = {};
+    const size_t off_kind = ar.add(ncell, reinterpret_cast<void**>(&f->kind));
+    const size_t off_mul = ar.add(ncell * 4, reinterpret_cast<void**>(&f->hf_mul));
+    const size_t off_sigma = ar.add(ncell * 4, reinterpret_cast<void**>(&f->sigma));
+    const size_t off_kx = ar.add(ntile * 4, reinterpret_cast<void**>(&f->kx_map));
+    const size_t off_kb = ar.add(ntile * 4, reinterpret_cast<void**>(&f->kb_map));
+    const size_t off_scale = ar.add((size_t)f->num_lf_groups * 12, reinterpret_cast<void**>(&f->lf_scale));
+    size_t off_lfq[3];
+    for (int c = 0; c < 3; ++c) off_lfq[c] = ar.add(ncell * lf_elem, &lfq_dev[c]);
+    const size_t off_deq_off = ar.add(27 * 3 * 4, reinterpret_cast<void**>(&f->deq_off));
+    const size_t off_lut = ar.add(256 * 4, reinterpret_cast<void**>(&f->deq_lut));
+    size_t off_sec[3];
+    for (int i = 0, n = 64; i < 3; ++i, n *= 2) off_sec[i] = ar.add((size_t)(n / 2) * 4, reinterpret_cast<void**>(&f->sec[i]));
+    std::vector<float> upw[3];
+    size_t off_upw[3] = {};
+    if (upf > 1) {
+        const float* src[3] = {d->upsampling.up2_weight, d->upsampling.up4_weight, d->upsampling.up8_weight};
+        const int ks[3] = {2, 4, 8};
+        for (int i = 0; i < 3; ++i) {
+            if (!src[i]) continue;
+            upw[i] = expand_up_weights(src[i], ks[i]);
+            off_upw[i] = ar.add(upw[i].size() * 4, reinterpret_cast<void**>(&f->up_weights[i]));
+            if (i == 0) {
+                memcpy(f->up2_wq, upw[i].data(), sizeof(f->up2_wq));
+                f->have_up2 = true;
             }
         }
+        const int need = upf == 2 ? 0 : upf == 4 ? 1 : 2;
+        if (upw[need].empty()) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "upsampling weights missing");
+    }
+    const size_t off_nz = grouped ? ar.add((size_t)nz_total * 4, reinterpret_cast<void**>(&f->nz)) : 0;
+    // upper bounds: one entry per cell, every dequantisation matrix, every group without HfMetadata
+    size_t deq_max = 0;
+    for (int t = 0; t < 27; ++t) deq_max += (size_t)kSize[t][0] * kSize[t][1] * 64 * 3;
+    const size_t off_entries = ar.add(ncell * sizeof(uint4), reinterpret_cast<void**>(&f->entries));
+    const size_t off_nzc = grouped ? ar.add(ncell * 4, reinterpret_cast<void**>(&f->nzc)) : 0;
+    const size_t off_nometa = ar.add((size_t)n_groups * 4, reinterpret_cast<void**>(&f->nometa_groups));
+    const size_t off_deq = ar.add(deq_max * 4, reinterpret_cast<void**>(&f->dequant));
+
+    // ---- staging buffer (pinned; reused round-robin, guarded by the event behind its last copy)
+    StageBuf& sb = ctx->stage[ctx->stage_next++ % 3];
+    if (sb.busy) {
+        HIP_TRY(ctx, hipEventSynchronize(sb.ev));
+        sb.busy = false;
+    }
+    if (sb.cap < ar.total) {
+        if (sb.p) (void)hipHostFree(sb.p);
+        sb.p = nullptr; sb.cap = 0;
+        const size_t cap = pool_bucket(ar.total + ar.total / 8);
+        HIP_TRY(ctx, hipHostMalloc(&sb.p, cap, hipHostMallocDefault));
+        sb.cap = cap;
+    }
+    if (!sb.ev) HIP_TRY(ctx, hipEventCreateWithFlags(&sb.ev, hipEventDisableTiming));
+    char* const H = static_cast<char*>(sb.p);
+    uint8_t* const kind = reinterpret_cast<uint8_t*>(H + off_kind);
+    int32_t* const hf_mul = reinterpret_cast<int32_t*>(H + off_mul);
+    float* const sigma = reinterpret_cast<float*>(H + off_sigma);
+    float* const kx_map = reinterpret_cast<float*>(H + off_kx);
+    float* const kb_map = reinterpret_cast<float*>(H + off_kb);
+    float* const lf_scale = reinterpret_cast<float*>(H + off_scale);
+    uint4* const entries = reinterpret_cast<uint4*>(H + off_entries);
+    uint32_t* const nzc = grouped ? reinterpret_cast<uint32_t*>(H + off_nzc) : nullptr;
+    uint32_t* const nzw = grouped ? reinterpret_cast<uint32_t*>(H + off_nz) : nullptr;
+
+    // ---- phase 1
+    struct GroupScan {
+        uint32_t count[kNumSlots];
+        uint32_t used_mask;      // transform types present (bit t)
+        uint32_t nometa;
+        int err;
+        const char* msg;
+    };
+    std::vector<GroupScan> gs(n_groups);
+    // one pass group's varblocks in decode order (raster inside the group): `emit(slot, entry, cyx)`; returns an error text or null
+    auto scan_group = [&](uint32_t g, auto&& emit, GroupScan* st) -> const char* {
+        const uint32_t gx = g % groups_x, gy = g / groups_x;
+        const uint32_t lfx = gx * gcells / f->lfg_cells_x, lfy = gy * gcells / f->lfg_cells_y;
+        const uint32_t lfg = lfy * f->lf_groups_per_row + lfx;
+        const JxlGpuHfGroup* hg = grouped ? &d->hf_groups[g] : nullptr;
+        if (!has_meta[lfg]) {
+            if (hg && (hg->num_varblocks || hg->num_nz)) return "HF lists for a group without HfMetadata";
+            if (st) st->nometa = 1;
+            return nullptr;
+        }
+        const JxlGpuLfGroup& lg = d->lf_groups[lfg];
+        const uint32_t lbw = ceil_div(lg.width_px, 8);                      // row stride of the LF group's grids
+        const uint32_t cx0 = lfx * f->lfg_cells_x, cy0 = lfy * f->lfg_cells_y;  // the LF group's first cell
+        const uint32_t x1 = std::min(w8, (gx + 1) * gcells), y1 = std::min(f->h8, (gy + 1) * gcells);
+        uint32_t vb_k = 0;   // varblocks of this group seen so far (decode order)
+        uint64_t nz_k = 0;   // their list words
+        static const uint16_t kNone[3] = {0, 0, 0};
+        for (uint32_t y = gy * gcells; y < y1; ++y) {
+            const uint8_t* krow = lg.block_kind + (size_t)(y - cy0) * lbw - cx0;
+            const int32_t* mrow = lg.hf_mul + (size_t)(y - cy0) * lbw - cx0;
+            for (uint32_t x = gx * gcells; x < x1; ++x) {
+                const uint8_t t = krow[x];
+                if (t > 26) continue;
+                const uint32_t bw = kSize[t][0], bh = kSize[t][1];
+                // hf_metadata.rs:144-158: a varblock never crosses a group; keep the device safe
+                if (x + bw > x1 || y + bh > y1) return "varblock crosses a group border";
+                const int32_t mul = mrow[x];
+                if (mul <= 0) return "non-positive HfMul";
+                if (!d->dequant[t][0] || !d->dequant[t][1] || !d->dequant[t][2]) return "missing dequant matrix for a used transform";
+                uint4 e = make_uint4(x | (y << 16), t, (uint32_t)mul, 0);
+                uint32_t cyx = 0;
+                if (hg) {
+                    if (vb_k >= hg->num_varblocks && !d->allow_partial) return "fewer nz_count entries than varblocks in a group";
+                    // allow_partial: the group's decode stopped before this varblock — no HF coefficients
+                    const uint16_t* cnt = vb_k < hg->num_varblocks ? hg->nz_count + 3 * (size_t)vb_k : kNone;  // decode order: Y, X, B
+                    const uint32_t max_nz = 63u * bw * bh;                 // hf_coeff.rs:193
+                    if (cnt[0] > max_nz || cnt[1] > max_nz || cnt[2] > max_nz) return "non_zeros too large";
+                    e.w = (uint32_t)(nz_base[g] + nz_k);
+                    e.y |= (uint32_t)cnt[2] << 16;
+                    cyx = (uint32_t)cnt[0] | (uint32_t)cnt[1] << 16;
+                    nz_k += (uint64_t)cnt[0] + cnt[1] + cnt[2];
+                    ++vb_k;
+                }
+                emit(slot_of(t), e, cyx);
+                if (st) st->used_mask |= 1u << t;
+            }
+        }
+        if (hg && ((vb_k != hg->num_varblocks && !(d->allow_partial && vb_k > hg->num_varblocks)) || nz_k != hg->num_nz))
+            return "HF group lists do not match the block map";
+        return nullptr;
+    };
+
+    // tasks: [0, n_rows) plane assembly by cell-row chunk; then the groups' scans; then the list copies
+    const uint32_t row_chunk = 32, n_row_tasks = ceil_div(f->h8, row_chunk);
+    const uint32_t nz_chunks = grouped ? std::max<uint32_t>(1, std::min<uint32_t>(16, (uint32_t)(nz_total >> 16))) : 0;
+    const auto t_phase1 = std::chrono::steady_clock::now();
+    ctx_host_parallel(ctx, n_row_tasks + n_groups + nz_chunks, [&](uint32_t task) {
+        if (task < n_row_tasks) {
+            // frame-level side planes from the per-LF-group grids, cell rows [r0, r1)
+            const uint32_t r0 = task * row_chunk, r1 = std::min(f->h8, r0 + row_chunk);
+            static const int SRC[3] = {1, 0, 2};  // util.rs:275-298: lf_x <- channel 1, lf_y <- channel 0, lf_b <- channel 2
+            for (uint32_t y = r0; y < r1; ++y) {
+                const uint32_t lfy = y / f->lfg_cells_y, ly = y - lfy * f->lfg_cells_y;
+                for (uint32_t lfx = 0; lfx < f->lf_groups_per_row; ++lfx) {
+                    const JxlGpuLfGroup& lg = d->lf_groups[lfy * f->lf_groups_per_row + lfx];
+                    const uint32_t bw = ceil_div(lg.width_px, 8), cx0 = lfx * f->lfg_cells_x;
+                    const size_t dst = (size_t)y * w8 + cx0;
+                    for (int c = 0; c < 3; ++c) {
+                        char* q = H + off_lfq[c] + dst * lf_elem;
+                        if (use_lf_frame) memset(q, 0, bw * lf_elem);
+                        else memcpy(q, static_cast<const char*>(lg.lf_quant[SRC[c]]) + (size_t)ly * bw * lf_elem, bw * lf_elem);
+                    }
+                    if (lg.has_hf_meta) {
+                        memcpy(kind + dst, lg.block_kind + (size_t)ly * bw, bw);
+                        memcpy(hf_mul + dst, lg.hf_mul + (size_t)ly * bw, bw * 4);
+                        if (lg.epf_sigma) memcpy(sigma + dst, lg.epf_sigma + (size_t)ly * bw, bw * 4);
+                        else for (uint32_t x = 0; x < bw; ++x) sigma[dst + x] = d->filter.epf_sigma_for_modular;
+                    } else {
+                        memset(kind + dst, JXLGPU_BLOCK_UNINIT, bw);
+                        memset(hf_mul + dst, 0, bw * 4);
+                        for (uint32_t x = 0; x < bw; ++x) sigma[dst + x] = d->filter.epf_sigma_for_modular;
+                    }
+                }
+            }
+            // chroma-from-luma maps (64 x 64 tiles): tile rows [r0 / 8, ...) of this chunk
+            for (uint32_t ty = r0 / 8; ty < std::min(f->h64, ceil_div(r1, 8u)); ++ty) {
+                if (ty * 8 < r0) continue;  // (chunks are multiples of 8 cell rows: never true)
+                const uint32_t lfy = ty * 8 / f->lfg_cells_y, lty = ty - lfy * (f->lfg_cells_y / 8);
+                for (uint32_t lfx = 0; lfx < f->lf_groups_per_row; ++lfx) {
+                    const JxlGpuLfGroup& lg = d->lf_groups[lfy * f->lf_groups_per_row + lfx];
+                    const uint32_t cw = ceil_div(lg.width_px, 64), tx0 = lfx * (f->lfg_cells_x / 8);
+                    for (uint32_t x = 0; x < cw; ++x) {
+                        float kx = 0.0f, kb = 0.0f;
+                        if (lg.has_hf_meta && !o.no_cfl) {  // vardct/mod.rs:355: no chroma-from-luma on subsampled frames
+                            // chroma_from_luma_hf_grouped, vardct/mod.rs:590-593
+                            kx = d->base_correlation_x + ((float)lg.x_from_y[(size_t)lty * cw + x] / (float)d->colour_factor);
+                            kb = d->base_correlation_b + ((float)lg.b_from_y[(size_t)lty * cw + x] / (float)d->colour_factor);
+                        }
+                        kx_map[(size_t)ty * w64 + tx0 + x] = kx;
+                        kb_map[(size_t)ty * w64 + tx0 + x] = kb;
+                    }
+                }
+            }
+        } else if (task < n_row_tasks + n_groups) {
+            const uint32_t g = task - n_row_tasks;
+            GroupScan& st = gs[g];
+            memset(&st, 0, sizeof(st));
+            st.msg = scan_group(g, [&](int slot, const uint4&, uint32_t) { ++st.count[slot]; }, &st);
+            st.err = st.msg ? JXLGPU_ERR_INVALID_ARG : JXLGPU_OK;
+        } else {
+            // the groups' non-zero lists, concatenated: an even share of the words per task
+            const uint32_t k = task - n_row_tasks - n_groups;
+            const uint64_t w0 = nz_total * k / nz_chunks, w1 = nz_total * (k + 1) / nz_chunks;
+            uint32_t g = (uint32_t)(std::upper_bound(nz_base.begin(), nz_base.end(), w0) - nz_base.begin()) - 1;
+            for (uint64_t w = w0; w < w1 && g < n_groups; ++g) {
+                const uint64_t ge = std::min<uint64_t>(nz_base[g + 1], w1);
+                if (ge > w) memcpy(nzw + w, d->hf_groups[g].nz + (w - nz_base[g]), (size_t)(ge - w) * 4);
+                w = std::max(w, ge);
+            }
+        }
+    });
+    for (uint32_t g = 0; g < n_groups; ++g)
+        if (gs[g].err) return fail(ctx, gs[g].err, gs[g].msg);
+    // copy_lf_dequant scale (vardct/mod.rs:398-400), f64 on the host exactly as the reference
+    for (uint32_t g = 0; g < f->num_lf_groups; ++g) {
+        const int32_t precision_scale = 1 << (9 - d->lf_groups[g].extra_precision);
+        for (int c = 0; c < 3; ++c)
+            lf_scale[(size_t)g * 3 + c] = (float)((double)d->m_lf[c] * (double)precision_scale / (double)scale_inv);
     }
 
-    // ---- device buffers + H2D
-    Scratch tmp;
-    void* d_bad_v = nullptr;
-    TRY(tmp.alloc(ctx, &d_bad_v, 4));
-    uint32_t* d_bad = static_cast<uint32_t*>(d_bad_v);
-    HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    // ---- prefix: where every (slot, group) run starts; the class tables
+    std::vector<uint32_t> start((size_t)n_groups * kNumSlots);
+    uint32_t used_mask = 0, n_entries = 0, n_nometa = 0;
+    memset(f->list_count, 0, sizeof(f->list_count));
+    for (int cls = 0; cls < CLS_COUNT; ++cls) f->class_first[cls] = 0xffffffffu;
+    for (int s = 0; s < kNumSlots; ++s) {
+        const int cls = class_of_slot(s);
+        if (f->class_first[cls] == 0xffffffffu) f->class_first[cls] = n_entries;
+        for (uint32_t g = 0; g < n_groups; ++g) {
+            start[(size_t)g * kNumSlots + s] = n_entries;
+            n_entries += gs[g].count[s];
+            f->list_count[cls] += gs[g].count[s];
+        }
+    }
+    uint32_t* const nometa = reinterpret_cast<uint32_t*>(H + off_nometa);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        used_mask |= gs[g].used_mask;
+        if (gs[g].nometa) nometa[n_nometa++] = g;
+    }
+    f->nometa_count = n_nometa;
+
+    // ---- phase 2: the entries (+ the dequantisation matrices of the types that appear, as one more task)
+    uint32_t* const deq_off = reinterpret_cast<uint32_t*>(H + off_deq_off);
+    float* const deq = reinterpret_cast<float*>(H + off_deq);
+    size_t deq_words = 0;
+    bool zero_stays_zero = true;
+    ctx_host_parallel(ctx, n_groups + 1, [&](uint32_t task) {
+        if (task < n_groups) {
+            uint32_t pos[kNumSlots];
+            for (int s = 0; s < kNumSlots; ++s) pos[s] = start[(size_t)task * kNumSlots + s];
+            (void)scan_group(task, [&](int slot, const uint4& e, uint32_t cyx) {
+                const uint32_t i = pos[slot]++;
+                entries[i] = e;
+                if (nzc) nzc[i] = cyx;
+            }, nullptr);
+            return;
+        }
+        // dequant matrices (only the types that appear), flat, 16-byte aligned offsets
+        memset(deq_off, 0, 27 * 3 * 4);
+        auto nonneg_finite = [](float v) { uint32_t u; memcpy(&u, &v, 4); return (u >> 31) == 0 && (u & 0x7f800000u) != 0x7f800000u; };
+        for (int t = 0; t < 27; ++t) {
+            if (!(used_mask >> t & 1u)) continue;
+            const size_t n = (size_t)kSize[t][0] * 8 * kSize[t][1] * 8;
+            for (int c = 0; c < 3; ++c) {
+                deq_off[t * 3 + c] = (uint32_t)deq_words;
+                f->deq_off_host[t][c] = (uint32_t)deq_words;
+                memcpy(deq + deq_words, d->dequant[t][c], n * 4);
+                // the list-fed kernels never touch the zeros: 0 * quant_bias * matrix * mul must be +0.0, true when the
+                // factors are finite and not negative — every conforming stream (the reference rejects weights <= 0 or
+                // >= 1e8, jxl-vardct/src/dequant.rs:191-196, 391-396)
+                if (grouped)
+                    for (size_t i = 0; i < n; ++i) zero_stays_zero &= nonneg_finite(d->dequant[t][c][i]);
+                deq_words += n;
+            }
+        }
+        for (int c = 0; c < 3; ++c) zero_stays_zero &= nonneg_finite(d->quant_bias[c]);
+        // quant_bias_numerator / k with the host's IEEE f32 division == the device's correctly
+        // rounded one; entries 0 and 1 are never selected (|q| <= 1 takes the quant_bias branch)
+        float* lut = reinterpret_cast<float*>(H + off_lut);
+        lut[0] = lut[1] = 0.0f;
+        for (int k = 2; k < 256; ++k) lut[k] = d->quant_bias_numerator / (float)k;
+        // sec_half(64/128/256): dct_common.rs:56-66
+        for (int i = 0, n = 64; i < 3; ++i, n *= 2) {
+            float* tbl = reinterpret_cast<float*>(H + off_sec[i]);
+            if (d->sec_half_large[i]) {
+                memcpy(tbl, d->sec_half_large[i], sizeof(float) * (n / 2));
+            } else {
+                for (int k = 0; k < n / 2; ++k) {
+                    float theta = (float)(2 * k + 1) / (float)(2 * n) * 3.14159265358979323846f;
+                    tbl[k] = (1.0f / cosf(theta)) / 2.0f;
+                }
+            }
+        }
+        for (int i = 0; i < 3; ++i)
+            if (!upw[i].empty()) memcpy(H + off_upw[i], upw[i].data(), upw[i].size() * 4);
+    });
+    ctx->up_split[0] = ms_since(t_phase1);
+    f->nz_total = nz_total;
     // grouped lists feed the transform kernels directly; dense cells are built from them only for frames
     // with >= 128-px varblocks (global-memory path) or on request (JXLGPU_NO_SPARSE_TR)
-    // ... and only if a zero coefficient dequantises to +0.0 (the list-fed kernels never touch the zeros):
-    // 0 * quant_bias * matrix * mul has that value when the factors are finite and not negative — true of
-    // every conforming stream (the reference rejects weights <= 0 or >= 1e8, jxl-vardct/src/dequant.rs:191-196, 391-396)
-    bool zero_stays_zero = true;
-    auto nonneg_finite = [](float v) { uint32_t u; memcpy(&u, &v, 4); return (u >> 31) == 0 && (u & 0x7f800000u) != 0x7f800000u; };
-    for (int c = 0; c < 3; ++c) zero_stays_zero &= nonneg_finite(d->quant_bias[c]);
-    if (grouped)
-        for (float v : deq)
-            if (!nonneg_finite(v)) { zero_stays_zero = false; break; }
-    f->sparse_tr = grouped && !ctx->tune.no_sparse_tr && lists[CLS_BIG].empty() && zero_stays_zero;
+    f->sparse_tr = grouped && !ctx->tune.no_sparse_tr && f->list_count[CLS_BIG] == 0 && zero_stays_zero;
+
+    // ---- trim the arena to what was used: entries, nzc, nometa and the matrices are the tail items
+    // (the items keep their offsets; the copy stops after the last used byte of each, the device allocation keeps the bound)
+    const auto t_dev = std::chrono::steady_clock::now();
+    char* dev_arena = nullptr;
+    if (!ctx->guard_mode) {
+        void* p = nullptr;
+        HIP_TRY(ctx, ctx_dev_malloc(ctx, &p, pool_bucket(ar.total)));
+        f->allocs.push_back(p);
+        dev_arena = static_cast<char*>(p);
+        for (const ArenaItem& it : ar.items) *it.dev = dev_arena + it.off;
+        // one copy for the fixed part + the lists up to the entries; the used parts of the tail items after it
+        struct Piece { size_t off, bytes; };
+        const Piece pieces[5] = {{0, off_entries}, {off_entries, (size_t)n_entries * sizeof(uint4)},
+                                 {off_nzc, grouped ? (size_t)n_entries * 4 : 0}, {off_nometa, (size_t)n_nometa * 4},
+                                 {off_deq, deq_words * 4}};
+        if (!ctx->ev_h2d[0]) {
+            HIP_TRY(ctx, hipEventCreate(&ctx->ev_h2d[0]));
+            HIP_TRY(ctx, hipEventCreate(&ctx->ev_h2d[1]));
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_h2d[0], ctx->stream_up));
+        for (const Piece& pc : pieces)
+            if (pc.bytes) HIP_TRY(ctx, hipMemcpyAsync(dev_arena + pc.off, H + pc.off, pc.bytes, hipMemcpyHostToDevice, ctx->stream_up));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_h2d[1], ctx->stream_up));
+        ctx->h2d_timed = true;
+    } else {
+        // JXLGPU_GUARD: every array in its own guarded mapping, exact size (out-of-bounds accesses must fault)
+        for (const ArenaItem& it : ar.items) {
+            size_t bytes = it.bytes;
+            if (it.off == off_entries) bytes = (size_t)n_entries * sizeof(uint4);
+            else if (grouped && it.off == off_nzc) bytes = (size_t)n_entries * 4;
+            else if (it.off == off_nometa) bytes = (size_t)n_nometa * 4;
+            else if (it.off == off_deq) bytes = deq_words * 4;
+            void* p = nullptr;
+            HIP_TRY(ctx, ctx_dev_malloc(ctx, &p, std::max<size_t>(bytes, 16)));
+            f->allocs.push_back(p);
+            *it.dev = p;
+            if (bytes) HIP_TRY(ctx, hipMemcpyAsync(p, H + it.off, bytes, hipMemcpyHostToDevice, ctx->stream_up));
+        }
+    }
+    HIP_TRY(ctx, hipEventRecord(sb.ev, ctx->stream_up));
+    sb.busy = true;
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, sb.ev, 0));  // everything rendered from this frame comes after the arena
+    for (int c = 0; c < 3; ++c) f->lfq[c] = lfq_dev[c];
+    if (!n_nometa) f->nometa_groups = nullptr;
+
+    // ---- the frame's working buffers (pooled, exact sizes) and the coefficient planes of the other transports
+    Scratch tmp;
+    uint32_t* d_bad = nullptr;
+    if (d->coeff_format == JXLGPU_COEFF_SPARSE) {
+        void* d_bad_v = nullptr;
+        TRY(tmp.alloc(ctx, &d_bad_v, 4));
+        d_bad = static_cast<uint32_t*>(d_bad_v);
+        HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    }
     if (!f->sparse_tr) TRY(dev_alloc(ctx, f, &f->coeff, npix * 3));
     TRY(dev_alloc(ctx, f, &f->pix_t, npix * 3));
     if (d->coeff_format != JXLGPU_COEFF_DENSE && f->coeff) HIP_TRY(ctx, hipMemsetAsync(f->coeff, 0, npix * 12, ctx->stream));
-    if (grouped) {
-        std::vector<uint32_t> words;
-        words.reserve((size_t)nz_total);
-        for (uint32_t g = 0; g < d->num_hf_groups; ++g)
-            words.insert(words.end(), d->hf_groups[g].nz, d->hf_groups[g].nz + d->hf_groups[g].num_nz);
-        TRY(dev_upload(ctx, f, &f->nz, words));
-        f->nz_total = nz_total;
-    }
     for (int c = 0; c < 3; ++c) {
         if (!grouped) TRY(upload_coeff_plane(ctx, f, d, c, tmp, d_bad));
-        uint8_t* p = nullptr;
-        TRY(dev_upload(ctx, f, &p, lfq_host[c]));
-        f->lfq[c] = p;
         TRY(dev_alloc(ctx, f, &f->lf_a[c], ncell));
         TRY(dev_alloc(ctx, f, &f->lf[c], ncell));
         if (use_lf_frame) {
@@ -756,69 +1221,11 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
         TRY(dev_alloc(ctx, f, &f->buf_a[c], npix));
         TRY(dev_alloc(ctx, f, &f->buf_b[c], npix));
     }
-    TRY(dev_upload(ctx, f, &f->kind, kind));
-    TRY(dev_upload(ctx, f, &f->hf_mul, hf_mul));
-    TRY(dev_upload(ctx, f, &f->sigma, sigma));
-    TRY(dev_upload(ctx, f, &f->kx_map, kx_map));
-    TRY(dev_upload(ctx, f, &f->kb_map, kb_map));
-    TRY(dev_upload(ctx, f, &f->lf_scale, lf_scale));
-    TRY(dev_upload(ctx, f, &f->dequant, deq));
-    TRY(dev_upload(ctx, f, &f->deq_off, deq_off));
-    {
-        // quant_bias_numerator / k with the host's IEEE f32 division == the device's correctly
-        // rounded one; entries 0 and 1 are never selected (|q| <= 1 takes the quant_bias branch)
-        std::vector<float> lut(256, 0.0f);
-        for (int k = 2; k < 256; ++k) lut[k] = d->quant_bias_numerator / (float)k;
-        TRY(dev_upload(ctx, f, &f->deq_lut, lut));
-    }
-    {
-        // one entry array, classes concatenated; the special 8x8 family sorted by transform type so
-        // that the per-lane dispatch of transform_special_kernel is (nearly) wave-uniform
-        std::stable_sort(lists[CLS_SPECIAL8].begin(), lists[CLS_SPECIAL8].end(),
-                         [](const VbEntry& a, const VbEntry& b) { return (a.e.y & 0xffffu) < (b.e.y & 0xffffu); });
-        std::vector<uint4> entries;
-        std::vector<uint32_t> cyx;
-        for (int cls = 0; cls < CLS_COUNT; ++cls) {
-            f->class_first[cls] = (uint32_t)entries.size();
-            f->list_count[cls] = (uint32_t)lists[cls].size();
-            for (const VbEntry& v : lists[cls]) {
-                entries.push_back(v.e);
-                if (grouped) cyx.push_back(v.cyx);
-            }
-        }
-        TRY(dev_upload(ctx, f, &f->entries, entries));
-        if (grouped) {
-            TRY(dev_upload(ctx, f, &f->nzc, cyx));
-            if (!f->sparse_tr) launch_grouped_to_dense(ctx->stream, f->entries, f->nzc, (uint32_t)entries.size(), f->nz, f->w8, f->coeff);
-        }
-    }
-    f->nometa_count = (uint32_t)nometa.size();
-    if (!nometa.empty()) TRY(dev_upload(ctx, f, &f->nometa_groups, nometa));
+    if (grouped && !f->sparse_tr) launch_grouped_to_dense(ctx->stream, f->entries, f->nzc, n_entries, f->nz, f->w8, f->coeff);
     if (f->list_count[CLS_BIG]) TRY(dev_alloc(ctx, f, &f->big_tmp, npix * 6));
-
-    // sec_half(64/128/256): dct_common.rs:56-66
-    for (int i = 0, n = 64; i < 3; ++i, n *= 2) {
-        std::vector<float> tbl(n / 2);
-        if (d->sec_half_large[i]) {
-            memcpy(tbl.data(), d->sec_half_large[i], sizeof(float) * (n / 2));
-        } else {
-            for (int k = 0; k < n / 2; ++k) {
-                float theta = (float)(2 * k + 1) / (float)(2 * n) * 3.14159265358979323846f;
-                tbl[k] = (1.0f / cosf(theta)) / 2.0f;
-            }
-        }
-        TRY(dev_upload(ctx, f, &f->sec[i], tbl));
-    }
-
     if (upf > 1) {
         const uint32_t ow = d->width * upf, oh = d->height * upf;
-        for (int c = 0; c < 3; ++c) {
-            TRY(dev_alloc(ctx, f, &f->up[c], (size_t)ow * oh));
-            if (upf == 8) continue;
-        }
-        TRY(upload_post_params(ctx, f, d->upsampling));
-        const int need = upf == 2 ? 0 : upf == 4 ? 1 : 2;
-        if (!f->up_weights[need]) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "upsampling weights missing");
+        for (int c = 0; c < 3; ++c) TRY(dev_alloc(ctx, f, &f->up[c], (size_t)ow * oh));
     }
 
     // ---- per-frame scalars
@@ -837,21 +1244,30 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     f->noise_corr_x = d->base_correlation_x;  // render.rs:175-180
     f->noise_corr_b = d->base_correlation_b;
 
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // descriptor memory may be released now
+    HIP_TRY(ctx, hipGetLastError());
     if (d->coeff_format == JXLGPU_COEFF_SPARSE) {
+        // the scatter kernels validate the positions on the device: the one transport that waits for it
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         uint32_t bad = 0;
         HIP_TRY(ctx, hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
         if (bad) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "sparse coefficient position outside the frame");
     }
-    // pointers inside the descriptor copy are dead from here on
+    // pointers inside the descriptor copy are dead from here on (everything they pointed to has been copied:
+    // into the pinned staging arena, or by blocking copies)
     for (int c = 0; c < 3; ++c) f->desc.coeff[c] = f->desc.lf_frame[c] = nullptr;
     f->desc.lf_groups = nullptr;
     f->desc.hf_groups = nullptr;
     memset(f->desc.dequant, 0, sizeof(f->desc.dequant));
+    frame_mark(ctx, f, ctx->stream);
     guard.armed = false;
     *out_frame = f;
+    ctx->up_split[1] = 0.0;
+    ctx->up_split[2] = ms_since(t_dev);
+    ctx->up_split[3] = ms_since(t_begin);
     return JXLGPU_OK;
 }
+
+extern "C" {
 
 int jxlgpu_frame_out_size(const jxlgpu_frame* f, uint32_t stages, uint32_t* width, uint32_t* height) {
     if (!f) return JXLGPU_ERR_INVALID_ARG;
@@ -1082,9 +1498,18 @@ int finish_render(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stri
     for (int c = 0; c < 3; ++c) f->result[c] = cur[c];
     f->result_stride = stride; f->result_w = ow; f->result_h = oh;
     HIP_TRY(ctx, hipGetLastError());
+    frame_mark(ctx, f, ctx->stream);
     if (out) {
         if (out->stride < ow) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "output stride < output width");
-        if (out->mem == JXLGPU_MEM_DEVICE) {
+        if (out->mem > JXLGPU_MEM_HOST_PINNED) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "unknown JxlGpuOut.mem");
+        if (out->mem == JXLGPU_MEM_HOST_PINNED) {
+            // the caller's planes are pinned (jxlgpu_host_alloc): the DMA engine writes them directly
+            for (int c = 0; c < 3; ++c)
+                if (out->planes[c])
+                    HIP_TRY(ctx, hipMemcpy2DAsync(out->planes[c], (size_t)out->stride * 4, cur[c], (size_t)stride * 4,
+                                                  (size_t)ow * 4, oh, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        } else if (out->mem == JXLGPU_MEM_DEVICE) {
             for (int c = 0; c < 3; ++c)
                 if (out->planes[c])
                     HIP_TRY(ctx, hipMemcpy2DAsync(out->planes[c], (size_t)out->stride * 4, cur[c], (size_t)stride * 4,
@@ -1600,6 +2025,7 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
             jxlgpu_frame* f = frames[i0 + i];
             for (int c = 0; c < 3; ++c) f->result[c] = f->buf_a[c];
             f->result_stride = f->wr; f->result_w = f->width; f->result_h = f->height;
+            frame_mark(ctx, f, sp);
         }
     }
     HIP_TRY(ctx, hipGetLastError());

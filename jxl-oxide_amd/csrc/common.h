@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <deque>
+#include <functional>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -228,14 +230,45 @@ struct GuardRec {
     hipMemGenericAllocationHandle_t handle = {};
 };
 
+// Host worker threads of a context (api.hip): the per-frame work-list build of an upload is split over them.
+struct WorkerPool;
+// Pinned staging buffer of the upload arena: the host build writes every descriptor array of a frame into one of
+// these, ONE hipMemcpyAsync moves it; `ev` (recorded behind that copy) guards its reuse.
+struct StageBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool busy = false;
+};
+// Device buffers (and the Modular host state) of a freed frame, waiting for the work that was queued when the
+// frame was freed: jxlgpu_frame_free never blocks, the buffers go back to the pool once `ev` have all fired.
+struct Deferred {
+    std::vector<void*> ptrs;
+    hipEvent_t ev[4] = {};
+    void* modular = nullptr;
+    void (*modular_free)(void*) = nullptr;
+};
+
 struct jxlgpu_ctx {
     int device = 0;
     uint32_t num_cus = 256;     // hipDeviceProp_t::multiProcessorCount (persistent grids are sized from it)
     Tuning tune;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: 64-pixel varblock kernels overlap the <=32 kernel
+    hipStream_t stream_up = nullptr;    // H2D of the upload arenas: overlaps the kernels of earlier frames
+    hipStream_t stream_down = nullptr;  // asynchronous D2H of formatted output (JXLGPU_MEM_HOST_PINNED)
+    StageBuf stage[3];
+    uint32_t stage_next = 0;
+    WorkerPool* workers = nullptr;      // created by the first upload that is worth splitting
+    int host_threads = -1;              // JXLGPU_HOST_THREADS (-1: min(8, cores) - 1 workers + the calling thread)
+    std::deque<Deferred> deferred;
+    std::vector<hipEvent_t> ev_spare;   // recycled events of reaped Deferred entries
+    double up_split[4] = {};            // last upload: host build, staging fill, alloc + enqueue, whole call (ms)
+    hipEvent_t ev_h2d[2] = {};          // around the last upload's arena copy (jxlgpu_upload_split reads the elapsed time)
+    bool h2d_timed = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_d2h[3] = {};      // one per output plane: host copy-out overlaps the next plane's D2H
+    hipEvent_t ev_slice[4] = {};    // formatted output: one per D2H slice
     std::string last_error;
     // Device-buffer pool: frames of one stream of images have the same sizes, so the ~25 buffers of
     // a freed frame are handed to the next upload instead of going through hipFree/hipMalloc
@@ -345,6 +378,8 @@ struct jxlgpu_frame {
     uint32_t noise_group_dim = 256;
     float noise_corr_x = 0.0f, noise_corr_b = 1.0f;  // base_correlations_xb (render.rs:175-180)
     float* deq_lut = nullptr;            // quant_bias_numerator / k, k < 256 (dequant_one_lut)
+    hipEvent_t ev_last = nullptr;        // behind the last asynchronous operation queued for this frame (jxlgpu_frame_wait)
+    bool ev_last_set = false;
     FrameDev* dev_args = nullptr;        // device copy of the default pipeline's arguments (batched launches)
     bool dev_args_ready = false;
     bool batch_ok = false;               // the frame qualifies for the batched default pipeline (V1-V8 and post)
@@ -413,6 +448,13 @@ void launch_epf(hipStream_t s, int step, const FilterArgs& a);
 // api.hip: pooled device memory (see jxlgpu_ctx::pool)
 hipError_t ctx_dev_malloc(jxlgpu_ctx* ctx, void** out, size_t bytes);
 void ctx_dev_release(jxlgpu_ctx* ctx, void* p);
+// release `ptrs` once everything queued so far on the ctx's streams has finished (never blocks)
+void ctx_defer_release(jxlgpu_ctx* ctx, std::vector<void*>&& ptrs, void* modular = nullptr, void (*modular_free)(void*) = nullptr);
+void ctx_reap(jxlgpu_ctx* ctx, bool wait);
+// f(0) ... f(n - 1) on the ctx's host worker threads + the caller; returns when all are done
+void ctx_host_parallel(jxlgpu_ctx* ctx, uint32_t n, const std::function<void(uint32_t)>& f);
+// mark "the frame's last queued operation is here" on stream `s` (jxlgpu_frame_wait)
+void frame_mark(jxlgpu_ctx* ctx, jxlgpu_frame* f, hipStream_t s);
 size_t noise_jump_table_bytes();
 const void* noise_jump_table_host();
 bool noise_geometry_unsupported(uint32_t height, uint32_t group_dim);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void format_u8_x4_kernel(FormatArgs a) {
 
 extern "C" int jxlgpu_frame_format_output(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuFormatDesc* fmt, void* out,
                                           uint32_t out_mem, uint32_t* out_w, uint32_t* out_h) {
-    if (!ctx || !f || !fmt || !out) return JXLGPU_ERR_INVALID_ARG;
+    if (!ctx || !f || !fmt || !out || out_mem > JXLGPU_MEM_HOST_PINNED) return JXLGPU_ERR_INVALID_ARG;
     if (fmt->orientation < 1 || fmt->orientation > 8 || fmt->sample_format > JXLGPU_FMT_U8) {
         ctx->last_error = "bad orientation / sample format";
         return JXLGPU_ERR_INVALID_ARG;
@@ -113,16 +113,44 @@ extern "C" int jxlgpu_frame_format_output(jxlgpu_ctx* ctx, jxlgpu_frame* f, cons
     else if (fmt->sample_format == JXLGPU_FMT_U16) format_kernel<JXLGPU_FMT_U16><<<grid, 256, 0, ctx->stream>>>(a);
     else format_kernel<JXLGPU_FMT_U8><<<grid, 256, 0, ctx->stream>>>(a);
     HIP_TRY(ctx, hipGetLastError());
-    if (out_mem != JXLGPU_MEM_DEVICE) {
+    if (out_mem == JXLGPU_MEM_HOST_PINNED) {
+        // asynchronous: the copy runs on the download stream behind the formatting kernel and the call returns;
+        // jxlgpu_frame_wait (or jxlgpu_synchronize) tells when `out` is complete.  The kernels of the next frames
+        // do not wait for it.
+        hipEvent_t ev = nullptr;
+        if (!f->ev_last) HIP_TRY(ctx, hipEventCreateWithFlags(&f->ev_last, hipEventDisableTiming));
+        ev = f->ev_last;
+        HIP_TRY(ctx, hipEventRecord(ev, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_down, ev, 0));
+        HIP_TRY(ctx, hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, ctx->stream_down));
+        frame_mark(ctx, f, ctx->stream_down);
+    } else if (out_mem != JXLGPU_MEM_DEVICE) {
         if (ctx->pinned_size < bytes) {
             if (ctx->pinned) (void)hipHostFree(ctx->pinned);
             ctx->pinned = nullptr; ctx->pinned_size = 0;
             HIP_TRY(ctx, hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
             ctx->pinned_size = bytes;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, dst, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        // D2H in slices: the ctx's worker threads move slice k into the caller's (pageable) buffer while slice
+        // k + 1 crosses PCIe
+        const size_t n_slices = bytes >= ((size_t)8 << 20) ? 4 : 1;
+        auto cut = [&](size_t k) { return k >= n_slices ? bytes : bytes * k / n_slices / 4096 * 4096; };
+        for (size_t k = 0; k < n_slices; ++k) {
+            if (!ctx->ev_slice[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_slice[k], hipEventDisableTiming));
+            HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->pinned + cut(k), (const char*)dst + cut(k), cut(k + 1) - cut(k),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_slice[k], ctx->stream));
+        }
+        for (size_t k = 0; k < n_slices; ++k) {
+            HIP_TRY(ctx, hipEventSynchronize(ctx->ev_slice[k]));
+            const size_t b0 = cut(k), nb = cut(k + 1) - b0;
+            const uint32_t parts = nb >= ((size_t)1 << 20) ? 8 : 1;
+            ctx_host_parallel(ctx, parts, [&](uint32_t i) {
+                const size_t p0 = nb * i / parts, p1 = nb * (i + 1) / parts;
+                memcpy((char*)out + b0 + p0, (const char*)ctx->pinned + b0 + p0, p1 - p0);
+            });
+        }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        memcpy(out, ctx->pinned, bytes);
     }
     if (out_w) *out_w = ow;
     if (out_h) *out_h = oh;

@@ -209,6 +209,40 @@ class Context:
         assert (rw.value, rh.value) == (ow, oh)
         return out
 
+    def host_alloc(self, shape, dtype):
+        """Pinned host memory (jxlgpu_host_alloc) as a numpy array; free it with host_free(arr)."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._check(self.lib.jxlgpu_host_alloc(self.handle, n, C.byref(p)))
+        buf = (C.c_char * n).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p:
+            self.lib.jxlgpu_host_free(self.handle, p)
+
+    def format_output_async(self, frame, sample_format, out_pinned, orientation=1):
+        """format_output into pinned memory (host_alloc): returns once the work is queued; frame_wait(frame)
+        (or synchronize) tells when `out_pinned` is complete."""
+        fmt = abi.FormatDesc(sample_format, orientation)
+        rw, rh = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.jxlgpu_frame_format_output(self.handle, frame.handle, C.byref(fmt), out_pinned.ctypes.data,
+                                                        abi.MEM_HOST_PINNED, C.byref(rw), C.byref(rh)))
+        return rw.value, rh.value
+
+    def frame_wait(self, frame):
+        self._check(self.lib.jxlgpu_frame_wait(self.handle, frame.handle))
+
+    def upload_split(self):
+        """Host-time split of the last vardct_upload (ms): build, -, alloc + enqueue, whole call, H2D on the device."""
+        ms = (C.c_double * 5)()
+        self._check(self.lib.jxlgpu_upload_split(self.handle, ms))
+        return list(ms)
+
     def download_lf(self, frame, w8, h8):
         lf = np.zeros((3, h8, w8), dtype=np.float32)
         arr = (abi.f32p * 3)(*[lf[c].ctypes.data_as(abi.f32p) for c in range(3)])
