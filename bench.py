@@ -61,7 +61,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5))
     ap.add_argument("--frames", type=int, default=None, help="frames in the whole job (default 64; 8 for configs 3 / 5)")
-    ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic frames in the job")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames in the job (block maps, coefficients, LF)")
+    ap.add_argument("--nz", default="0.15", help="VarDCT configs: fraction of the coefficients that are non-zero after quantisation "
+                    "(SURVEY 8(d): 0.15); a comma list runs the whole measurement once per value, one JSON line each")
+    ap.add_argument("--verify-frames", type=int, default=2, help="distinct frames checked against the oracle after the timed region")
     ap.add_argument("--transport", default="grouped", choices=("grouped", "dense_i32", "sparse_i16"),
                     help="coefficient transport of the resident input (VarDCT configs): the decoder's per-varblock "
                          "non-zero lists (default; consumed by the transform kernels directly) or dense planes")
@@ -94,241 +97,249 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = runtime.Context(local_rank)
 
-    n_total = args.frames or (64 if args.config == 2 else 8)
-    job = make_job(args.config, args.distinct, args.transport)
-    # config 5 at N > 1 (BASELINE: "groups sharded across the GPUs"): every rank holds every frame and renders
-    # its band of output rows of each (jxlgpu_vardct_render_region); everything else shards whole frames
-    band_sharded = args.config == 5 and world > 1
-    mine = list(range(n_total)) if band_sharded else list(shard.frame_shard(n_total, rank, world))
-    wls = {d: job["make"](d) for d in sorted({i % args.distinct for i in mine})}  # untimed
-    frames = [job["upload"](ctx, wls[i % args.distinct]) for i in mine]            # own device copy each; untimed
-    mp_per_frame = job["out_w"] * job["out_h"] / 1e6
+    def run_density(nz):
+        n_total = args.frames or (64 if args.config == 2 else 8)
+        job = make_job(args.config, args.distinct, args.transport, nz)
+        # config 5 at N > 1 (BASELINE: "groups sharded across the GPUs"): every rank holds every frame and renders
+        # its band of output rows of each (jxlgpu_vardct_render_region); everything else shards whole frames
+        band_sharded = args.config == 5 and world > 1
+        mine = list(range(n_total)) if band_sharded else list(shard.frame_shard(n_total, rank, world))
+        wls = {d: job["make"](d) for d in sorted({i % args.distinct for i in mine})}  # untimed
+        frames = [job["upload"](ctx, wls[i % args.distinct]) for i in mine]            # own device copy each; untimed
+        mp_per_frame = job["out_w"] * job["out_h"] / 1e6
 
-    passes = args.passes if args.passes else (8 if args.config == 2 else 1)
+        passes = args.passes if args.passes else (8 if args.config == 2 else 1)
 
-    # ---- N > 1: the stitched output is part of the job.  Every step's result is formatted on the device and
-    # gathered to rank 0 (RCCL over xGMI) by shard.PipelinedGather: the gather of step k overlaps the kernels of
-    # step k + 1, the host never waits inside the timed region, and `value` INCLUDES it.
-    gather, gather_fmt, band = None, None, None
-    if world > 1 and args.config in (2, 5):
-        if band_sharded:
-            bands = shard.band_rows(job["out_h"], world)
-            band = bands[rank]
-            hb = max(b[1] - b[0] for b in bands)
-            gather_fmt = abi.FMT_U16   # "16-bit" output samples of config 5
-            shape = (n_total, hb, job["out_w"], 3 * 2)   # as bytes: every RCCL build moves uint8
-        else:
-            gather_fmt = abi.FMT_U8
-            shape = (-(-n_total // world), job["out_h"], job["out_w"], 3)
-        gather = shard.PipelinedGather(shape, torch.uint8, "cuda", lib_stream=ctx.stream(), dst=0)
-    gstep = [0]
+        # ---- N > 1: the stitched output is part of the job.  Every step's result is formatted on the device and
+        # gathered to rank 0 (RCCL over xGMI) by shard.PipelinedGather: the gather of step k overlaps the kernels of
+        # step k + 1, the host never waits inside the timed region, and `value` INCLUDES it.
+        gather, gather_fmt, band = None, None, None
+        if world > 1 and args.config in (2, 5):
+            if band_sharded:
+                bands = shard.band_rows(job["out_h"], world)
+                band = bands[rank]
+                hb = max(b[1] - b[0] for b in bands)
+                gather_fmt = abi.FMT_U16   # "16-bit" output samples of config 5
+                shape = (n_total, hb, job["out_w"], 3 * 2)   # as bytes: every RCCL build moves uint8
+            else:
+                gather_fmt = abi.FMT_U8
+                shape = (-(-n_total // world), job["out_h"], job["out_w"], 3)
+            gather = shard.PipelinedGather(shape, torch.uint8, "cuda", lib_stream=ctx.stream(), dst=0)
+        gstep = [0]
 
-    def render_only():
-        if band_sharded:
-            for f in frames:
-                ctx.vardct_render_region(f, abi.STAGE_ALL, (0, band[0], job["out_w"], band[1] - band[0]), to_host=False)
-        else:
-            job["render"](ctx, frames)
+        def render_only():
+            if band_sharded:
+                for f in frames:
+                    ctx.vardct_render_region(f, abi.STAGE_ALL, (0, band[0], job["out_w"], band[1] - band[0]), to_host=False)
+            else:
+                job["render"](ctx, frames)
 
-    def step(with_gather=True):
-        for _ in range(passes):
-            render_only()
-            if gather is not None and with_gather and frames:
-                buf = gather.slot(gstep[0])
-                shard.format_frames_into(ctx, frames, gather_fmt, buf)
-                gather.submit(gstep[0])
-                gstep[0] += 1
+        def step(with_gather=True):
+            for _ in range(passes):
+                render_only()
+                if gather is not None and with_gather and frames:
+                    buf = gather.slot(gstep[0])
+                    shard.format_frames_into(ctx, frames, gather_fmt, buf)
+                    gather.submit(gstep[0])
+                    gstep[0] += 1
 
-    def barrier():
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        def barrier():
+            ctx.synchronize()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
 
-    # ---- warmup; find the dominant kernel group with event brackets (one batch at a time)
-    gather_error = None
-    if gather is not None:
-        # the first overlapped step runs under a guard: if this torch / RCCL build rejects any piece of the plumbing
-        # (every rank fails at the same call), the job goes on without the gather instead of losing the measurement
-        try:
+        # ---- warmup; find the dominant kernel group with event brackets (one batch at a time)
+        gather_error = None
+        if gather is not None:
+            # the first overlapped step runs under a guard: if this torch / RCCL build rejects any piece of the plumbing
+            # (every rank fails at the same call), the job goes on without the gather instead of losing the measurement
+            try:
+                step()
+                barrier()
+            except Exception as e:  # noqa: BLE001
+                gather_error = f"{type(e).__name__}: {e}"[:300]
+                print(f"[bench] rank {rank}: overlapped gather unavailable ({gather_error}); timing the render only", file=sys.stderr)
+                gather = None
+        for _ in range(max(args.warmup, 1)):
             step()
-            barrier()
-        except Exception as e:  # noqa: BLE001
-            gather_error = f"{type(e).__name__}: {e}"[:300]
-            print(f"[bench] rank {rank}: overlapped gather unavailable ({gather_error}); timing the render only", file=sys.stderr)
-            gather = None
-    for _ in range(max(args.warmup, 1)):
-        step()
-    barrier()
-    group_ms, group_n = {}, {}
-    for g in job["groups"]:
-        ctx.profile_select(g)
-        step()
-        ms, n = ctx.profile_read()
-        group_ms[g], group_n[g] = ms, n
-    dominant = max(group_ms, key=group_ms.get)
-    ctx.profile_select(dominant)
+        barrier()
+        group_ms, group_n = {}, {}
+        for g in job["groups"]:
+            ctx.profile_select(g)
+            step()
+            ms, n = ctx.profile_read()
+            group_ms[g], group_n[g] = ms, n
+        dominant = max(group_ms, key=group_ms.get)
+        ctx.profile_select(dominant)
 
-    # ---- timed region: exactly K steps
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof_ms, prof_n = ctx.profile_read()
-    ctx.profile_select(-1)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    value = n_total * passes * args.steps * mp_per_frame / elapsed
-    value_render_only = None
-    if gather is not None:
-        # the same K steps without the formatting + gather, for comparison (not the headline at N > 1)
+        # ---- timed region: exactly K steps
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step(with_gather=False)
+            step()
         barrier()
-        e2 = time.perf_counter() - t0
-        t = torch.tensor([e2], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        value_render_only = n_total * passes * args.steps * mp_per_frame / float(t.item())
-
-    # ---- stitched output (config 4's gather): u8 formatting on the device + one gather, timed apart
-    gather_ms = None
-    if not args.no_extras and args.config == 2 and frames and world == 1:
-        shard.gather_formatted_batch(ctx, frames, abi.FMT_U8)  # warm (allocations, RCCL channels)
-        barrier()
-        reps = 3
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            shard.gather_formatted_batch(ctx, frames, abi.FMT_U8)
-        barrier()
-        gather_s = (time.perf_counter() - t0) / reps
+        elapsed = time.perf_counter() - t0
+        prof_ms, prof_n = ctx.profile_read()
+        ctx.profile_select(-1)
         if world > 1:
-            t = torch.tensor([gather_s], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            gather_s = float(t.item())
-        gather_ms = gather_s * 1e3
+            elapsed = float(t.item())
+        value = n_total * passes * args.steps * mp_per_frame / elapsed
+        value_render_only = None
+        if gather is not None:
+            # the same K steps without the formatting + gather, for comparison (not the headline at N > 1)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step(with_gather=False)
+            barrier()
+            e2 = time.perf_counter() - t0
+            t = torch.tensor([e2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            value_render_only = n_total * passes * args.steps * mp_per_frame / float(t.item())
 
-    out = None
-    if rank == 0:
-        f0 = frames[0]
-        # a batched step = ceil(frames / 32) launches of the group; prof_n brackets in K steps
-        frames_per_launch = len(frames) * passes * args.steps / max(prof_n, 1) if job["batched"] else 1
-        alg_frame = job["alg_bytes"](f0, dominant)
-        avg_ms = prof_ms / max(prof_n, 1)
-        achieved = alg_frame * frames_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, traffic_src = job["traffic"](dominant, frames_per_launch)
-        roofline = {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": job["group_names"][dominant], "avg_launch_ms": round(avg_ms, 4), "launches": int(prof_n),
-            "frames_per_launch": round(frames_per_launch, 2),
-            "algorithmic_bytes_per_launch": int(alg_frame * frames_per_launch),
-            "group_ms_per_frame": {job["group_names"][g].split(":")[0]: round(group_ms[g] / max(len(frames) * passes, 1), 4) for g in group_ms},
-            "pipeline_algorithmic_frac": round(job["alg_bytes"](f0, None) * n_total * passes * args.steps / elapsed / 1e9 / world / HBM_PEAK_GBS, 4),
-            "traffic_ratio": None if not traffic else round(traffic / (alg_frame * frames_per_launch), 3),
-        }
-        roofline_valu = None
-        if args.config == 2 and dominant == 2:
-            # the streaming kernel's region and segmentation, as fused_prepare() lays them out
-            iw, ih = (W4K - 4) // 8 * 8 - 16, (H4K - 4) // 8 * 8 - 16
-            nseg = max(1, (ih + POST_ROWS_PER_SEG // 2) // POST_ROWS_PER_SEG)
-            rows = (-(-ih // nseg) + 3) // 4 * 4
-            segs = -(-ih // rows)
-            strips = -(-iw // POST_STRIP)
-            winstr = strips * segs * (rows + POST_HALO_ROWS) * POST_VALU_PER_ROW * frames_per_launch
-            ach = winstr / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            roofline_valu = {"bound": "valu", "achieved": round(ach, 1), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
-                             "frac": round(ach / VALU_PEAK_GINSTR, 4),
-                             "note": "streaming post kernel, f32 in the reference's operation order (no FMA contraction, "
-                                     "correctly rounded division); a packed v_pk_*_f32 instruction counts once; halo rows "
-                                     "and columns are recomputed (%d/%d x %d/%d)" % (
-                                         POST_STRIP + 8, POST_STRIP, rows + POST_HALO_ROWS, rows)}
-        verified = None
-        if not args.no_verify and not band_sharded:
-            verified = job["verify"](ctx, frames, mine, wls, args.distinct)
-        if not args.no_verify and gather is not None:
-            # the stitched output as it arrived on rank 0: one frame that another rank rendered (config 2 / 4), or frame 0
-            # reassembled from every rank's band (config 5), against the oracle's formatted render
-            from oracle import pyoracle
-            got_all = gather.finish(gstep[0] - 1)
-            if band_sharded:
-                wl = wls[0]
-                exp, _ = pyoracle.vardct_render(wl.desc(), abi.STAGE_ALL, job["out_w"], job["out_h"])
-                exp16 = pyoracle.format_output(exp, gather_fmt, 1)
-                ok = True
-                for r, (y0, y1) in enumerate(shard.band_rows(job["out_h"], world)):
-                    ok &= bool(np.array_equal(got_all[r][0, :y1 - y0].cpu().numpy().view(np.uint16), exp16[y0:y1]))
-                gv = {"ok": ok, "what": "frame 0 reassembled on rank 0 from the %d gathered u16 bands == oracle render, formatted" % world}
-            else:
-                other = list(shard.frame_shard(n_total, world - 1, world))[0]
-                wl = wls.get(other % args.distinct) or job["make"](other % args.distinct)
-                exp, _ = pyoracle.vardct_render(wl.desc(), abi.STAGE_ALL, job["out_w"], job["out_h"])
-                ok = bool(np.array_equal(got_all[world - 1][0].cpu().numpy(), pyoracle.format_output(exp, gather_fmt, 1)))
-                gv = {"ok": ok, "what": "first frame of rank %d as gathered on rank 0 (u8) == oracle render, formatted" % (world - 1)}
-            verified = dict(verified or {"ok": True}, gathered=gv)
-            verified["ok"] = bool(verified["ok"] and gv["ok"])
-        e2e = None
-        if not args.no_extras and args.config == 2:
-            e2e = end_to_end(ctx, wls[mine[0] % args.distinct], mp_per_frame)
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (bounded CPU sample)
-            cpu = cpu_baseline(args.config, args.cpu_seconds)
-        out = {
-            "metric": job["metric"],
-            "value": round(value, 1),
-            "unit": "MP/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "strong",
-            "value_includes": ("render + device formatting + gather of the stitched output to rank 0 (overlapped: shard.PipelinedGather)"
-                               if gather is not None else "render (N = 1: the output is on the one GPU; formatting timed apart as gather_ms)"),
-            "value_render_only": None if value_render_only is None else round(value_render_only, 1),
-            "gather_error": gather_error,
-            "gathered_GB_per_step": None if gather is None else round(gather.bytes_to_dst / max(gstep[0], 1) * passes / 1e9, 3),
-            "vs_baseline": None,
-            "dtype": job["dtype"],
-            "data": "synthetic",
-            "config": {
-                "workload": job["workload"],
-                "frames_in_job": n_total,
-                "passes_per_step": passes,
-                "frames_per_gpu_per_step": len(frames) * passes,
-                "distinct_frames": args.distinct,
-                "sharding": ("one frame = N bands of output rows, one per rank (shard.band_rows + jxlgpu_vardct_render_region), u16 bands gathered to rank 0"
-                             if band_sharded else
-                             "frames across ranks (shard.frame_shard), no data-path collective; the u8 output gathered to rank 0"),
-                "input": job.get("input", "decoded state resident in HBM"),
-                "launches": "jxlgpu_vardct_render_batch: one launch per stage for <= 32 frames" if job["batched"] else "one frame at a time",
-            },
-            "roofline": roofline,
-            "roofline_valu": roofline_valu,
-            "verified": verified,
-            "gather_ms": None if gather_ms is None else round(gather_ms, 3),
-            "value_with_gather": None if gather_ms is None else round(
-                n_total * passes * mp_per_frame / (elapsed / args.steps + passes * gather_ms * 1e-3), 1),
-            "end_to_end": e2e,
-            "cpu_baseline": cpu,
-        }
-    for f in frames:
-        f.free()
+        # ---- stitched output (config 4's gather): u8 formatting on the device + one gather, timed apart
+        gather_ms = None
+        if not args.no_extras and args.config == 2 and frames and world == 1:
+            shard.gather_formatted_batch(ctx, frames, abi.FMT_U8)  # warm (allocations, RCCL channels)
+            barrier()
+            reps = 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                shard.gather_formatted_batch(ctx, frames, abi.FMT_U8)
+            barrier()
+            gather_s = (time.perf_counter() - t0) / reps
+            if world > 1:
+                t = torch.tensor([gather_s], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                gather_s = float(t.item())
+            gather_ms = gather_s * 1e3
+
+        out = None
+        if rank == 0:
+            f0 = frames[0]
+            # a batched step = ceil(frames / 32) launches of the group; prof_n brackets in K steps
+            frames_per_launch = len(frames) * passes * args.steps / max(prof_n, 1) if job["batched"] else 1
+            alg_frame = job["alg_bytes"](f0, dominant)
+            avg_ms = prof_ms / max(prof_n, 1)
+            achieved = alg_frame * frames_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            traffic, traffic_src = job["traffic"](dominant, frames_per_launch)
+            roofline = {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": job["group_names"][dominant], "avg_launch_ms": round(avg_ms, 4), "launches": int(prof_n),
+                "frames_per_launch": round(frames_per_launch, 2),
+                "algorithmic_bytes_per_launch": int(alg_frame * frames_per_launch),
+                "group_ms_per_frame": {job["group_names"][g].split(":")[0]: round(group_ms[g] / max(len(frames) * passes, 1), 4) for g in group_ms},
+                "pipeline_algorithmic_frac": round(job["alg_bytes"](f0, None) * n_total * passes * args.steps / elapsed / 1e9 / world / HBM_PEAK_GBS, 4),
+                "traffic_ratio": None if not traffic else round(traffic / (alg_frame * frames_per_launch), 3),
+            }
+            roofline_valu = None
+            if args.config == 2 and dominant == 2:
+                # the streaming kernel's region and segmentation, as fused_prepare() lays them out
+                iw, ih = (W4K - 4) // 8 * 8 - 16, (H4K - 4) // 8 * 8 - 16
+                nseg = max(1, (ih + POST_ROWS_PER_SEG // 2) // POST_ROWS_PER_SEG)
+                rows = (-(-ih // nseg) + 3) // 4 * 4
+                segs = -(-ih // rows)
+                strips = -(-iw // POST_STRIP)
+                winstr = strips * segs * (rows + POST_HALO_ROWS) * POST_VALU_PER_ROW * frames_per_launch
+                ach = winstr / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+                roofline_valu = {"bound": "valu", "achieved": round(ach, 1), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
+                                 "frac": round(ach / VALU_PEAK_GINSTR, 4),
+                                 "note": "streaming post kernel, f32 in the reference's operation order (no FMA contraction, "
+                                         "correctly rounded division); a packed v_pk_*_f32 instruction counts once; halo rows "
+                                         "and columns are recomputed (%d/%d x %d/%d)" % (
+                                             POST_STRIP + 8, POST_STRIP, rows + POST_HALO_ROWS, rows)}
+            verified = None
+            if not args.no_verify and not band_sharded:
+                vw = dict(list(wls.items())[:max(1, args.verify_frames)])
+                verified = job["verify"](ctx, frames, mine, vw, args.distinct)
+            if not args.no_verify and gather is not None:
+                # the stitched output as it arrived on rank 0: one frame that another rank rendered (config 2 / 4), or frame 0
+                # reassembled from every rank's band (config 5), against the oracle's formatted render
+                from oracle import pyoracle
+                got_all = gather.finish(gstep[0] - 1)
+                if band_sharded:
+                    wl = wls[0]
+                    exp, _ = pyoracle.vardct_render(wl.desc(), abi.STAGE_ALL, job["out_w"], job["out_h"])
+                    exp16 = pyoracle.format_output(exp, gather_fmt, 1)
+                    ok = True
+                    for r, (y0, y1) in enumerate(shard.band_rows(job["out_h"], world)):
+                        ok &= bool(np.array_equal(got_all[r][0, :y1 - y0].cpu().numpy().view(np.uint16), exp16[y0:y1]))
+                    gv = {"ok": ok, "what": "frame 0 reassembled on rank 0 from the %d gathered u16 bands == oracle render, formatted" % world}
+                else:
+                    other = list(shard.frame_shard(n_total, world - 1, world))[0]
+                    wl = wls.get(other % args.distinct) or job["make"](other % args.distinct)
+                    exp, _ = pyoracle.vardct_render(wl.desc(), abi.STAGE_ALL, job["out_w"], job["out_h"])
+                    ok = bool(np.array_equal(got_all[world - 1][0].cpu().numpy(), pyoracle.format_output(exp, gather_fmt, 1)))
+                    gv = {"ok": ok, "what": "first frame of rank %d as gathered on rank 0 (u8) == oracle render, formatted" % (world - 1)}
+                verified = dict(verified or {"ok": True}, gathered=gv)
+                verified["ok"] = bool(verified["ok"] and gv["ok"])
+            e2e = None
+            if not args.no_extras and args.config == 2:
+                e2e = end_to_end(ctx, wls[mine[0] % args.distinct], mp_per_frame)
+            cpu = None
+            if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (bounded CPU sample)
+                cpu = cpu_baseline(args.config, args.cpu_seconds)
+            out = {
+                "metric": job["metric"],
+                "value": round(value, 1),
+                "unit": "MP/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                "higher_is_better": True,
+                "scaling": "strong",
+                "value_includes": ("render + device formatting + gather of the stitched output to rank 0 (overlapped: shard.PipelinedGather)"
+                                   if gather is not None else "render (N = 1: the output is on the one GPU; formatting timed apart as gather_ms)"),
+                "value_render_only": None if value_render_only is None else round(value_render_only, 1),
+                "gather_error": gather_error,
+                "gathered_GB_per_step": None if gather is None else round(gather.bytes_to_dst / max(gstep[0], 1) * passes / 1e9, 3),
+                "vs_baseline": None,
+                "dtype": job["dtype"],
+                "data": "synthetic",
+                "config": {
+                    "workload": job["workload"],
+                    "frames_in_job": n_total,
+                    "passes_per_step": passes,
+                    "frames_per_gpu_per_step": len(frames) * passes,
+                    "distinct_frames": args.distinct,
+                "nz_fraction": nz if args.config != 3 else None,
+                    "sharding": ("one frame = N bands of output rows, one per rank (shard.band_rows + jxlgpu_vardct_render_region), u16 bands gathered to rank 0"
+                                 if band_sharded else
+                                 "frames across ranks (shard.frame_shard), no data-path collective; the u8 output gathered to rank 0"),
+                    "input": job.get("input", "decoded state resident in HBM"),
+                    "launches": "jxlgpu_vardct_render_batch: one launch per stage for <= 32 frames" if job["batched"] else "one frame at a time",
+                },
+                "roofline": roofline,
+                "roofline_valu": roofline_valu,
+                "verified": verified,
+                "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+                "value_with_gather": None if gather_ms is None else round(
+                    n_total * passes * mp_per_frame / (elapsed / args.steps + passes * gather_ms * 1e-3), 1),
+                "end_to_end": e2e,
+                "cpu_baseline": cpu,
+            }
+        for f in frames:
+            f.free()
+        ctx.synchronize()
+        if out is not None:
+            print(json.dumps(out), flush=True)
+
+    # one JSON line per density (default: the one density SURVEY §8(d) specifies)
+    for nz in [float(v) for v in str(args.nz).split(",") if v.strip()]:
+        run_density(nz)
     ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if out is not None:
-        print(json.dumps(out), flush=True)
 
 
 # ------------------------------------------------------------------------------------------------
-def make_job(config, distinct, transport="grouped"):
+def make_job(config, distinct, transport="grouped", nz=0.15):
     import numpy as np
     from jxl_oxide_amd import abi
 
@@ -385,7 +396,7 @@ def make_job(config, distinct, transport="grouped"):
                       "sparse_i16": "as dense_i32 (zero-fill + scatter at upload, not timed)"}[transport],
             "workload": f"{W4K}x{H4K} VarDCT d1 XYB, Gabor + EPF iters 2, XYB->sRGB f32 planar (BASELINE config 2 frames, config 4 batch of 64)",
             "out_w": W4K, "out_h": H4K,
-            "make": lambda d: VardctWorkload(W4K, H4K, seed=2000 + d),
+            "make": lambda d: VardctWorkload(W4K, H4K, seed=2000 + d, nz_fraction=nz),
             "upload": lambda ctx, wl: ctx.vardct_upload(wl.desc(coeff_transport=transport)),
             "render": lambda ctx, frames: ctx.vardct_render_batch(frames, stages),
             "groups": (1, 2),
@@ -415,7 +426,7 @@ def make_job(config, distinct, transport="grouped"):
             "metric": "Megapixels/sec decoded (8K out: coded 4K VarDCT, 2x upsampling, EPF iters 3, PQ)", "dtype": "f32", "batched": False,
             "workload": "coded 3840x2160 VarDCT, Gabor + EPF iters 3, 2x non-separable upsampling -> 7680x4320, intensity target 4000, Rec.2100 PQ (BASELINE config 5)",
             "out_w": 2 * W4K, "out_h": 2 * H4K,
-            "make": lambda d: VardctWorkload(W4K, H4K, seed=5000 + d, epf_iters=3, upsampling=2, intensity_target=4000.0, hdr_pq=True),
+            "make": lambda d: VardctWorkload(W4K, H4K, seed=5000 + d, epf_iters=3, upsampling=2, intensity_target=4000.0, hdr_pq=True, nz_fraction=nz),
             "upload": lambda ctx, wl: ctx.vardct_upload(wl.desc(coeff_transport=transport)),
             "render": render, "groups": (1, 2),
             "group_names": {1: "transform: V4-V8", 2: "post: fused_post_kernel<true,4> (Gabor + EPF step 0) + post_pk_kernel (steps 1, 2) + upsample2_lds_kernel (2x + PQ, packed colour chain)"},
@@ -454,19 +465,62 @@ def make_job(config, distinct, transport="grouped"):
 
 
 def end_to_end(ctx, wl, mp_per_frame):
-    """PCIe-inclusive: upload (grouped non-zero lists) + render + u8 interleaved download, per frame."""
+    """PCIe-inclusive, what a decoder calling the library once per frame feels (never `value`):
+    serial    : upload -> render -> u8 interleaved download into pageable memory, one frame at a time, best of 5, with
+                the split (host build / H2D / render / format + D2H);
+    pipelined : the same three calls per frame with three frames in flight — jxlgpu_vardct_upload does not wait for the
+                device, jxlgpu_frame_format_output writes a pinned buffer (jxlgpu_host_alloc) asynchronously,
+                jxlgpu_frame_wait + jxlgpu_frame_free retire the oldest frame: upload k+1 overlaps render k overlaps
+                download k-1."""
+    import numpy as np
     from jxl_oxide_amd import abi
     d = wl.desc(coeff_transport="grouped")
-    best = 1e9
-    for _ in range(4):
+    for _ in range(3):  # warm the three staging buffers and the pool
+        f = ctx.vardct_upload(d); ctx.vardct_render(f, abi.STAGE_ALL, to_host=False); ctx.format_output(f, abi.FMT_U8, 1); f.free()
+    best, split = 1e9, None
+    for _ in range(5):
         t0 = time.perf_counter()
         f = ctx.vardct_upload(d)
+        t1 = time.perf_counter()
         ctx.vardct_render(f, abi.STAGE_ALL, to_host=False)
-        ctx.format_output(f, abi.FMT_U8, 1)
-        best = min(best, time.perf_counter() - t0)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        ref = ctx.format_output(f, abi.FMT_U8, 1)
+        t3 = time.perf_counter()
+        sp = ctx.upload_split()
         f.free()
-    return {"ms_per_frame": round(best * 1e3, 3), "MP_per_s": round(mp_per_frame / best, 1),
-            "what": "jxlgpu_vardct_upload (grouped non-zero lists, 4.6 MB instead of 99.5 MB of dense planes; host work-list build included) + render + u8 interleaved D2H, one frame at a time, best of 4"}
+        if t3 - t0 < best:
+            best = t3 - t0
+            split = {"upload_call_ms": round((t1 - t0) * 1e3, 3), "host_build_ms": round(sp[0], 3), "h2d_ms": round(sp[4], 3),
+                     "render_ms": round((t2 - t1) * 1e3 - sp[4], 3), "format_d2h_pageable_ms": round((t3 - t2) * 1e3, 3)}
+    depth, n = 3, 48
+    outs = [ctx.host_alloc((wl.height, wl.width, 3), np.uint8) for _ in range(depth)]
+    pipe = 1e9
+    for _ in range(2):
+        inflight = []
+        t0 = time.perf_counter()
+        for k in range(n):
+            f = ctx.vardct_upload(d)
+            ctx.vardct_render(f, abi.STAGE_ALL, to_host=False)
+            ctx.format_output_async(f, abi.FMT_U8, outs[k % depth])
+            inflight.append(f)
+            if len(inflight) == depth:
+                g = inflight.pop(0); ctx.frame_wait(g); g.free()
+        for g in inflight:
+            ctx.frame_wait(g); g.free()
+        pipe = min(pipe, (time.perf_counter() - t0) / n)
+    same = bool(np.array_equal(outs[(n - 1) % depth], ref))
+    for o in outs:
+        ctx.host_free(o)
+    nzw = int(sum(int(d.hf_groups[g].num_nz) for g in range(d.num_hf_groups)))
+    return {"ms_per_frame": round(pipe * 1e3, 3), "MP_per_s": round(mp_per_frame / pipe, 1),
+            "serial_ms_per_frame": round(best * 1e3, 3), "serial_MP_per_s": round(mp_per_frame / best, 1), "serial_split": split,
+            "pipelined_output_identical_to_serial": same,
+            "what": "per frame: jxlgpu_vardct_upload (grouped non-zero lists; work-list build on the ctx's host threads, one pinned arena, "
+                    "one async H2D) + jxlgpu_vardct_render + jxlgpu_frame_format_output (u8 interleaved).  ms_per_frame: three frames in "
+                    "flight, output into pinned memory (upload k+1 / render k / download k-1 overlap); serial_*: one frame at a time, "
+                    "output into pageable memory, best of 5",
+            "list_MB_per_frame": None if nzw is None else round(nzw * 4 / 1e6, 2)}
 
 
 def cpu_baseline(config, seconds):

@@ -170,7 +170,10 @@ class VardctWorkload:
     def __init__(self, width, height, seed=0, epf_iters=2, gabor=True, tf=abi.TF_SRGB,
                  intensity_target=255.0, upsampling=1, types=None, lf_i16=True,
                  zero_fraction=0.85, skip_lf_smoothing=False, hdr_pq=False, group_dim=256,
-                 color_mode=None, noise=False, lf_frame=False):
+                 color_mode=None, noise=False, lf_frame=False, nz_fraction=None):
+        """nz_fraction (None: the historical generator, ~4.7 % of the coefficients end up non-zero): the fraction of
+        ALL coefficients of the frame that are non-zero after quantisation — the largest-magnitude draws survive, so
+        the non-zeros sit at the low frequencies like a real stream's.  SURVEY §8(d) specifies 0.15 for the headline."""
         rng = np.random.default_rng(SEED_BASE + seed)
         self.width, self.height = width, height
         self.group_dim = group_dim
@@ -204,8 +207,17 @@ class VardctWorkload:
             scale = amp / step
             blk_mul = hf_mul[ys[sel], xs[sel]].astype(np.float32)[:, None, None, None]
             vals = rng.laplace(0.0, 1.0, size=(n, 3, H, W)).astype(np.float32) * scale * blk_mul
-            keep = rng.random(size=(n, 3, H, W)) >= zero_fraction
-            q = np.where(keep, np.rint(vals), 0).astype(np.int32)
+            if nz_fraction is None:
+                keep = rng.random(size=(n, 3, H, W)) >= zero_fraction
+                q = np.where(keep, np.rint(vals), 0).astype(np.int32)
+            else:
+                # gain such that exactly the top `nz_fraction` of the magnitudes (LLF corner excluded) round away from zero
+                vals[:, :, :bh, :bw] = 0
+                mag = np.abs(vals).ravel()
+                k = min(mag.size - 1, max(0, int(round(nz_fraction * mag.size))))
+                tau = np.partition(mag, mag.size - 1 - k)[mag.size - 1 - k] if k > 0 else np.inf
+                gain = np.float32(0.5) / np.float32(tau) if np.isfinite(tau) and tau > 0 else np.float32(0)
+                q = np.clip(np.rint(vals * gain), -32767, 32767).astype(np.int32)
             q[:, :, :bh, :bw] = 0  # LLF positions are not coded in HF (hf_coeff.rs)
             for i, (cy, cx) in enumerate(zip(ys[sel], xs[sel])):
                 coeff[:, cy * 8:cy * 8 + H, cx * 8:cx * 8 + W] = q[i]

@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$1
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH_SHORT="python $R/bench.py --steps 2 --warmup 1 --frames 8 --no-cpu-baseline --no-extras --no-verify"
+BENCH_SHORT="python $R/bench.py --steps 2 --warmup 1 --frames 8 --no-cpu-baseline --no-extras --no-verify --distinct 2"
 case "$1" in
   stats) timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras ;;
   hbm)   timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $BENCH_SHORT
