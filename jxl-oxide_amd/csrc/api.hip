@@ -221,9 +221,9 @@ void ctx_defer_release(jxlgpu_ctx* ctx, std::vector<void*>&& ptrs, void* modular
     Deferred d;
     d.ptrs = std::move(ptrs);
     d.modular = modular; d.modular_free = modular_free;
-    hipStream_t st[4] = {ctx->stream, ctx->stream2, ctx->stream_up, ctx->stream_down};
+    hipStream_t st[5] = {ctx->stream, ctx->stream2, ctx->stream_up, ctx->stream_down, ctx->stream_tr};
     bool ok = true;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
         d.ev[i] = ctx_event(ctx);
         ok = ok && d.ev[i] && hipEventRecord(d.ev[i], st[i]) == hipSuccess;
     }
@@ -502,6 +502,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     ctx->tune.no_fused = getenv("JXLGPU_NO_FUSED") != nullptr;
     ctx->tune.no_sparse_tr = getenv("JXLGPU_NO_SPARSE_TR") != nullptr;
     ctx->tune.debug_sync = getenv("JXLGPU_DEBUG_SYNC") != nullptr;
+    ctx->tune.no_batch_overlap = getenv("JXLGPU_NO_BATCH_OVERLAP") != nullptr;
     if (const char* v = getenv("JXLGPU_GUARD")) {
         const int m = atoi(v);
         if (m == 1 || m == 2) ctx->guard_mode = m;
@@ -528,6 +529,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream_tr, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_down, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -557,7 +559,7 @@ void jxlgpu_destroy(jxlgpu_ctx* ctx) {
         (void)hipFree(ctx->tr_prof);
     }
 #endif
-    for (hipStream_t st : {ctx->stream, ctx->stream2, ctx->stream_up, ctx->stream_down})
+    for (hipStream_t st : {ctx->stream_tr, ctx->stream, ctx->stream2, ctx->stream_up, ctx->stream_down})
         if (st) (void)hipStreamSynchronize(st);
     ctx_reap(ctx, true);
     delete ctx->workers;
@@ -570,6 +572,8 @@ void jxlgpu_destroy(jxlgpu_ctx* ctx) {
     for (hipEvent_t e : ctx->ev_h2d) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream_tr) (void)hipStreamDestroy(ctx->stream_tr);
+    for (hipEvent_t e : ctx->ev_tr) if (e) (void)hipEventDestroy(e);
     if (ctx->stream_up) (void)hipStreamDestroy(ctx->stream_up);
     if (ctx->stream_down) (void)hipStreamDestroy(ctx->stream_down);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -590,6 +594,7 @@ int jxlgpu_synchronize(jxlgpu_ctx* ctx) {
     if (!ctx) return JXLGPU_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_up));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_tr));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_down));
@@ -1962,12 +1967,15 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
         for (uint32_t i = 0; i < n; ++i) TRY(jxlgpu_vardct_render(ctx, frames[i], stages, nullptr));
         return JXLGPU_OK;
     }
-    // One stream, <= 32 frames per launch, stage after stage.  Running the V1-V8 launches of chunk k+1
-    // on a second stream beside the post stage of chunk k was measured (round 2) and is slower: both
-    // stages are VALU-issue bound on this workload, so they only share the SIMDs.
+    // <= `chunk` frames per launch, stage after stage.  V1-V8 run on their own stream: the transform launches of
+    // chunk k+1 (latency-bound: list-fed, a third of the VALU issue slots) share the CUs with the post launch of
+    // chunk k (VALU-bound) instead of queueing behind it.  Order per frame: its transform waits for whatever was
+    // queued last for that frame (upload, an earlier render that still reads the transform output), its post
+    // stage waits for its transform.
+    const bool overlap = !ctx->tune.no_batch_overlap;
     const uint32_t chunk = ctx->tune.batch_chunk > 0 ? std::min<uint32_t>((uint32_t)ctx->tune.batch_chunk, JXLGPU_MAX_BATCH)
-                                                     : JXLGPU_MAX_BATCH;
-    hipStream_t st = ctx->stream, sp = ctx->stream;
+                                                     : (overlap ? std::min<uint32_t>(16u, JXLGPU_MAX_BATCH) : JXLGPU_MAX_BATCH);
+    hipStream_t st = overlap ? ctx->stream_tr : ctx->stream, sp = ctx->stream;
     for (uint32_t i0 = 0; i0 < n; i0 += chunk) {
         const uint32_t m = std::min<uint32_t>(chunk, n - i0);
         FrameBatch b;
@@ -1983,6 +1991,7 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
             max_stream = std::max(max_stream, f->batch_stream_wgs);
             max_ring = std::max(max_ring, f->n_ring_tiles);
             any_smooth |= !f->desc.skip_adaptive_lf_smoothing;
+            if (overlap && f->ev_last && f->ev_last_set) HIP_TRY(ctx, hipStreamWaitEvent(st, f->ev_last, 0));
         }
         ctx->prof_begin(PROF_LF, st);
         HIP_TRY(ctx, launch_lf_batch(st, b, m, max_w8, max_h8, any_smooth));
@@ -2000,6 +2009,12 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
                                    : launch_transform_batch(st, nullptr, b, m, max_wgs, max_special));
         }
         ctx->prof_end(PROF_TRANSFORM, st);
+        if (overlap) {
+            hipEvent_t& ev = ctx->ev_tr[ctx->ev_tr_next++ % 8];
+            if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventRecord(ev, st));
+            HIP_TRY(ctx, hipStreamWaitEvent(sp, ev, 0));
+        }
         if (!batched) {
             for (uint32_t i = 0; i < m; ++i) {
                 jxlgpu_frame* f = frames[i0 + i];

@@ -211,6 +211,7 @@ struct Tuning {
     bool no_fused = false;       // JXLGPU_NO_FUSED: one kernel per post stage
     bool no_sparse_tr = false;   // JXLGPU_NO_SPARSE_TR: grouped lists are expanded to dense cells first (dense kernels)
     bool debug_sync = false;     // JXLGPU_DEBUG_SYNC: synchronise + report after every launch group
+    bool no_batch_overlap = false; // JXLGPU_NO_BATCH_OVERLAP: batched renders on one stream, stage after stage (round-3 form)
     int tr_wgs_per_cu[4] = {0, 0, 0, 0};  // JXLGPU_TR_WGS_PER_CU="a,b,c,d": persistent transform workgroups per CU
                                  // for the 8-, 16-, 32- and 64-px launch (0: one workgroup per item, no run-ahead)
     int sqz_seg = 64;            // JXLGPU_SQZ_SEG: pairs per inverse-Squeeze segment
@@ -244,7 +245,7 @@ struct StageBuf {
 // frame was freed: jxlgpu_frame_free never blocks, the buffers go back to the pool once `ev` have all fired.
 struct Deferred {
     std::vector<void*> ptrs;
-    hipEvent_t ev[4] = {};
+    hipEvent_t ev[5] = {};
     void* modular = nullptr;
     void (*modular_free)(void*) = nullptr;
 };
@@ -255,6 +256,9 @@ struct jxlgpu_ctx {
     Tuning tune;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: 64-pixel varblock kernels overlap the <=32 kernel
+    hipStream_t stream_tr = nullptr;    // batched renders: V1-V8 of chunk k+1 beside the post stage of chunk k
+    hipEvent_t ev_tr[8] = {};
+    uint32_t ev_tr_next = 0;
     hipStream_t stream_up = nullptr;    // H2D of the upload arenas: overlaps the kernels of earlier frames
     hipStream_t stream_down = nullptr;  // asynchronous D2H of formatted output (JXLGPU_MEM_HOST_PINNED)
     StageBuf stage[3];

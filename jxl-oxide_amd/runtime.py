@@ -23,6 +23,8 @@ def gpu_canary(attempts=3, timeout=120, quiet=False):
     died), "nodevice" or "missing" (binary not built)."""
     import os
     import subprocess
+    if os.environ.get("JXLGPU_NO_CANARY"):  # profiling runs: rocprofv3 would follow the child process
+        return "skipped"
     exe = canary_path()
     if not os.path.exists(exe):
         if not quiet:
