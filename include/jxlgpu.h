@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 16u
+#define JXLGPU_ABI_VERSION 18u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -177,8 +177,10 @@ typedef struct {
  * (dx, dy) is the coefficient's position inside the varblock after the need_transpose swap
  * (:236-241) and coeff = unpack_signed(ucoeff) << coeff_shift (:235).  The device transform
  * consumes these lists directly (no dense coefficient plane is ever built): the shim replaces the
- * store at hf_coeff.rs:243 by a push.  Single-pass frames with |coeff| < 32768 only (what a
- * non-progressive stream is); anything else uses JXLGPU_COEFF_SPARSE / _DENSE.                 */
+ * store at hf_coeff.rs:243 by a push.  Every triple needs |coeff| < 32768 (anything else uses
+ * JXLGPU_COEFF_SPARSE / _DENSE).  Progressive frames (frame_header.passes.num_passes > 1) hand over one
+ * JxlGpuHfGroup per (pass, group): pass p adds its `unpack_signed(ucoeff) << coeff_shift` values to what the
+ * earlier passes left at the same positions (`+=`, hf_coeff.rs:234); see JxlGpuVardctDesc.num_passes.     */
 typedef struct {
     uint32_t num_varblocks;   /* BlockInfo::Data cells of the group                               */
     uint32_t num_nz;          /* entries in `nz` = sum of nz_count                                */
@@ -223,6 +225,12 @@ typedef struct {
      * frames (jpeg_upsampling != 0).                                                             */
     uint32_t num_hf_groups;
     const JxlGpuHfGroup* hf_groups;
+    /* JXLGPU_COEFF_GROUPED, progressive frames: `hf_groups` holds num_passes x num_hf_groups entries, pass after
+     * pass (hf_groups[p * num_hf_groups + g]); every pass lists every varblock of the block map (with zero counts
+     * where it has nothing).  The device sums the passes into its coefficient cells (an integer accumulation, then
+     * the dense transform kernels: dequantisation is not linear in the coefficient).  0 or 1: a single pass, the
+     * lists feed the transform kernels directly.                                                          */
+    uint32_t num_passes;
     /* A truncated stream rendered as far as it goes (`allow_partial`, jxl-render/src/vardct/mod.rs:275-305:
      * a pass group whose decode failed part-way keeps what was decoded): with JXLGPU_COEFF_GROUPED a group
      * may then list FEWER varblocks than its block map holds — the rest have no HF coefficients.        */
@@ -397,16 +405,49 @@ int jxlgpu_blend_rects(jxlgpu_ctx* ctx, float* base, uint32_t base_stride, uint3
 #define JXLGPU_FMT_F32 0u
 #define JXLGPU_FMT_U16 1u
 #define JXLGPU_FMT_U8 2u
+#define JXLGPU_MAX_EXTRA 8u
 typedef struct {
     uint32_t sample_format;   /* JXLGPU_FMT_*                                                     */
     uint32_t orientation;     /* ImageMetadata.orientation, 1..8 (EXIF numbering)                 */
+    /* extra channels interleaved behind the three colour samples of every pixel (RGBA: the alpha channel;
+     * `ImageStream` with alpha, jxl-oxide/src/fb.rs:40-118): indices of planes rendered with
+     * jxlgpu_frame_render_extra, each of the size of the colour result.  0 = colour only.              */
+    uint32_t num_extra;       /* 0..4 */
+    uint32_t extra[4];
 } JxlGpuFormatDesc;
-/* Writes out_w*out_h*3 samples (out_w/out_h swap for orientations 5..8) to `out` (host memory when
+/* Writes out_w*out_h*(3 + num_extra) samples (out_w/out_h swap for orientations 5..8) to `out` (host memory when
  * out_mem == JXLGPU_MEM_HOST, a device pointer for JXLGPU_MEM_DEVICE).  Needs a render queued on `frame`.
  * JXLGPU_MEM_HOST_PINNED (`out` from jxlgpu_host_alloc): asynchronous — the call returns once the kernel and the
  * copy are queued, `out` is complete after jxlgpu_frame_wait(frame).                                          */
 int jxlgpu_frame_format_output(jxlgpu_ctx* ctx, jxlgpu_frame* frame, const JxlGpuFormatDesc* fmt,
                                void* out, uint32_t out_mem, uint32_t* out_w, uint32_t* out_h);
+
+/* ---- extra channels (alpha, depth, spot colours, ...) ----
+ * The reference carries every extra channel of a frame through the tail of the render next to the colour
+ * channels: `prepare_color_upsampling` adds the frame's upsampling shift to the channel's own (ec_upsampling /
+ * dim_shift), and `upsample_nonseparable` (jxl-render/src/image.rs:487-557, called at render.rs:149) converts
+ * the integer grid with the channel's OWN bit depth (`convert_to_float_modular` -> BitDepth::parse_integer_sample,
+ * jxl-image/src/lib.rs:458-494) and upsamples it with the image's 5x5 kernels (features/upsampling.rs:6-41: 8x
+ * passes first, then the 2x / 4x remainder).  The restoration filters and the colour transform never touch extra
+ * channels.  One call per channel: upload + int -> float + upsampling; the result stays on the device with the frame
+ * (slot `index` < JXLGPU_MAX_EXTRA; jxlgpu_frame_format_output interleaves it) and is copied to `out` if that is not
+ * NULL (f32, `out_stride` elements per row; JXLGPU_MEM_HOST_PINNED: asynchronous, see jxlgpu_frame_wait).          */
+typedef struct {
+    const void* data;          /* width x height integer samples, tight rows: the channel as the Modular decode left it */
+    uint32_t width, height;    /* the channel's own (possibly downsampled) size                          */
+    uint32_t sample_type;      /* JXLGPU_SAMPLE_I16 / JXLGPU_SAMPLE_I32                                   */
+    uint32_t bit_depth;        /* ec_info[i].bit_depth.bits_per_sample                                   */
+    uint32_t float_sample;     /* BitDepth::FloatSample                                                   */
+    uint32_t exp_bits;
+    uint32_t upsampling_log2;  /* the channel's ChannelShift when upsample_nonseparable runs: log2(ec upsampling) +
+                                  log2(frame upsampling), 0..6 (0: conversion only)                       */
+    JxlGpuUpsampling weights;  /* ImageMetadata.up2/up4/up8_weight (`factor` is ignored); needed when
+                                  upsampling_log2 != 0                                                    */
+} JxlGpuExtraChannel;
+int jxlgpu_frame_render_extra(jxlgpu_ctx* ctx, jxlgpu_frame* frame, uint32_t index, const JxlGpuExtraChannel* ec,
+                              float* out, uint32_t out_stride, uint32_t out_mem);
+/* Device plane of extra channel `index` (tight rows) and its size; NULL before jxlgpu_frame_render_extra. */
+const float* jxlgpu_frame_extra_plane(const jxlgpu_frame* frame, uint32_t index, uint32_t* width, uint32_t* height);
 
 /* Bytes the algorithm must move per render for the given stages (compulsory HBM traffic:
  * coefficient read + final write + side data), used by bench.py for the roofline.                 */

@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 16
+ABI_VERSION = 18
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -179,6 +179,7 @@ class VardctDesc(C.Structure):
         ("sparse_count", C.c_uint64 * 3),
         ("num_hf_groups", C.c_uint32),
         ("hf_groups", C.POINTER(HfGroup)),
+        ("num_passes", C.c_uint32),
         ("allow_partial", C.c_uint32),
         ("lf_frame", f32p * 3),
         ("lf_frame_stride", C.c_uint32),
@@ -214,8 +215,25 @@ class Out(C.Structure):
     _fields_ = [("planes", f32p * 3), ("stride", C.c_uint32), ("mem", C.c_uint32)]
 
 
+MAX_EXTRA = 8
+
+
 class FormatDesc(C.Structure):
-    _fields_ = [("sample_format", C.c_uint32), ("orientation", C.c_uint32)]
+    _fields_ = [("sample_format", C.c_uint32), ("orientation", C.c_uint32),
+                ("num_extra", C.c_uint32), ("extra", C.c_uint32 * 4)]
+
+
+class ExtraChannel(C.Structure):
+    _fields_ = [
+        ("data", C.c_void_p),
+        ("width", C.c_uint32), ("height", C.c_uint32),
+        ("sample_type", C.c_uint32),
+        ("bit_depth", C.c_uint32),
+        ("float_sample", C.c_uint32),
+        ("exp_bits", C.c_uint32),
+        ("upsampling_log2", C.c_uint32),
+        ("weights", Upsampling),
+    ]
 
 
 class SqueezeStep(C.Structure):
@@ -297,6 +315,8 @@ _SYMBOLS = [
     ("jxlgpu_frame_download_lf", C.c_int, [C.c_void_p, C.c_void_p, f32p * 3]),
     ("jxlgpu_frame_format_output", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(FormatDesc), C.c_void_p, C.c_uint32,
                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("jxlgpu_frame_render_extra", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(ExtraChannel), C.c_void_p, C.c_uint32, C.c_uint32]),
+    ("jxlgpu_frame_extra_plane", f32p, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("jxlgpu_frame_algorithmic_bytes", C.c_uint64, [C.c_void_p, C.c_uint32]),
     ("jxlgpu_modular_upload", C.c_int, [C.c_void_p, C.POINTER(ModularDesc), C.POINTER(C.c_void_p)]),
     ("jxlgpu_modular_inverse", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -433,6 +433,7 @@ std::vector<float> expand_up_weights(const float* weights, int k) {
 }  // namespace
 
 void fill_color_args_public(const JxlGpuColorParams& cp, ColorArgs* c) { fill_color_args(cp, c); }
+std::vector<float> expand_up_weights_public(const float* weights, int k) { return expand_up_weights(weights, k); }
 
 // nullptr if the colour op list can run on the device, else why not
 const char* color_params_unsupported(const JxlGpuColorParams& cp) {
@@ -855,17 +856,22 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     const uint32_t n_groups = groups_x * groups_y;
     if (grouped && (d->num_hf_groups != n_groups || !d->hf_groups))
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "num_hf_groups does not match the frame size");
-    std::vector<uint64_t> nz_base(n_groups + 1, 0);  // list words in front of each group
+    // progressive frames: one list set per pass, pass-major (hf_groups[p * n_groups + g])
+    const uint32_t n_passes = grouped ? std::max(1u, d->num_passes) : 1u;
+    if (n_passes > 11) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "more than 11 passes");  // jxl-frame/src/header.rs Passes: num_passes <= 11
+    if (n_passes > 1 && d->allow_partial) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "allow_partial with a multi-pass grouped frame");
+    const uint32_t n_lists = n_groups * n_passes;
+    std::vector<uint64_t> nz_base((size_t)n_lists + 1, 0);  // list words in front of each (pass, group)
     if (grouped) {
-        for (uint32_t g = 0; g < n_groups; ++g) {
+        for (uint32_t g = 0; g < n_lists; ++g) {
             const JxlGpuHfGroup& hg = d->hf_groups[g];
             if ((hg.num_varblocks && !hg.nz_count) || (hg.num_nz && !hg.nz))
                 return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null list pointers in an HF group");
             nz_base[g + 1] = nz_base[g] + hg.num_nz;
         }
-        if (nz_base[n_groups] >= (1ull << 32)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "more than 2^32 non-zero coefficients");
+        if (nz_base[n_lists] >= (1ull << 32)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "more than 2^32 non-zero coefficients");
     }
-    const uint64_t nz_total = nz_base[n_groups];
+    const uint64_t nz_total = nz_base[n_lists];
 
     // ---- the arena: fixed-size items first, the lists (upper bounds) behind them
     Arena ar;
@@ -905,6 +911,14 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     for (int t = 0; t < 27; ++t) deq_max += (size_t)kSize[t][0] * kSize[t][1] * 64 * 3;
     const size_t off_entries = ar.add(ncell * sizeof(uint4), reinterpret_cast<void**>(&f->entries));
     const size_t off_nzc = grouped ? ar.add(ncell * 4, reinterpret_cast<void**>(&f->nzc)) : 0;
+    // passes 1 .. n_passes - 1: their own entry / count arrays (same varblocks, other list offsets and counts)
+    std::vector<uint4*> pass_entries_dev(n_passes, nullptr);
+    std::vector<uint32_t*> pass_nzc_dev(n_passes, nullptr);
+    std::vector<size_t> off_pass_entries(n_passes, 0), off_pass_nzc(n_passes, 0);
+    for (uint32_t p = 1; p < n_passes; ++p) {
+        off_pass_entries[p] = ar.add(ncell * sizeof(uint4), reinterpret_cast<void**>(&pass_entries_dev[p]));
+        off_pass_nzc[p] = ar.add(ncell * 4, reinterpret_cast<void**>(&pass_nzc_dev[p]));
+    }
     const size_t off_nometa = ar.add((size_t)n_groups * 4, reinterpret_cast<void**>(&f->nometa_groups));
     const size_t off_deq = ar.add(deq_max * 4, reinterpret_cast<void**>(&f->dequant));
 
@@ -943,11 +957,11 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     };
     std::vector<GroupScan> gs(n_groups);
     // one pass group's varblocks in decode order (raster inside the group): `emit(slot, entry, cyx)`; returns an error text or null
-    auto scan_group = [&](uint32_t g, auto&& emit, GroupScan* st) -> const char* {
+    auto scan_group = [&](uint32_t g, uint32_t pass, auto&& emit, GroupScan* st) -> const char* {
         const uint32_t gx = g % groups_x, gy = g / groups_x;
         const uint32_t lfx = gx * gcells / f->lfg_cells_x, lfy = gy * gcells / f->lfg_cells_y;
         const uint32_t lfg = lfy * f->lf_groups_per_row + lfx;
-        const JxlGpuHfGroup* hg = grouped ? &d->hf_groups[g] : nullptr;
+        const JxlGpuHfGroup* hg = grouped ? &d->hf_groups[(size_t)pass * n_groups + g] : nullptr;
         if (!has_meta[lfg]) {
             if (hg && (hg->num_varblocks || hg->num_nz)) return "HF lists for a group without HfMetadata";
             if (st) st->nometa = 1;
@@ -980,7 +994,7 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
                     const uint16_t* cnt = vb_k < hg->num_varblocks ? hg->nz_count + 3 * (size_t)vb_k : kNone;  // decode order: Y, X, B
                     const uint32_t max_nz = 63u * bw * bh;                 // hf_coeff.rs:193
                     if (cnt[0] > max_nz || cnt[1] > max_nz || cnt[2] > max_nz) return "non_zeros too large";
-                    e.w = (uint32_t)(nz_base[g] + nz_k);
+                    e.w = (uint32_t)(nz_base[(size_t)pass * n_groups + g] + nz_k);
                     e.y |= (uint32_t)cnt[2] << 16;
                     cyx = (uint32_t)cnt[0] | (uint32_t)cnt[1] << 16;
                     nz_k += (uint64_t)cnt[0] + cnt[1] + cnt[2];
@@ -999,7 +1013,8 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     const uint32_t row_chunk = 32, n_row_tasks = ceil_div(f->h8, row_chunk);
     const uint32_t nz_chunks = grouped ? std::max<uint32_t>(1, std::min<uint32_t>(16, (uint32_t)(nz_total >> 16))) : 0;
     const auto t_phase1 = std::chrono::steady_clock::now();
-    ctx_host_parallel(ctx, n_row_tasks + n_groups + nz_chunks, [&](uint32_t task) {
+    std::vector<const char*> pass_err((size_t)n_lists, nullptr);   // passes >= 1: validated in phase 1, written in phase 2
+    ctx_host_parallel(ctx, n_row_tasks + n_lists + nz_chunks, [&](uint32_t task) {
         if (task < n_row_tasks) {
             // frame-level side planes from the per-LF-group grids, cell rows [r0, r1)
             const uint32_t r0 = task * row_chunk, r1 = std::min(f->h8, r0 + row_chunk);
@@ -1050,14 +1065,17 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
             const uint32_t g = task - n_row_tasks;
             GroupScan& st = gs[g];
             memset(&st, 0, sizeof(st));
-            st.msg = scan_group(g, [&](int slot, const uint4&, uint32_t) { ++st.count[slot]; }, &st);
+            st.msg = scan_group(g, 0, [&](int slot, const uint4&, uint32_t) { ++st.count[slot]; }, &st);
             st.err = st.msg ? JXLGPU_ERR_INVALID_ARG : JXLGPU_OK;
+        } else if (task < n_row_tasks + n_lists) {
+            const uint32_t l = task - n_row_tasks;   // a later pass of a group: validation only
+            pass_err[l] = scan_group(l % n_groups, l / n_groups, [](int, const uint4&, uint32_t) {}, nullptr);
         } else {
             // the groups' non-zero lists, concatenated: an even share of the words per task
-            const uint32_t k = task - n_row_tasks - n_groups;
+            const uint32_t k = task - n_row_tasks - n_lists;
             const uint64_t w0 = nz_total * k / nz_chunks, w1 = nz_total * (k + 1) / nz_chunks;
             uint32_t g = (uint32_t)(std::upper_bound(nz_base.begin(), nz_base.end(), w0) - nz_base.begin()) - 1;
-            for (uint64_t w = w0; w < w1 && g < n_groups; ++g) {
+            for (uint64_t w = w0; w < w1 && g < n_lists; ++g) {
                 const uint64_t ge = std::min<uint64_t>(nz_base[g + 1], w1);
                 if (ge > w) memcpy(nzw + w, d->hf_groups[g].nz + (w - nz_base[g]), (size_t)(ge - w) * 4);
                 w = std::max(w, ge);
@@ -1066,6 +1084,8 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     });
     for (uint32_t g = 0; g < n_groups; ++g)
         if (gs[g].err) return fail(ctx, gs[g].err, gs[g].msg);
+    for (uint32_t l = n_groups; l < n_lists; ++l)
+        if (pass_err[l]) return fail(ctx, JXLGPU_ERR_INVALID_ARG, pass_err[l]);
     // copy_lf_dequant scale (vardct/mod.rs:398-400), f64 on the host exactly as the reference
     for (uint32_t g = 0; g < f->num_lf_groups; ++g) {
         const int32_t precision_scale = 1 << (9 - d->lf_groups[g].extra_precision);
@@ -1099,14 +1119,17 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     float* const deq = reinterpret_cast<float*>(H + off_deq);
     size_t deq_words = 0;
     bool zero_stays_zero = true;
-    ctx_host_parallel(ctx, n_groups + 1, [&](uint32_t task) {
-        if (task < n_groups) {
+    ctx_host_parallel(ctx, n_lists + 1, [&](uint32_t task) {
+        if (task < n_lists) {
+            const uint32_t g = task % n_groups, pass = task / n_groups;
+            uint4* const ent = pass == 0 ? entries : reinterpret_cast<uint4*>(H + off_pass_entries[pass]);
+            uint32_t* const cnt = pass == 0 ? nzc : reinterpret_cast<uint32_t*>(H + off_pass_nzc[pass]);
             uint32_t pos[kNumSlots];
-            for (int s = 0; s < kNumSlots; ++s) pos[s] = start[(size_t)task * kNumSlots + s];
-            (void)scan_group(task, [&](int slot, const uint4& e, uint32_t cyx) {
+            for (int s = 0; s < kNumSlots; ++s) pos[s] = start[(size_t)g * kNumSlots + s];
+            (void)scan_group(g, pass, [&](int slot, const uint4& e, uint32_t cyx) {
                 const uint32_t i = pos[slot]++;
-                entries[i] = e;
-                if (nzc) nzc[i] = cyx;
+                ent[i] = e;
+                if (cnt) cnt[i] = cyx;
             }, nullptr);
             return;
         }
@@ -1153,7 +1176,8 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     f->nz_total = nz_total;
     // grouped lists feed the transform kernels directly; dense cells are built from them only for frames
     // with >= 128-px varblocks (global-memory path) or on request (JXLGPU_NO_SPARSE_TR)
-    f->sparse_tr = grouped && !ctx->tune.no_sparse_tr && f->list_count[CLS_BIG] == 0 && zero_stays_zero;
+    // ... and for progressive frames: the passes are summed into dense cells first (integer accumulation)
+    f->sparse_tr = grouped && n_passes == 1 && !ctx->tune.no_sparse_tr && f->list_count[CLS_BIG] == 0 && zero_stays_zero;
 
     // ---- trim the arena to what was used: entries, nzc, nometa and the matrices are the tail items
     // (the items keep their offsets; the copy stops after the last used byte of each, the device allocation keeps the bound)
@@ -1167,9 +1191,13 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
         for (const ArenaItem& it : ar.items) *it.dev = dev_arena + it.off;
         // one copy for the fixed part + the lists up to the entries; the used parts of the tail items after it
         struct Piece { size_t off, bytes; };
-        const Piece pieces[5] = {{0, off_entries}, {off_entries, (size_t)n_entries * sizeof(uint4)},
-                                 {off_nzc, grouped ? (size_t)n_entries * 4 : 0}, {off_nometa, (size_t)n_nometa * 4},
-                                 {off_deq, deq_words * 4}};
+        std::vector<Piece> pieces = {{0, off_entries}, {off_entries, (size_t)n_entries * sizeof(uint4)},
+                                     {off_nzc, grouped ? (size_t)n_entries * 4 : 0}, {off_nometa, (size_t)n_nometa * 4},
+                                     {off_deq, deq_words * 4}};
+        for (uint32_t p = 1; p < n_passes; ++p) {
+            pieces.push_back({off_pass_entries[p], (size_t)n_entries * sizeof(uint4)});
+            pieces.push_back({off_pass_nzc[p], (size_t)n_entries * 4});
+        }
         if (!ctx->ev_h2d[0]) {
             HIP_TRY(ctx, hipEventCreate(&ctx->ev_h2d[0]));
             HIP_TRY(ctx, hipEventCreate(&ctx->ev_h2d[1]));
@@ -1187,6 +1215,10 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
             else if (grouped && it.off == off_nzc) bytes = (size_t)n_entries * 4;
             else if (it.off == off_nometa) bytes = (size_t)n_nometa * 4;
             else if (it.off == off_deq) bytes = deq_words * 4;
+            for (uint32_t p = 1; p < n_passes; ++p) {
+                if (it.off == off_pass_entries[p]) bytes = (size_t)n_entries * sizeof(uint4);
+                if (it.off == off_pass_nzc[p]) bytes = (size_t)n_entries * 4;
+            }
             void* p = nullptr;
             HIP_TRY(ctx, ctx_dev_malloc(ctx, &p, std::max<size_t>(bytes, 16)));
             f->allocs.push_back(p);
@@ -1226,7 +1258,11 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
         TRY(dev_alloc(ctx, f, &f->buf_a[c], npix));
         TRY(dev_alloc(ctx, f, &f->buf_b[c], npix));
     }
-    if (grouped && !f->sparse_tr) launch_grouped_to_dense(ctx->stream, f->entries, f->nzc, n_entries, f->nz, f->w8, f->coeff);
+    if (grouped && !f->sparse_tr) {
+        launch_grouped_to_dense(ctx->stream, f->entries, f->nzc, n_entries, f->nz, f->w8, f->coeff, false);
+        for (uint32_t p = 1; p < n_passes; ++p)  // `+=`, hf_coeff.rs:234: stream order makes the passes' sums exact
+            launch_grouped_to_dense(ctx->stream, pass_entries_dev[p], pass_nzc_dev[p], n_entries, f->nz, f->w8, f->coeff, true);
+    }
     if (f->list_count[CLS_BIG]) TRY(dev_alloc(ctx, f, &f->big_tmp, npix * 6));
     if (upf > 1) {
         const uint32_t ow = d->width * upf, oh = d->height * upf;

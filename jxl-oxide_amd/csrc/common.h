@@ -401,6 +401,9 @@ struct jxlgpu_frame {
     // result of the last render
     const float* result[3] = {};
     uint32_t result_stride = 0, result_w = 0, result_h = 0;
+    // extra channels (jxlgpu_frame_render_extra): device planes, tight rows
+    float* extra[JXLGPU_MAX_EXTRA] = {};
+    uint32_t extra_w[JXLGPU_MAX_EXTRA] = {}, extra_h[JXLGPU_MAX_EXTRA] = {};
     // modular state lives in modular.hip's own struct
     void* modular = nullptr;
     void (*modular_free)(void*) = nullptr;
@@ -443,7 +446,7 @@ hipError_t launch_transform_batch_sparse(hipStream_t s, hipStream_t side, const 
                                          const uint32_t max_wgs[4], uint32_t max_special);
 // grouped lists -> dense cell-tiled coefficients (fallback for frames with >= 128-px varblocks; `coeff` zeroed first)
 void launch_grouped_to_dense(hipStream_t s, const uint4* entries, const uint32_t* nzc, uint32_t n_entries,
-                             const uint32_t* nz, uint32_t w8, int32_t* coeff);
+                             const uint32_t* nz, uint32_t w8, int32_t* coeff, bool accumulate);
 int transform_items_nbi(int cls);
 void launch_nometa_groups(hipStream_t s, const TransformArgs& a, const uint32_t* groups,
                           uint32_t count, uint32_t group_dim, uint32_t groups_per_row);
@@ -455,6 +458,8 @@ void ctx_dev_release(jxlgpu_ctx* ctx, void* p);
 // release `ptrs` once everything queued so far on the ctx's streams has finished (never blocks)
 void ctx_defer_release(jxlgpu_ctx* ctx, std::vector<void*>&& ptrs, void* modular = nullptr, void (*modular_free)(void*) = nullptr);
 void ctx_reap(jxlgpu_ctx* ctx, bool wait);
+// upsample_inner's weights_quarter (features/upsampling.rs:77-93) from the 15 / 55 / 210 coded weights
+std::vector<float> expand_up_weights_public(const float* weights, int k);
 // f(0) ... f(n - 1) on the ctx's host worker threads + the caller; returns when all are done
 void ctx_host_parallel(jxlgpu_ctx* ctx, uint32_t n, const std::function<void(uint32_t)>& f);
 // mark "the frame's last queued operation is here" on stream `s` (jxlgpu_frame_wait)

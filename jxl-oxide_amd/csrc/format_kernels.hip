@@ -7,9 +7,11 @@
 namespace {
 
 struct FormatArgs {
-    const float* in[3];
+    const float* in[3 + 4];   // colour planes, then the selected extra channels
     void* out;
     uint32_t in_stride, ow, oh, orientation;
+    uint32_t nch;             // 3 + number of extra channels
+    uint32_t ex_stride[4];    // row strides of the extra planes (tight: their width)
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -30,10 +32,9 @@ __global__ __launch_bounds__(256) void format_kernel(FormatArgs a) {
         default: ox = a.oh - y - 1; oy = x; break;
     }
     const size_t gi = (size_t)oy * a.in_stride + ox;
-    const size_t o = ((size_t)y * a.ow + x) * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float v = a.in[c][gi];
+    const size_t o = ((size_t)y * a.ow + x) * a.nch;
+    for (uint32_t c = 0; c < a.nch; ++c) {
+        float v = c < 3 ? a.in[c][gi] : a.in[c][(size_t)oy * a.ex_stride[c - 3] + ox];
         if (FMT == JXLGPU_FMT_F32) {
             ((float*)a.out)[o + c] = v;
         } else if (FMT == JXLGPU_FMT_U16) {
@@ -77,8 +78,8 @@ __global__ __launch_bounds__(256) void format_u8_x4_kernel(FormatArgs a) {
 extern "C" int jxlgpu_frame_format_output(jxlgpu_ctx* ctx, jxlgpu_frame* f, const JxlGpuFormatDesc* fmt, void* out,
                                           uint32_t out_mem, uint32_t* out_w, uint32_t* out_h) {
     if (!ctx || !f || !fmt || !out || out_mem > JXLGPU_MEM_HOST_PINNED) return JXLGPU_ERR_INVALID_ARG;
-    if (fmt->orientation < 1 || fmt->orientation > 8 || fmt->sample_format > JXLGPU_FMT_U8) {
-        ctx->last_error = "bad orientation / sample format";
+    if (fmt->orientation < 1 || fmt->orientation > 8 || fmt->sample_format > JXLGPU_FMT_U8 || fmt->num_extra > 4) {
+        ctx->last_error = "bad orientation / sample format / more than 4 extra channels";
         return JXLGPU_ERR_INVALID_ARG;
     }
     if (!f->result[0]) {
@@ -89,7 +90,7 @@ extern "C" int jxlgpu_frame_format_output(jxlgpu_ctx* ctx, jxlgpu_frame* f, cons
     const uint32_t w = f->result_w, h = f->result_h;
     const uint32_t ow = fmt->orientation <= 4 ? w : h, oh = fmt->orientation <= 4 ? h : w;
     const size_t esz = fmt->sample_format == JXLGPU_FMT_F32 ? 4 : fmt->sample_format == JXLGPU_FMT_U16 ? 2 : 1;
-    const size_t bytes = (size_t)ow * oh * 3 * esz;
+    const size_t bytes = (size_t)ow * oh * (3 + fmt->num_extra) * esz;
     void* dst = out;
     if (out_mem != JXLGPU_MEM_DEVICE) {
         if (f->fmt_bytes < bytes) {
@@ -102,10 +103,21 @@ extern "C" int jxlgpu_frame_format_output(jxlgpu_ctx* ctx, jxlgpu_frame* f, cons
         dst = f->fmt_buf;
     }
     FormatArgs a;
+    memset(&a, 0, sizeof(a));
     for (int c = 0; c < 3; ++c) a.in[c] = f->result[c];
+    a.nch = 3 + fmt->num_extra;
+    for (uint32_t i = 0; i < fmt->num_extra; ++i) {
+        const uint32_t e = fmt->extra[i];
+        if (e >= JXLGPU_MAX_EXTRA || !f->extra[e] || f->extra_w[e] != f->result_w || f->extra_h[e] != f->result_h) {
+            ctx->last_error = "format_output: extra channel not rendered, or not of the size of the colour result";
+            return JXLGPU_ERR_INVALID_ARG;
+        }
+        a.in[3 + i] = f->extra[e];
+        a.ex_stride[i] = f->extra_w[e];
+    }
     a.out = dst; a.in_stride = f->result_stride; a.ow = ow; a.oh = oh; a.orientation = fmt->orientation;
     dim3 grid(ceil_div(ow, 256), oh);
-    const bool x4 = fmt->sample_format == JXLGPU_FMT_U8 && fmt->orientation == 1 && (ow & 3) == 0 && (a.in_stride & 3) == 0 &&
+    const bool x4 = fmt->num_extra == 0 && fmt->sample_format == JXLGPU_FMT_U8 && fmt->orientation == 1 && (ow & 3) == 0 && (a.in_stride & 3) == 0 &&
                     (reinterpret_cast<uintptr_t>(dst) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.in[0]) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(a.in[1]) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.in[2]) & 15) == 0;
     if (x4) format_u8_x4_kernel<<<dim3(ceil_div(ow / 4, 256), oh), 256, 0, ctx->stream>>>(a);

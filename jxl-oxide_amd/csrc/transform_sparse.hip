@@ -31,6 +31,7 @@ __global__ __launch_bounds__(64) void transform_special_sparse_batch_kernel(Fram
 
 // Fallback: expand the lists into the dense cell-tiled coefficients (zeroed by the caller).  One wave
 // per varblock, its three lists back to back.
+template <bool ACC>
 __global__ __launch_bounds__(256) void grouped_to_dense_kernel(const uint4* __restrict__ entries,
                                                                const uint32_t* __restrict__ nzc, uint32_t n_entries,
                                                                const uint32_t* __restrict__ nz, uint32_t w8,
@@ -54,8 +55,13 @@ __global__ __launch_bounds__(256) void grouped_to_dense_kernel(const uint4* __re
         for (uint32_t k = lane; k < cnt[s]; k += 64) {
             const uint32_t w = nz[off + k];
             const uint32_t dx = w & 255u, dy = (w >> 8) & 255u;
-            if (dx < bw * 8 && dy < bh * 8)  // positions outside the varblock are ignored, as in the list-fed kernels
-                coeff[coeff_tiled_index(px0 + dx, py0 + dy, chan[s], w8)] = (int32_t)w >> 16;
+            if (dx < bw * 8 && dy < bh * 8) {  // positions outside the varblock are ignored, as in the list-fed kernels
+                int32_t* q = &coeff[coeff_tiled_index(px0 + dx, py0 + dy, chan[s], w8)];
+                // a later pass of a progressive frame adds to what the earlier ones left (a position appears at most
+                // once per pass and channel: plain read-modify-write, launches are ordered by the stream)
+                if (ACC) *q += (int32_t)w >> 16;
+                else *q = (int32_t)w >> 16;
+            }
         }
         off += cnt[s];
     }
@@ -126,7 +132,8 @@ hipError_t launch_transform_batch_sparse(hipStream_t s, hipStream_t side, const 
 }
 
 void launch_grouped_to_dense(hipStream_t s, const uint4* entries, const uint32_t* nzc, uint32_t n_entries,
-                             const uint32_t* nz, uint32_t w8, int32_t* coeff) {
+                             const uint32_t* nz, uint32_t w8, int32_t* coeff, bool accumulate) {
     if (!n_entries) return;
-    grouped_to_dense_kernel<<<ceil_div(n_entries, 4), 256, 0, s>>>(entries, nzc, n_entries, nz, w8, coeff);
+    if (accumulate) grouped_to_dense_kernel<true><<<ceil_div(n_entries, 4), 256, 0, s>>>(entries, nzc, n_entries, nz, w8, coeff);
+    else grouped_to_dense_kernel<false><<<ceil_div(n_entries, 4), 256, 0, s>>>(entries, nzc, n_entries, nz, w8, coeff);
 }

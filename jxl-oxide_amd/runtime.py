@@ -197,14 +197,28 @@ class Context:
         self._check(self.lib.jxlgpu_blend_rects(self.handle, base_ptr, base_stride, base_w, base_h, new_ptr,
                                                 new_stride, new_w, new_h, arr, len(rects)))
 
-    def format_output(self, frame, sample_format, orientation=1):
+    def render_extra(self, frame, index, ec, to_host=True):
+        """Extra channel `index` of the frame: int -> float with its own bit depth + non-separable upsampling; the plane
+        stays on the device with the frame (format_output interleaves it).  Returns it as (h, w) f32 if to_host."""
+        w, h = ec.width << ec.upsampling_log2, ec.height << ec.upsampling_log2
+        if not to_host:
+            self._check(self.lib.jxlgpu_frame_render_extra(self.handle, frame.handle, index, C.byref(ec), None, 0, abi.MEM_HOST))
+            return None
+        out = np.zeros((h, w), dtype=np.float32)
+        self._check(self.lib.jxlgpu_frame_render_extra(self.handle, frame.handle, index, C.byref(ec), out.ctypes.data, w, abi.MEM_HOST))
+        return out
+
+    def format_output(self, frame, sample_format, orientation=1, extra=()):
         """Interleaved, oriented f32/u16/u8 image of the last render — a whole frame or a region —
-        formatted on the device."""
+        formatted on the device; `extra`: indices of rendered extra channels appended to every pixel (RGBA)."""
         w, h = frame.result_size()
         ow, oh = (w, h) if orientation <= 4 else (h, w)
         dt = {abi.FMT_F32: np.float32, abi.FMT_U16: np.uint16, abi.FMT_U8: np.uint8}[sample_format]
-        out = np.zeros((oh, ow, 3), dtype=dt)
+        out = np.zeros((oh, ow, 3 + len(extra)), dtype=dt)
         fmt = abi.FormatDesc(sample_format, orientation)
+        fmt.num_extra = len(extra)
+        for i, e in enumerate(extra):
+            fmt.extra[i] = e
         rw, rh = C.c_uint32(), C.c_uint32()
         self._check(self.lib.jxlgpu_frame_format_output(self.handle, frame.handle, C.byref(fmt), out.ctypes.data,
                                                         abi.MEM_HOST, C.byref(rw), C.byref(rh)))

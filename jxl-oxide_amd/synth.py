@@ -35,6 +35,42 @@ def _load_up_weights():
     return z["up2"], z["up4"], z["up8"]
 
 
+def make_extra_channel(width, height, seed=0, i16=True, bit_depth=8, float_sample=False, exp_bits=0, upsampling_log2=0):
+    """An extra channel as the Modular decode leaves it (integer samples of its own bit depth) and the descriptor of
+    jxlgpu_frame_render_extra.  `width` x `height` is the channel's own size.  Returns (ExtraChannel, keep-alive list)."""
+    rng = np.random.default_rng(SEED_BASE + 977 * (seed + 1))
+    dt = np.int16 if i16 else np.int32
+    if float_sample:
+        # valid bit patterns of the (1, exp_bits, mantissa) float: finite, exponent field not all-ones and not zero
+        mant_bits = bit_depth - exp_bits - 1
+        e = rng.integers(1, (1 << exp_bits) - 1, size=(height, width))
+        m = rng.integers(0, 1 << mant_bits, size=(height, width))
+        sgn = rng.integers(0, 2, size=(height, width))
+        pat = (sgn << (bit_depth - 1)) | (e << mant_bits) | m
+        data = pat.astype(np.uint32).view(np.int32).astype(np.int64)
+        if i16:
+            data = pat.astype(np.uint16).view(np.int16)
+        data = np.ascontiguousarray(data.astype(dt))
+    else:
+        # a soft matte plus samples slightly outside [0, max] (the Modular decode does not clamp)
+        yy, xx = np.mgrid[0:height, 0:width]
+        v = (np.sin(xx / 7.0) * np.cos(yy / 5.0) * 0.5 + 0.5) * ((1 << bit_depth) - 1)
+        v = v + rng.integers(-3, 4, size=(height, width))
+        lim = 32767 if i16 else (1 << 31) - 1
+        data = np.ascontiguousarray(np.clip(np.rint(v), -lim - 1, lim).astype(dt))
+    ec = abi.ExtraChannel()
+    ec.data = data.ctypes.data
+    ec.width, ec.height = width, height
+    ec.sample_type = abi.SAMPLE_I16 if i16 else abi.SAMPLE_I32
+    ec.bit_depth, ec.float_sample, ec.exp_bits = bit_depth, 1 if float_sample else 0, exp_bits
+    ec.upsampling_log2 = upsampling_log2
+    up = _load_up_weights()
+    ec.weights.up2_weight = up[0].ctypes.data_as(abi.f32p)
+    ec.weights.up4_weight = up[1].ctypes.data_as(abi.f32p)
+    ec.weights.up8_weight = up[2].ctypes.data_as(abi.f32p)
+    return ec, [data, up]
+
+
 # jxl-image/src/color.rs:613-627 OpsinInverseMatrix defaults
 OPSIN_INV = np.array([
     11.031566901960783, -9.866943921568629, -0.16462299647058826,
@@ -308,7 +344,7 @@ class VardctWorkload:
         self._keep = []
 
     # ---- descriptor
-    def desc(self, coeff_transport="dense_i32", sparse_split=False, partial=None):
+    def desc(self, coeff_transport="dense_i32", sparse_split=False, partial=None, pass_shifts=None):
         """`coeff_transport`: "dense_i32" (the reference's framebuffer), "dense_i16", "sparse_i32",
         "sparse_i16" (SURVEY §8f rank 2).  `sparse_split` splits every value over two list entries
         at the same position, as two passes of a progressive frame would (hf_coeff.rs:234 `+=`)."""
@@ -343,9 +379,29 @@ class VardctWorkload:
                 d.coeff[c] = plane.ctypes.data
         elif coeff_transport == "grouped":
             d.coeff_format = abi.COEFF_GROUPED
-            hf_groups, arrays = self.grouped_lists(partial)
-            keep_c += [hf_groups, arrays]
-            d.num_hf_groups = len(hf_groups)
+            if pass_shifts:
+                # a progressive frame: pass p carries the part of every coefficient above bit pass_shifts[p] that the
+                # earlier passes have not sent (`unpack_signed(ucoeff) << coeff_shift`, hf_coeff.rs:235); the parts sum
+                # to the coefficient
+                assert pass_shifts[-1] == 0 and partial is None
+                rest = self.coeff.astype(np.int64)
+                per_pass = []
+                for sft in pass_shifts:
+                    part = (rest >> sft) << sft
+                    rest = rest - part
+                    per_pass.append(self.grouped_lists(None, coeff=part.astype(np.int32)))
+                n = len(per_pass[0][0])
+                hf_groups = (abi.HfGroup * (n * len(per_pass)))()
+                for pi, (hf, arrays) in enumerate(per_pass):
+                    for g in range(n):
+                        hf_groups[pi * n + g] = hf[g]
+                keep_c += [hf_groups, per_pass]
+                d.num_passes = len(per_pass)
+                d.num_hf_groups = n
+            else:
+                hf_groups, arrays = self.grouped_lists(partial)
+                keep_c += [hf_groups, arrays]
+                d.num_hf_groups = len(hf_groups)
             d.hf_groups = C.cast(hf_groups, C.POINTER(abi.HfGroup))
         else:
             d.coeff_format = abi.COEFF_SPARSE
@@ -445,7 +501,7 @@ class VardctWorkload:
                 out[:, ys[i] * 8:(ys[i] + bh) * 8, xs[i] * 8:(xs[i] + bw) * 8] = 0
         return out
 
-    def grouped_lists(self, partial=None):
+    def grouped_lists(self, partial=None, coeff=None):
         """JXLGPU_COEFF_GROUPED: per 256x256 pass group, the `non_zeros` counts and the
         (dx, dy, coeff) triples in the order `write_hf_coeff` decodes them (hf_coeff.rs:97-254):
         Data cells of the group in raster order, channels Y, X, B.  The order of the triples inside
@@ -468,10 +524,11 @@ class VardctWorkload:
         counts = np.zeros((nvb, 3), dtype=np.int64)
         ent_vb, ent_slot, ent_word = [], [], []
         for slot, c in enumerate((1, 0, 2)):       # decoded Y, X, B (hf_coeff.rs:138-140)
-            py, px = np.nonzero(self.coeff[c])
+            src = self.coeff if coeff is None else coeff
+            py, px = np.nonzero(src[c])
             vb = owner[py // 8, px // 8]
             assert (vb >= 0).all()
-            val = self.coeff[c][py, px]
+            val = src[c][py, px]
             assert np.abs(val).max(initial=0) < 32768
             dx, dy = px - xs[vb] * 8, py - ys[vb] * 8
             counts[:, slot] = np.bincount(vb, minlength=nvb)

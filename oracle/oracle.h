@@ -57,6 +57,12 @@ void orc_upsample_inner(const float* in, size_t in_stride, size_t w, size_t h, f
 int orc_format_output(const float* const planes[3], size_t stride, uint32_t width, uint32_t height,
                       uint32_t sample_format, uint32_t orientation, void* out);
 
+int orc_format_output_n(const float* const* planes, const size_t* strides, uint32_t nch, uint32_t width, uint32_t height,
+                        uint32_t sample_format, uint32_t orientation, void* out);
+
+/* ---- extra.c ---- */
+int orc_extra_channel(const JxlGpuExtraChannel* ec, float* out, size_t out_stride);
+
 /* ---- color.c ---- */
 void orc_color_transform(float* const ch[3], size_t n, const JxlGpuColorParams* cp);
 

@@ -142,6 +142,36 @@ def format_output(planes, sample_format, orientation):
     return out
 
 
+def extra_channel(ec):
+    """jxlgpu_frame_render_extra's contract on the CPU: (h << L, w << L) f32."""
+    w, h = ec.width << ec.upsampling_log2, ec.height << ec.upsampling_log2
+    out = np.zeros((h, w), dtype=np.float32)
+    f = lib().orc_extra_channel
+    f.argtypes, f.restype = [C.c_void_p, f32p, C.c_size_t], C.c_int
+    rc = f(C.addressof(ec), _p(out), w)
+    if rc != 0:
+        raise RuntimeError(f"oracle extra_channel failed: {rc}")
+    return out
+
+
+def format_output_n(planes, sample_format, orientation):
+    """planes: list of (h, w) float32 arrays (3 colour + extra channels) -> (oh, ow, n) interleaved."""
+    planes = [np.ascontiguousarray(p, dtype=np.float32) for p in planes]
+    h, w = planes[0].shape
+    n = len(planes)
+    ow, oh = (w, h) if orientation <= 4 else (h, w)
+    dt = {0: np.float32, 1: np.uint16, 2: np.uint8}[sample_format]
+    out = np.zeros((oh, ow, n), dtype=dt)
+    arr = (f32p * n)(*[_p(p) for p in planes])
+    strides = (C.c_size_t * n)(*[p.shape[1] for p in planes])
+    f = lib().orc_format_output_n
+    f.argtypes, f.restype = [C.POINTER(f32p), C.POINTER(C.c_size_t), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p], C.c_int
+    rc = f(arr, strides, n, w, h, sample_format, orientation, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle format_output_n failed: {rc}")
+    return out
+
+
 def noise_group(width, height, seed0, seed1):
     """Raw noise of one group (NoiseGroup::new): (3, height, stride) floats in [1, 2)."""
     stride = -(-width // 16) * 16

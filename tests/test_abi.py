@@ -58,7 +58,7 @@ def test_field_offsets_match_the_compiler():
     """offsetof() of every field of every POD struct == the ctypes mirror (same names, same order)."""
     import subprocess
     import tempfile
-    pairs = [("JxlGpuFormatDesc", abi.FormatDesc), ("JxlGpuFilterParams", abi.FilterParams),
+    pairs = [("JxlGpuFormatDesc", abi.FormatDesc), ("JxlGpuExtraChannel", abi.ExtraChannel), ("JxlGpuFilterParams", abi.FilterParams),
              ("JxlGpuColorParams", abi.ColorParams), ("JxlGpuUpsampling", abi.Upsampling),
              ("JxlGpuNoiseParams", abi.NoiseParams), ("JxlGpuLfGroup", abi.LfGroup), ("JxlGpuHfGroup", abi.HfGroup),
              ("JxlGpuVardctDesc", abi.VardctDesc),

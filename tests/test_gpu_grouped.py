@@ -210,3 +210,35 @@ def test_lf_frame_replaces_the_lf_stages(gpu_ctx, oracle, transport, size):
         _same(got, np.ascontiguousarray(exp[:, reg[1]:reg[1] + reg[3], reg[0]:reg[0] + reg[2]]), "lf_frame, region")
     finally:
         f.free()
+
+
+@pytest.mark.parametrize("shifts", [[2, 0], [4, 1, 0], [1, 0, 0]])
+@pytest.mark.parametrize("size", [(264, 200), (520, 300)])
+def test_progressive_passes_accumulate(gpu_ctx, oracle, size, shifts):
+    """Multi-pass (progressive) frames through the grouped transport: one list set per (pass, group), pass p adding
+    `unpack_signed(ucoeff) << coeff_shift` to what the earlier passes left (hf_coeff.rs:234-235).  The oracle sees
+    the summed dense planes: the result must be bit-identical; so must a batched render of the frame."""
+    w, h = size
+    wl = VardctWorkload(w, h, seed=23, nz_fraction=0.2)
+    exp, _ = oracle.vardct_render(wl.desc(), S_ALL, w, h)
+    f = gpu_ctx.vardct_upload(wl.desc(coeff_transport="grouped", pass_shifts=shifts))
+    try:
+        _same(gpu_ctx.vardct_render(f, S_ALL), exp, f"{size} passes {shifts}")
+        gpu_ctx.vardct_render_batch([f], S_ALL)
+        gpu_ctx.synchronize()
+        _same(gpu_ctx.download_result(f), exp, f"{size} passes {shifts}, batched")
+    finally:
+        f.free()
+
+
+def test_pass_lists_are_validated(gpu_ctx):
+    from jxl_oxide_amd.runtime import JxlGpuError
+    wl = VardctWorkload(264, 200, seed=5)
+    d = wl.desc(coeff_transport="grouped", pass_shifts=[2, 0])
+    d.hf_groups[d.num_hf_groups].num_nz += 1   # the second pass of group 0 no longer matches its counts
+    with pytest.raises(JxlGpuError):
+        gpu_ctx.vardct_upload(d)
+    d = wl.desc(coeff_transport="grouped", pass_shifts=[2, 0])
+    d.num_passes = 12
+    with pytest.raises(JxlGpuError):
+        gpu_ctx.vardct_upload(d)

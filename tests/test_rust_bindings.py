@@ -31,7 +31,7 @@ def test_struct_sizes_equal_the_c_layout():
         "JxlGpuFilterParams": abi.FilterParams, "JxlGpuColorParams": abi.ColorParams, "JxlGpuBlendRect": abi.BlendRect,
         "JxlGpuNoiseParams": abi.NoiseParams, "JxlGpuUpsampling": abi.Upsampling, "JxlGpuLfGroup": abi.LfGroup,
         "JxlGpuHfGroup": abi.HfGroup, "JxlGpuVardctDesc": abi.VardctDesc, "JxlGpuRegion": abi.Region, "JxlGpuOut": abi.Out,
-        "JxlGpuFormatDesc": abi.FormatDesc, "JxlGpuSqueezeStep": abi.SqueezeStep, "JxlGpuTransform": abi.Transform,
+        "JxlGpuFormatDesc": abi.FormatDesc, "JxlGpuExtraChannel": abi.ExtraChannel, "JxlGpuSqueezeStep": abi.SqueezeStep, "JxlGpuTransform": abi.Transform,
         "JxlGpuModularChannel": abi.ModularChannel, "JxlGpuModularDesc": abi.ModularDesc,
     }
     assert set(mirror) == set(sizes), set(mirror) ^ set(sizes)
