@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="per CPU-baseline configuration")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip gather / end-to-end measurements")
+    ap.add_argument("--gather", default="p2p", choices=("p2p", "rccl", "none"),
+                    help="N > 1: how the stitched output reaches rank 0 inside the timed region — p2p: every rank's formatting kernels "
+                         "store into rank 0's buffer through an IPC peer mapping (shard.PeerWriteGather; falls back to rccl if the "
+                         "mapping cannot be made); rccl: overlapped dist.gather (shard.PipelinedGather); none: the output stays sharded")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,7 +117,7 @@ def main():
         # ---- N > 1: the stitched output is part of the job.  Every step's result is formatted on the device and
         # gathered to rank 0 (RCCL over xGMI) by shard.PipelinedGather: the gather of step k overlaps the kernels of
         # step k + 1, the host never waits inside the timed region, and `value` INCLUDES it.
-        gather, gather_fmt, band = None, None, None
+        gather, gather_fmt, band, gather_mode = None, None, None, None
         if world > 1 and args.config in (2, 5):
             if band_sharded:
                 bands = shard.band_rows(job["out_h"], world)
@@ -124,13 +128,24 @@ def main():
             else:
                 gather_fmt = abi.FMT_U8
                 shape = (-(-n_total // world), job["out_h"], job["out_w"], 3)
-            gather = shard.PipelinedGather(shape, torch.uint8, "cuda", lib_stream=ctx.stream(), dst=0)
+            slot_bytes = int(np.prod(shape[1:]))
+            if args.gather == "p2p":
+                try:
+                    gather = shard.PeerWriteGather(ctx, slot_bytes, shape[0], dst=0)
+                    gather_mode = "p2p"
+                except Exception as e:  # noqa: BLE001  (every rank fails at the same call: the handle exchange is collective)
+                    print(f"[bench] rank {rank}: peer-write gather unavailable ({type(e).__name__}: {e}); using the RCCL gather", file=sys.stderr)
+                    gather = None
+            if gather is None and args.gather != "none":
+                gather = shard.PipelinedGather(shape, torch.uint8, "cuda", lib_stream=ctx.stream(), dst=0)
+                gather_mode = "rccl"
         gstep = [0]
 
         def render_only():
             if band_sharded:
                 for f in frames:
-                    ctx.vardct_render_region(f, abi.STAGE_ALL, (0, band[0], job["out_w"], band[1] - band[0]), to_host=False)
+                    if band[1] > band[0]:   # more ranks than 8-row units: this rank has nothing to render
+                        ctx.vardct_render_region(f, abi.STAGE_ALL, (0, band[0], job["out_w"], band[1] - band[0]), to_host=False)
             else:
                 job["render"](ctx, frames)
 
@@ -138,9 +153,12 @@ def main():
             for _ in range(passes):
                 render_only()
                 if gather is not None and with_gather and frames:
-                    buf = gather.slot(gstep[0])
-                    shard.format_frames_into(ctx, frames, gather_fmt, buf)
-                    gather.submit(gstep[0])
+                    if gather_mode == "p2p":
+                        gather.write(frames, gather_fmt)
+                    else:
+                        buf = gather.slot(gstep[0])
+                        shard.format_frames_into(ctx, frames, gather_fmt, buf)
+                        gather.submit(gstep[0])
                     gstep[0] += 1
 
         def barrier():
@@ -260,7 +278,25 @@ def main():
                 # the stitched output as it arrived on rank 0: one frame that another rank rendered (config 2 / 4), or frame 0
                 # reassembled from every rank's band (config 5), against the oracle's formatted render
                 from oracle import pyoracle
-                got_all = gather.finish(gstep[0] - 1)
+                if gather_mode == "p2p":
+                    # (every rank's stream has drained and a barrier has passed since the last write: barrier() above)
+                    raw = gather.result()   # (world, slots, slot_bytes) uint8 on rank 0
+
+                    class _Slot:   # the indexing the checks below use on the RCCL gather's tensors
+                        def __init__(self, a):
+                            self.a = a
+
+                        def __getitem__(self, k):
+                            return _Slot(self.a[k])
+
+                        def cpu(self):
+                            return self
+
+                        def numpy(self):
+                            return self.a
+                    got_all = [_Slot(raw[r].reshape((shape[0],) + tuple(shape[1:]))) for r in range(world)]
+                else:
+                    got_all = gather.finish(gstep[0] - 1)
                 if band_sharded:
                     wl = wls[0]
                     exp, _ = pyoracle.vardct_render(wl.desc(), abi.STAGE_ALL, job["out_w"], job["out_h"])
@@ -293,11 +329,15 @@ def main():
                 "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                 "higher_is_better": True,
                 "scaling": "strong",
-                "value_includes": ("render + device formatting + gather of the stitched output to rank 0 (overlapped: shard.PipelinedGather)"
+                "value_includes": (("render + device formatting whose stores land in rank 0's HBM through IPC peer mappings over xGMI (shard.PeerWriteGather: "
+                                    "no collective, every rank over its own link)" if gather_mode == "p2p" else
+                                    "render + device formatting + gather of the stitched output to rank 0 (overlapped: shard.PipelinedGather)")
                                    if gather is not None else "render (N = 1: the output is on the one GPU; formatting timed apart as gather_ms)"),
                 "value_render_only": None if value_render_only is None else round(value_render_only, 1),
                 "gather_error": gather_error,
-                "gathered_GB_per_step": None if gather is None else round(gather.bytes_to_dst / max(gstep[0], 1) * passes / 1e9, 3),
+                "gather_mode": gather_mode,
+                "gathered_GB_per_step": None if gather is None else round(
+                    (gather.slot_bytes * gather.slots * (world - 1) if gather_mode == "p2p" else gather.bytes_to_dst / max(gstep[0], 1)) * passes / 1e9, 3),
                 "vs_baseline": None,
                 "dtype": job["dtype"],
                 "data": "synthetic",
@@ -323,6 +363,8 @@ def main():
                 "end_to_end": e2e,
                 "cpu_baseline": cpu,
             }
+        if gather is not None and gather_mode == "p2p":
+            gather.close()   # collective: unmaps on the writers, frees on rank 0
         for f in frames:
             f.free()
         ctx.synchronize()

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 18u
+#define JXLGPU_ABI_VERSION 19u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -327,12 +327,13 @@ int jxlgpu_vardct_render(jxlgpu_ctx* ctx, jxlgpu_frame* frame, uint32_t stages, 
 /* Region (cropped) render: `RenderContext::request_image_region` / `render_frame_cropped`
  * (jxl-render/src/lib.rs:232, jxl-oxide-tests/tests/crop/mod.rs:8-222).  `region` is a rectangle of the
  * frame's OUTPUT (after upsampling), `Region { left, top, width, height }` of jxl-render/src/region.rs:4-10;
- * it is intersected with the frame.  The result is region.width x region.height samples, bit-identical to
- * that rectangle of a whole-frame render: the device transforms only the varblocks the padded colour region
+ * it is intersected with the frame.  The result is the INTERSECTION's width x height samples (what
+ * jxlgpu_frame_result_size reports afterwards; region.width x region.height when the region lies inside the
+ * frame), written at the origin of `out`, bit-identical to that rectangle of a whole-frame render: the device transforms only the varblocks the padded colour region
  * touches (the padding rules of jxl-render/src/util.rs:51-120: upsampling support, EPF / Gabor reach) and
  * runs the filters, upsampling and colour transform on the rectangle.  The LF image (V1-V3) is always
- * whole: it is 1/64 of the frame.  `stages` must include JXLGPU_STAGE_TRANSFORM.  Noise synthesis
- * (seeded per absolute group) with a region is JXLGPU_ERR_UNSUPPORTED.                                */
+ * whole: it is 1/64 of the frame.  `stages` must include JXLGPU_STAGE_TRANSFORM.  A frame with noise
+ * synthesis (seeded per absolute group) is rendered whole and the region cropped from it.               */
 typedef struct {
     int32_t left, top;
     uint32_t width, height;
@@ -448,6 +449,24 @@ int jxlgpu_frame_render_extra(jxlgpu_ctx* ctx, jxlgpu_frame* frame, uint32_t ind
                               float* out, uint32_t out_stride, uint32_t out_mem);
 /* Device plane of extra channel `index` (tight rows) and its size; NULL before jxlgpu_frame_render_extra. */
 const float* jxlgpu_frame_extra_plane(const jxlgpu_frame* frame, uint32_t index, uint32_t* width, uint32_t* height);
+
+/* ---- multi-GPU: the stitched output without a collective (BASELINE configs 4 / 5) ----
+ * One process per GPU.  The rank that owns the stitched output allocates it with jxlgpu_device_alloc and exports
+ * it (jxlgpu_ipc_export); every other rank opens the handle (jxlgpu_ipc_open: a peer mapping over xGMI) and passes
+ * `base + its offset` as the JXLGPU_MEM_DEVICE destination of jxlgpu_frame_format_output (or of a render's
+ * JxlGpuOut): the formatting kernel's stores go straight to the owner's HBM, all ranks at once, each over its own
+ * xGMI link to the owner — no rooted gather, no staging copy, nothing for the host to wait for but the end of its
+ * own stream.  The 64 handle bytes travel by whatever the host program already has (a pipe, MPI, a torch store).
+ * Needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose driver only offers dmabuf IPC.                              */
+#define JXLGPU_IPC_HANDLE_BYTES 64
+int jxlgpu_device_alloc(jxlgpu_ctx* ctx, size_t bytes, void** out);   /* plain device memory (exportable), zero-filled */
+void jxlgpu_device_free(jxlgpu_ctx* ctx, void* p);
+int jxlgpu_ipc_export(jxlgpu_ctx* ctx, void* dev_ptr, uint8_t handle[JXLGPU_IPC_HANDLE_BYTES]);
+int jxlgpu_ipc_open(jxlgpu_ctx* ctx, const uint8_t handle[JXLGPU_IPC_HANDLE_BYTES], void** dev_ptr);
+int jxlgpu_ipc_close(jxlgpu_ctx* ctx, void* dev_ptr);
+/* Device-to-host copy of `bytes` from a device pointer (e.g. the stitched output on its owner), after everything
+ * queued on the ctx's streams: for hosts without another GPU runtime binding.                                   */
+int jxlgpu_device_download(jxlgpu_ctx* ctx, const void* dev_ptr, void* host, size_t bytes);
 
 /* Bytes the algorithm must move per render for the given stages (compulsory HBM traffic:
  * coefficient read + final write + side data), used by bench.py for the roofline.                 */

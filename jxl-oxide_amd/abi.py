@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -216,6 +216,7 @@ class Out(C.Structure):
 
 
 MAX_EXTRA = 8
+IPC_HANDLE_BYTES = 64
 
 
 class FormatDesc(C.Structure):
@@ -317,6 +318,12 @@ _SYMBOLS = [
                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("jxlgpu_frame_render_extra", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(ExtraChannel), C.c_void_p, C.c_uint32, C.c_uint32]),
     ("jxlgpu_frame_extra_plane", f32p, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("jxlgpu_device_alloc", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("jxlgpu_device_free", None, [C.c_void_p, C.c_void_p]),
+    ("jxlgpu_ipc_export", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint8)]),
+    ("jxlgpu_ipc_open", C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_void_p)]),
+    ("jxlgpu_ipc_close", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("jxlgpu_device_download", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     ("jxlgpu_frame_algorithmic_bytes", C.c_uint64, [C.c_void_p, C.c_uint32]),
     ("jxlgpu_modular_upload", C.c_int, [C.c_void_p, C.POINTER(ModularDesc), C.POINTER(C.c_void_p)]),
     ("jxlgpu_modular_inverse", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),

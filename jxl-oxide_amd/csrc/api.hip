@@ -569,6 +569,10 @@ void jxlgpu_destroy(jxlgpu_ctx* ctx) {
         if (sb.p) (void)hipHostFree(sb.p);
         if (sb.ev) (void)hipEventDestroy(sb.ev);
     }
+    for (StageBuf& sb : ctx->rt_stage) {
+        if (sb.p) (void)hipHostFree(sb.p);
+        if (sb.ev) (void)hipEventDestroy(sb.ev);
+    }
     for (hipEvent_t e : ctx->ev_spare) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_h2d) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1850,7 +1854,9 @@ static int vardct_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages,
         if (!clip_region(region_in, fw, fh, &region)) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "the region does not intersect the frame");
         const bool any_filter = ((stages & JXLGPU_STAGE_GABOR) && d.filter.gab_enabled) || ((stages & JXLGPU_STAGE_EPF) && d.filter.epf_iters);
         // cut when every consumer of the transform output can be: the fused filters, or no filters at all
-        cut = f->subs.empty() && (!any_filter || fused_post_supported(ctx, f, true, 2));
+        // (a frame with noise renders whole: the generator is seeded per absolute group; the region is cropped at the end)
+        const bool noisy = (stages & JXLGPU_STAGE_NOISE) && d.noise.enabled;
+        cut = f->subs.empty() && !noisy && (!any_filter || fused_post_supported(ctx, f, true, 2));
     }
     if (!f->subs.empty()) {
         // chroma-subsampled frames (JPEG transcodes): whole frame, the region is cropped from it

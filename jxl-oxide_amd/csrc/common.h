@@ -263,6 +263,8 @@ struct jxlgpu_ctx {
     hipStream_t stream_down = nullptr;  // asynchronous D2H of formatted output (JXLGPU_MEM_HOST_PINNED)
     StageBuf stage[3];
     uint32_t stage_next = 0;
+    StageBuf rt_stage[4];               // region renders: tile lists on their way to the device
+    uint32_t rt_stage_next = 0;
     WorkerPool* workers = nullptr;      // created by the first upload that is worth splitting
     int host_threads = -1;              // JXLGPU_HOST_THREADS (-1: min(8, cores) - 1 workers + the calling thread)
     std::deque<Deferred> deferred;

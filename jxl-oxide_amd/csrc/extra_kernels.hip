@@ -120,3 +120,63 @@ extern "C" const float* jxlgpu_frame_extra_plane(const jxlgpu_frame* f, uint32_t
     if (height) *height = f->extra_h[index];
     return f->extra[index];
 }
+
+// ---- multi-GPU plumbing: exportable device memory and IPC mappings (include/jxlgpu.h "multi-GPU")
+static_assert(sizeof(hipIpcMemHandle_t) <= JXLGPU_IPC_HANDLE_BYTES, "IPC handle larger than the ABI's byte array");
+
+extern "C" int jxlgpu_device_alloc(jxlgpu_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out || !bytes) return JXLGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(out, bytes));
+    HIP_TRY(ctx, hipMemsetAsync(*out, 0, bytes, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return JXLGPU_OK;
+}
+
+extern "C" void jxlgpu_device_free(jxlgpu_ctx* ctx, void* p) {
+    if (!p) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)jxlgpu_synchronize(ctx);
+    }
+    (void)hipFree(p);
+}
+
+extern "C" int jxlgpu_ipc_export(jxlgpu_ctx* ctx, void* dev_ptr, uint8_t handle[JXLGPU_IPC_HANDLE_BYTES]) {
+    if (!ctx || !dev_ptr || !handle) return JXLGPU_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipIpcMemHandle_t h;
+    HIP_TRY(ctx, hipIpcGetMemHandle(&h, dev_ptr));
+    memset(handle, 0, JXLGPU_IPC_HANDLE_BYTES);
+    memcpy(handle, &h, sizeof(h));
+    return JXLGPU_OK;
+}
+
+extern "C" int jxlgpu_ipc_open(jxlgpu_ctx* ctx, const uint8_t handle[JXLGPU_IPC_HANDLE_BYTES], void** dev_ptr) {
+    if (!ctx || !handle || !dev_ptr) return JXLGPU_ERR_INVALID_ARG;
+    *dev_ptr = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    HIP_TRY(ctx, hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return JXLGPU_OK;
+}
+
+extern "C" int jxlgpu_ipc_close(jxlgpu_ctx* ctx, void* dev_ptr) {
+    if (!ctx || !dev_ptr) return JXLGPU_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // stores to the peer must have left before the mapping goes
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_down));
+    HIP_TRY(ctx, hipIpcCloseMemHandle(dev_ptr));
+    return JXLGPU_OK;
+}
+
+extern "C" int jxlgpu_device_download(jxlgpu_ctx* ctx, const void* dev_ptr, void* host, size_t bytes) {
+    if (!ctx || !dev_ptr || !host) return JXLGPU_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = jxlgpu_synchronize(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(host, dev_ptr, bytes, hipMemcpyDeviceToHost));
+    return JXLGPU_OK;
+}

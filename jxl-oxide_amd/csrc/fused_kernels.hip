@@ -562,7 +562,7 @@ bool fused_post_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, bool gab
 // applies (Gabor + 2 EPF steps on a frame with an interior; the ring-tile list is created on first
 // use).  *plain_srgb: the colour tail is the plain XYB -> sRGB list (branch-free epilogue).
 // Region renders: the origins (x0 | y0 << 16) in `tiles` go to scratch slot `slot` of the frame, in
-// stream order (the source is pageable: the runtime stages it before hipMemcpyAsync returns).
+// stream order.
 static hipError_t upload_region_tiles(jxlgpu_ctx* ctx, jxlgpu_frame* f, int slot, const std::vector<uint32_t>& tiles,
                                       const uint32_t** dev) {
     const size_t n = std::max<size_t>(tiles.size(), 1);
@@ -575,8 +575,33 @@ static hipError_t upload_region_tiles(jxlgpu_ctx* ctx, jxlgpu_frame* f, int slot
         f->region_tiles_cap[slot] = n * 2;
     }
     if (!tiles.empty()) {
-        hipError_t e = hipMemcpyAsync(f->region_tiles[slot], tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        // through a pinned staging buffer of the context (a ring of four, each guarded by the event behind its last
+        // copy): the copy is asynchronous for real and stream-ordered — a pageable source would make the runtime
+        // block the host until every earlier kernel on the stream has finished
+        StageBuf& sb = ctx->rt_stage[ctx->rt_stage_next++ % 4];
+        if (sb.busy) {
+            hipError_t e = hipEventSynchronize(sb.ev);
+            if (e != hipSuccess) return e;
+            sb.busy = false;
+        }
+        const size_t bytes = tiles.size() * 4;
+        if (sb.cap < bytes) {
+            if (sb.p) (void)hipHostFree(sb.p);
+            sb.p = nullptr; sb.cap = 0;
+            hipError_t e = hipHostMalloc(&sb.p, std::max<size_t>(bytes * 2, 4096), hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            sb.cap = std::max<size_t>(bytes * 2, 4096);
+        }
+        if (!sb.ev) {
+            hipError_t e = hipEventCreateWithFlags(&sb.ev, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        memcpy(sb.p, tiles.data(), bytes);
+        hipError_t e = hipMemcpyAsync(f->region_tiles[slot], sb.p, bytes, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) return e;
+        e = hipEventRecord(sb.ev, ctx->stream);
+        if (e != hipSuccess) return e;
+        sb.busy = true;
     }
     *dev = f->region_tiles[slot];
     return hipSuccess;

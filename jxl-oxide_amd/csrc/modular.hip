@@ -2755,7 +2755,8 @@ static int modular_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages
         jxlgpu_frame_out_size(f, stages, &fw, &fh);
         if (!clip_region(region_in, fw, fh, &region)) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "the region does not intersect the frame");
         const bool any_filter = ((stages & JXLGPU_STAGE_GABOR) && f->desc.filter.gab_enabled) || ((stages & JXLGPU_STAGE_EPF) && f->desc.filter.epf_iters);
-        cut = !any_filter || fused_post_supported(ctx, f, true, 2);  // the staged filters run on whole planes: crop afterwards
+        const bool noisy = (stages & JXLGPU_STAGE_NOISE) && f->desc.noise.enabled;  // seeded per absolute group: whole frame, then crop
+        cut = !noisy && (!any_filter || fused_post_supported(ctx, f, true, 2));  // the staged filters run on whole planes: crop afterwards
     }
     rc = run_post_stages(ctx, f, stages, f->desc.filter, f->desc.upsampling.factor ? f->desc.upsampling.factor : 1,
                          cur, &stride, &ow, &oh, false, cut ? &region : nullptr);

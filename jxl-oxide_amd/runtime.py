@@ -149,7 +149,9 @@ class Context:
         o.mem = abi.MEM_HOST
         r = abi.Region(left, top, width, height)
         self._check(fn(self.handle, frame.handle, stages, C.byref(r), C.byref(o)))
-        return out
+        # the library clips the region to the frame and writes the intersection at the origin of `out`
+        rw, rh = frame.result_size()
+        return out[:, :rh, :rw]
 
     def vardct_render_region(self, frame, stages, region, to_host=True):
         """`region` = (left, top, width, height) of the output, inside the frame -> planes[3][height, width]."""
@@ -248,6 +250,42 @@ class Context:
         rw, rh = C.c_uint32(), C.c_uint32()
         self._check(self.lib.jxlgpu_frame_format_output(self.handle, frame.handle, C.byref(fmt), out_pinned.ctypes.data,
                                                         abi.MEM_HOST_PINNED, C.byref(rw), C.byref(rh)))
+        return rw.value, rh.value
+
+    # ---- multi-GPU plumbing (no torch involved)
+    def device_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._check(self.lib.jxlgpu_device_alloc(self.handle, nbytes, C.byref(p)))
+        return p.value
+
+    def device_free(self, ptr):
+        self.lib.jxlgpu_device_free(self.handle, ptr)
+
+    def ipc_export(self, ptr):
+        h = (C.c_uint8 * abi.IPC_HANDLE_BYTES)()
+        self._check(self.lib.jxlgpu_ipc_export(self.handle, ptr, h))
+        return bytes(h)
+
+    def ipc_open(self, handle_bytes):
+        h = (C.c_uint8 * abi.IPC_HANDLE_BYTES)(*handle_bytes)
+        p = C.c_void_p()
+        self._check(self.lib.jxlgpu_ipc_open(self.handle, h, C.byref(p)))
+        return p.value
+
+    def ipc_close(self, ptr):
+        self._check(self.lib.jxlgpu_ipc_close(self.handle, ptr))
+
+    def device_download(self, ptr, shape, dtype):
+        out = np.zeros(shape, dtype=dtype)
+        self._check(self.lib.jxlgpu_device_download(self.handle, ptr, out.ctypes.data, out.nbytes))
+        return out
+
+    def format_output_to(self, frame, sample_format, dev_ptr, orientation=1):
+        """format_output with a device destination (own memory or a peer mapping from ipc_open); asynchronous."""
+        fmt = abi.FormatDesc(sample_format, orientation)
+        rw, rh = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.jxlgpu_frame_format_output(self.handle, frame.handle, C.byref(fmt), dev_ptr, abi.MEM_DEVICE,
+                                                        C.byref(rw), C.byref(rh)))
         return rw.value, rh.value
 
     def frame_wait(self, frame):

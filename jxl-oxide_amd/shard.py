@@ -201,11 +201,14 @@ class PipelinedGather:
         self.multi = dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective)
         self.rank = dist.get_rank(group) if self.multi else 0
         self.world = dist.get_world_size(group) if self.multi else 1
+        # `dst` is a GLOBAL rank (what dist.gather takes); with a sub-group the group rank differs from it
+        self.global_rank = dist.get_rank() if self.multi else 0
+        self.is_dst = (self.global_rank == dst) if self.multi else True
         self.depth = depth
         self.cuda = torch.device(device).type == "cuda"
         self.local = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
         self.recv = [None] * depth
-        if self.multi and self.rank == dst:
+        if self.multi and self.is_dst:
             self.recv = [[torch.zeros(shape, dtype=dtype, device=device) for _ in range(self.world)] for _ in range(depth)]
         self.ext = torch.cuda.ExternalStream(lib_stream) if (self.cuda and lib_stream) else None
         self.done = [None] * depth   # event behind the gather that last read local[i]
@@ -216,6 +219,10 @@ class PipelinedGather:
         i = step % self.depth
         if self.done[i] is not None and self.ext is not None:
             self.ext.wait_event(self.done[i])      # the formatting kernels queue behind the gather that read this buffer
+        elif self.done[i] is not None:
+            # no library stream to order behind: the host waits for the gather that last read this buffer, or the next
+            # formatting (on a stream torch knows nothing about) would overwrite it mid-flight
+            self.done[i].synchronize()
         elif self.work[i] is not None and not self.cuda:
             self.work[i].wait()
         return self.local[i]
@@ -229,7 +236,7 @@ class PipelinedGather:
             ev = torch.cuda.Event()
             ev.record(self.ext)
             torch.cuda.current_stream().wait_event(ev)
-        w = dist.gather(self.local[i], self.recv[i] if self.rank == self.dst else None, dst=self.dst, group=self.group,
+        w = dist.gather(self.local[i], self.recv[i] if self.is_dst else None, dst=self.dst, group=self.group,
                         async_op=True)
         self.work[i] = w
         if self.cuda:
@@ -239,7 +246,7 @@ class PipelinedGather:
             self.done[i] = d
         else:
             w.wait()
-        if self.rank == self.dst:
+        if self.is_dst:
             self.bytes_to_dst += (self.world - 1) * self.local[i].numel() * self.local[i].element_size()
 
     def finish(self, step=None):
@@ -249,6 +256,70 @@ class PipelinedGather:
         if step is None or not self.multi:
             return [self.local[(step or 0) % self.depth]] if step is not None else None
         i = step % self.depth
-        if self.rank != self.dst:
+        if not self.is_dst:
             return None
         return self.recv[i]
+
+
+class PeerWriteGather:
+    """The stitched output WITHOUT a collective: rank `dst` owns world x slots x slot_bytes of
+    its HBM (jxlgpu_device_alloc) and exports it; every other rank maps it (jxlgpu_ipc_open: a peer mapping over
+    xGMI) and its formatting kernels store straight into its own slots there — all ranks at once, each over its own
+    link to `dst`, where a rooted `dist.gather` funnels one ring through rank 0's receive path.  The host never
+    waits inside a step; a step is complete on `dst` after every rank's stream has drained (finish()).  Only the 64
+    handle bytes and the barriers go through torch.distributed (any backend: gloo is enough)."""
+
+    def __init__(self, ctx, slot_bytes, slots, dst=0, group=None):
+        import torch.distributed as dist
+        self.dist, self.ctx, self.group, self.dst = dist, ctx, group, dst
+        self.multi = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.rank = dist.get_rank(group) if self.multi else 0
+        self.world = dist.get_world_size(group) if self.multi else 1
+        self.global_rank = dist.get_rank() if self.multi else 0
+        self.is_dst = (self.global_rank == dst) if self.multi else True
+        self.slot_bytes, self.slots = int(slot_bytes), int(slots)
+        self.bytes_to_dst = 0
+        self.base = None
+        self.owned = False
+        obj = [None]
+        if self.is_dst:
+            self.base = ctx.device_alloc(self.world * self.slots * self.slot_bytes)
+            self.owned = True
+            obj = [ctx.ipc_export(self.base)] if self.multi else [None]
+        if self.multi:
+            dist.broadcast_object_list(obj, src=dst, group=group)
+            if not self.is_dst:
+                self.base = ctx.ipc_open(obj[0])
+        self.mine = self.base + self.rank * self.slots * self.slot_bytes
+
+    def write(self, frames, sample_format, orientation=1, first_slot=0):
+        """Formats the last render of every frame into this rank's slots first_slot, ... in dst's buffer (asynchronous)."""
+        assert first_slot + len(frames) <= self.slots
+        for i, f in enumerate(frames):
+            self.ctx.format_output_to(f, sample_format, self.mine + (first_slot + i) * self.slot_bytes, orientation)
+        if not self.is_dst:
+            self.bytes_to_dst += len(frames) * self.slot_bytes
+
+    def finish(self):
+        """Every rank's stores have landed on dst when this returns on all ranks."""
+        self.ctx.synchronize()
+        if self.multi:
+            self.dist.barrier(group=self.group)
+
+    def result(self):
+        """On dst: the stitched bytes as a (world, slots, slot_bytes) uint8 array (host copy); None elsewhere."""
+        import numpy as np
+        if not self.is_dst:
+            return None
+        return self.ctx.device_download(self.base, (self.world, self.slots, self.slot_bytes), np.uint8)
+
+    def close(self):
+        if self.base is None:
+            return
+        if self.multi and not self.is_dst:
+            self.ctx.ipc_close(self.base)
+        if self.multi:
+            self.dist.barrier(group=self.group)   # nobody maps the buffer any more
+        if self.owned:
+            self.ctx.device_free(self.base)
+        self.base = None

@@ -108,13 +108,17 @@ def test_region_clipping_and_errors(gpu_ctx):
         assert e.value.code == abi.ERR_INVALID_ARG
     finally:
         frame.free()
-    # noise is seeded per absolute group: refused with a region
+    # noise is seeded per absolute group: the frame renders whole and the region is cropped from it
     wl = VardctWorkload(264, 200, seed=4, noise=True)
     frame = gpu_ctx.vardct_upload(wl.desc())
     try:
-        with pytest.raises(Exception) as e:
-            gpu_ctx.vardct_render_region(frame, S_ALL, (10, 10, 50, 50))
-        assert e.value.code == abi.ERR_UNSUPPORTED
+        full = gpu_ctx.vardct_render(frame, S_ALL)
+        got = gpu_ctx.vardct_render_region(frame, S_ALL, (10, 10, 50, 50))
+        assert np.array_equal(got.view(np.uint32), full[:, 10:60, 10:60].view(np.uint32))
+        # a region that overhangs the frame comes back at the intersection's size
+        got = gpu_ctx.vardct_render_region(frame, S_ALL, (230, 180, 100, 100))
+        assert got.shape == (3, 20, 34)
+        assert np.array_equal(got.view(np.uint32), full[:, 180:200, 230:264].view(np.uint32))
     finally:
         frame.free()
 
