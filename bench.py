@@ -95,10 +95,18 @@ def main():
     if rank == 0:
         canary = runtime.gpu_canary(quiet=True)  # pure-HIP program first: a faulting box shows up here, by name
         print(f"CANARY {canary}", file=sys.stderr, flush=True)
+    # test hook (one-GPU boxes): JXLGPU_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 with gloo as the control backend, so
+    # that the N > 1 code path (sharding, peer-write gather, verification) can be exercised without a second GPU
+    one_device = bool(os.environ.get("JXLGPU_BENCH_ONE_DEVICE"))
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = runtime.Context(local_rank)
 
     def run_density(nz):
@@ -201,7 +209,7 @@ def main():
         prof_ms, prof_n = ctx.profile_read()
         ctx.profile_select(-1)
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         value = n_total * passes * args.steps * mp_per_frame / elapsed
@@ -214,7 +222,7 @@ def main():
                 step(with_gather=False)
             barrier()
             e2 = time.perf_counter() - t0
-            t = torch.tensor([e2], dtype=torch.float64, device="cuda")
+            t = torch.tensor([e2], dtype=torch.float64, device="cpu" if one_device else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             value_render_only = n_total * passes * args.steps * mp_per_frame / float(t.item())
 
@@ -230,7 +238,7 @@ def main():
             barrier()
             gather_s = (time.perf_counter() - t0) / reps
             if world > 1:
-                t = torch.tensor([gather_s], dtype=torch.float64, device="cuda")
+                t = torch.tensor([gather_s], dtype=torch.float64, device="cpu" if one_device else "cuda")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 gather_s = float(t.item())
             gather_ms = gather_s * 1e3

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 19u
+#define JXLGPU_ABI_VERSION 20u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -296,6 +296,13 @@ int jxlgpu_frame_wait(jxlgpu_ctx* ctx, jxlgpu_frame* frame);
  * the caller wants the copy off its thread.  Free with jxlgpu_host_free.                                      */
 int jxlgpu_host_alloc(jxlgpu_ctx* ctx, size_t bytes, void** out);
 void jxlgpu_host_free(jxlgpu_ctx* ctx, void* p);
+/* Memory budget (the reference's `AllocTracker`, jxl-grid/src/alloc_tracker.rs:17-75: every grid allocation is charged
+ * to a byte budget and fails with OutOfMemory beyond it).  `limit_bytes` bounds the device memory the ctx's FRAMES may
+ * hold at one time (live buffers; recycled buffers waiting in the ctx's pool are given back first and do not count);
+ * an upload or render that would exceed it fails with JXLGPU_ERR_OOM and leaves the ctx usable.  0 = no limit (the
+ * default).  jxlgpu_memory_usage reports the bytes held by live frames and by the pool.                            */
+int jxlgpu_set_memory_limit(jxlgpu_ctx* ctx, uint64_t limit_bytes);
+int jxlgpu_memory_usage(const jxlgpu_ctx* ctx, uint64_t* live_bytes, uint64_t* pooled_bytes);
 /* Measurement hook: where the host time of the ctx's last jxlgpu_vardct_upload went, in milliseconds —
  * ms[0] work-list / side-plane build (worker threads), ms[1] reserved (0), ms[2] device allocations + enqueueing
  * the copies, ms[3] the whole call, ms[4] the arena's H2D copy on the device (HIP events; waits for it).      */

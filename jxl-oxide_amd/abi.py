@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -301,6 +301,8 @@ _SYMBOLS = [
     ("jxlgpu_host_alloc", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("jxlgpu_host_free", None, [C.c_void_p, C.c_void_p]),
     ("jxlgpu_upload_split", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    ("jxlgpu_set_memory_limit", C.c_int, [C.c_void_p, C.c_uint64]),
+    ("jxlgpu_memory_usage", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("jxlgpu_profile_select", C.c_int, [C.c_void_p, C.c_int]),
     ("jxlgpu_profile_read", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("jxlgpu_vardct_upload", C.c_int, [C.c_void_p, C.POINTER(VardctDesc), C.POINTER(C.c_void_p)]),

@@ -89,13 +89,22 @@ static void guard_free(jxlgpu_ctx* ctx, void* p) {
 
 hipError_t ctx_dev_malloc(jxlgpu_ctx* ctx, void** out, size_t bytes) {
     bytes = std::max<size_t>(bytes, 16);
-    if (ctx->guard_mode) return guard_malloc(ctx, out, bytes);
+    if (ctx->mem_limit && ctx->live_bytes + bytes > ctx->mem_limit) {
+        ctx_reap(ctx, true);  // frames being freed may still hold part of the budget
+        if (ctx->live_bytes + bytes > ctx->mem_limit) return hipErrorOutOfMemory;   // AllocTracker::alloc -> OutOfMemory
+    }
+    if (ctx->guard_mode) {
+        hipError_t e = guard_malloc(ctx, out, bytes);
+        if (e == hipSuccess) { ctx->live[*out] = bytes; ctx->live_bytes += bytes; }
+        return e;
+    }
     auto it = ctx->pool.find(bytes);
     if (it != ctx->pool.end()) {
         *out = it->second;
         ctx->pool.erase(it);
         ctx->pool_bytes -= bytes;
         ctx->live[*out] = bytes;
+        ctx->live_bytes += bytes;
         return hipSuccess;
     }
     hipError_t e = hipMalloc(out, bytes);
@@ -107,18 +116,23 @@ hipError_t ctx_dev_malloc(jxlgpu_ctx* ctx, void** out, size_t bytes) {
         ctx->pool_bytes = 0;
         e = hipMalloc(out, bytes);
     }
-    if (e == hipSuccess) ctx->live[*out] = bytes;
+    if (e == hipSuccess) { ctx->live[*out] = bytes; ctx->live_bytes += bytes; }
     return e;
 }
 
 // The caller guarantees that no queued work still touches `p` (frame_free synchronises first).
 void ctx_dev_release(jxlgpu_ctx* ctx, void* p) {
     if (!p) return;
-    if (ctx->guard_mode) { guard_free(ctx, p); return; }
     auto it = ctx->live.find(p);
+    if (ctx->guard_mode) {
+        if (it != ctx->live.end()) { ctx->live_bytes -= it->second; ctx->live.erase(it); }
+        guard_free(ctx, p);
+        return;
+    }
     if (it == ctx->live.end()) { (void)hipFree(p); return; }
     const size_t bytes = it->second;
     ctx->live.erase(it);
+    ctx->live_bytes -= bytes;
     if (ctx->pool_bytes + bytes <= ctx->pool_cap) {
         ctx->pool.emplace(bytes, p);
         ctx->pool_bytes += bytes;
@@ -629,6 +643,19 @@ void jxlgpu_host_free(jxlgpu_ctx* ctx, void* p) {
     if (!p) return;
     if (ctx) (void)hipSetDevice(ctx->device);
     (void)hipHostFree(p);
+}
+
+int jxlgpu_set_memory_limit(jxlgpu_ctx* ctx, uint64_t limit_bytes) {
+    if (!ctx) return JXLGPU_ERR_INVALID_ARG;
+    ctx->mem_limit = (size_t)limit_bytes;
+    return JXLGPU_OK;
+}
+
+int jxlgpu_memory_usage(const jxlgpu_ctx* ctx, uint64_t* live_bytes, uint64_t* pooled_bytes) {
+    if (!ctx) return JXLGPU_ERR_INVALID_ARG;
+    if (live_bytes) *live_bytes = ctx->live_bytes;
+    if (pooled_bytes) *pooled_bytes = ctx->pool_bytes;
+    return JXLGPU_OK;
 }
 
 int jxlgpu_upload_split(jxlgpu_ctx* ctx, double ms[5]) {

@@ -282,6 +282,7 @@ struct jxlgpu_ctx {
     std::unordered_map<void*, size_t> live;
     std::multimap<size_t, void*> pool;
     size_t pool_bytes = 0, pool_cap = (size_t)8 << 30;
+    size_t live_bytes = 0, mem_limit = 0;   // jxlgpu_set_memory_limit: bound on live_bytes (0: none)
     int guard_mode = 0;         // JXLGPU_GUARD: 1 = buffers end at an unmapped page, 2 = start after one
     size_t guard_gran = 0;
     int guard_seq = 0, guard_zero = -1;   // JXLGPU_GUARD_ZERO=k|all: allocation #k (all) is zero-filled instead of poisoned

@@ -252,6 +252,14 @@ class Context:
                                                         abi.MEM_HOST_PINNED, C.byref(rw), C.byref(rh)))
         return rw.value, rh.value
 
+    def set_memory_limit(self, nbytes):
+        self._check(self.lib.jxlgpu_set_memory_limit(self.handle, int(nbytes)))
+
+    def memory_usage(self):
+        live, pooled = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.jxlgpu_memory_usage(self.handle, C.byref(live), C.byref(pooled)))
+        return live.value, pooled.value
+
     # ---- multi-GPU plumbing (no torch involved)
     def device_alloc(self, nbytes):
         p = C.c_void_p()

@@ -1,0 +1,76 @@
+"""The memory budget hook (jxlgpu_set_memory_limit / jxlgpu_memory_usage): the reference charges every grid to an
+`AllocTracker` (jxl-grid/src/alloc_tracker.rs:17-75) and fails with OutOfMemory beyond the budget; so does a context —
+with JXLGPU_ERR_OOM, and it stays usable.  Also: jxlgpu_frame_free never blocks, its memory comes back once the queued
+work has finished."""
+import numpy as np
+import pytest
+
+from jxl_oxide_amd import abi, runtime
+from jxl_oxide_amd.synth import VardctWorkload
+
+pytestmark = pytest.mark.gpu
+
+
+def test_memory_limit_and_usage(oracle):
+    ctx = runtime.Context(0)
+    try:
+        wl = VardctWorkload(264, 200, seed=9)
+        exp, _ = oracle.vardct_render(wl.desc(), abi.STAGE_ALL, 264, 200)
+        assert ctx.memory_usage() == (0, 0)
+        ctx.set_memory_limit(1 << 20)          # a 264 x 200 frame needs ~ 5 MB of device buffers
+        with pytest.raises(runtime.JxlGpuError) as e:
+            ctx.vardct_upload(wl.desc())
+        assert e.value.code == abi.ERR_OOM
+        ctx.synchronize()
+        assert ctx.memory_usage()[0] == 0       # nothing of the failed upload stays charged
+        ctx.set_memory_limit(64 << 20)
+        f = ctx.vardct_upload(wl.desc(coeff_transport="grouped"))
+        live, _ = ctx.memory_usage()
+        assert 1 << 20 < live < 64 << 20
+        got = ctx.vardct_render(f, abi.STAGE_ALL)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+        f.free()
+        ctx.synchronize()
+        live2, pooled = ctx.memory_usage()
+        assert live2 == 0 and pooled >= live      # recycled, not held by a frame
+        # the pool does not count against the budget: the same frame fits again
+        f = ctx.vardct_upload(wl.desc(coeff_transport="grouped"))
+        f.free()
+        ctx.set_memory_limit(0)
+    finally:
+        ctx.close()
+
+
+def test_frame_free_does_not_wait_for_the_device(oracle):
+    """Upload / render / free in a loop without ever synchronising: results stay right, and the pool hands the
+    buffers of retired frames to later uploads (bounded memory)."""
+    ctx = runtime.Context(0)
+    try:
+        wl = VardctWorkload(520, 264, seed=10)
+        d = wl.desc(coeff_transport="grouped")
+        exp, _ = oracle.vardct_render(wl.desc(), abi.STAGE_ALL, 520, 264)
+        exp8 = oracle.format_output(exp, abi.FMT_U8, 1)
+        outs = [ctx.host_alloc((264, 520, 3), np.uint8) for _ in range(3)]
+        inflight = []
+        for k in range(24):
+            f = ctx.vardct_upload(d)
+            ctx.vardct_render(f, abi.STAGE_ALL, to_host=False)
+            ctx.format_output_async(f, abi.FMT_U8, outs[k % 3])
+            inflight.append((f, k % 3))
+            if len(inflight) == 3:
+                g, slot = inflight.pop(0)
+                ctx.frame_wait(g)
+                assert np.array_equal(outs[slot], exp8), k
+                g.free()
+        for g, slot in inflight:
+            ctx.frame_wait(g)
+            assert np.array_equal(outs[slot], exp8)
+            g.free()
+        ctx.synchronize()
+        live, pooled = ctx.memory_usage()
+        assert live == 0
+        assert pooled < 8 * (6 << 20) * 4      # a handful of frames' worth, not 24
+        for o in outs:
+            ctx.host_free(o)
+    finally:
+        ctx.close()
