@@ -478,6 +478,18 @@ extern "C" {
 
 uint32_t jxlgpu_abi_version(void) { return JXLGPU_ABI_VERSION; }
 
+// The transform stream of batched renders: lowest priority when JXLGPU_STREAM_PRIO is set (the post launches on the
+// render stream then get the wave slots first, the latency-bound transform launches fill what is left).
+static hipError_t create_tr_stream(jxlgpu_ctx* ctx) {
+    const char* v = getenv("JXLGPU_STREAM_PRIO");
+    if (v && atoi(v) != 0) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            return hipStreamCreateWithPriority(&ctx->stream_tr, hipStreamNonBlocking, atoi(v) > 0 ? lo : hi);
+    }
+    return hipStreamCreateWithFlags(&ctx->stream_tr, hipStreamNonBlocking);
+}
+
 int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     if (!out_ctx) return JXLGPU_ERR_INVALID_ARG;
     *out_ctx = nullptr;
@@ -544,7 +556,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream_tr, hipStreamNonBlocking) != hipSuccess ||
+        create_tr_stream(ctx) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_down, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||

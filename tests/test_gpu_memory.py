@@ -32,7 +32,9 @@ def test_memory_limit_and_usage(oracle):
         f.free()
         ctx.synchronize()
         live2, pooled = ctx.memory_usage()
-        assert live2 == 0 and pooled >= live      # recycled, not held by a frame
+        import os
+        guarded = bool(os.environ.get("JXLGPU_GUARD"))   # the guard allocator unmaps instead of pooling
+        assert live2 == 0 and (pooled >= live or guarded)      # recycled, not held by a frame
         # the pool does not count against the budget: the same frame fits again
         f = ctx.vardct_upload(wl.desc(coeff_transport="grouped"))
         f.free()
@@ -47,9 +49,9 @@ def test_frame_free_does_not_wait_for_the_device(oracle):
     ctx = runtime.Context(0)
     try:
         wl = VardctWorkload(520, 264, seed=10)
-        d = wl.desc(coeff_transport="grouped")
         exp, _ = oracle.vardct_render(wl.desc(), abi.STAGE_ALL, 520, 264)
         exp8 = oracle.format_output(exp, abi.FMT_U8, 1)
+        d = wl.desc(coeff_transport="grouped")   # (a workload keeps the arrays of its LAST descriptor alive)
         outs = [ctx.host_alloc((264, 520, 3), np.uint8) for _ in range(3)]
         inflight = []
         for k in range(24):
