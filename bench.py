@@ -61,7 +61,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5))
     ap.add_argument("--frames", type=int, default=None, help="frames in the whole job (default 64; 8 for configs 3 / 5)")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames in the job (block maps, coefficients, LF)")
+    ap.add_argument("--distinct", type=int, default=None, help="distinct synthetic frames in the job (block maps, coefficients, LF): "
+                    "default 8 for the headline config, 2 for configs 3 / 5 (their oracle check renders 8K frames on the CPU)")
     ap.add_argument("--nz", default="0.15", help="VarDCT configs: fraction of the coefficients that are non-zero after quantisation "
                     "(SURVEY 8(d): 0.15); a comma list runs the whole measurement once per value, one JSON line each")
     ap.add_argument("--verify-frames", type=int, default=2, help="distinct frames checked against the oracle after the timed region")
@@ -78,6 +79,8 @@ def main():
                          "mapping cannot be made); rccl: overlapped dist.gather (shard.PipelinedGather); none: the output stays sharded")
     args = ap.parse_args()
 
+    if args.distinct is None:
+        args.distinct = 8 if args.config == 2 else 2
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -261,7 +264,36 @@ def main():
                 "group_ms_per_frame": {job["group_names"][g].split(":")[0]: round(group_ms[g] / max(len(frames) * passes, 1), 4) for g in group_ms},
                 "pipeline_algorithmic_frac": round(job["alg_bytes"](f0, None) * n_total * passes * args.steps / elapsed / 1e9 / world / HBM_PEAK_GBS, 4),
                 "traffic_ratio": None if not traffic else round(traffic / (alg_frame * frames_per_launch), 3),
+                "concurrency": ("the batched launches of this group run while the V1-V8 launches of the next 16-frame chunk occupy part of "
+                                "the CUs (separate streams): avg_launch_ms is the duration under that sharing; roofline_isolated has the "
+                                "kernel alone") if (job["batched"] and not os.environ.get("JXLGPU_NO_BATCH_OVERLAP")) else None,
             }
+            # The timed region runs V1-V8 of chunk k+1 beside the post launch of chunk k (two streams): the bracket above is
+            # the kernel's duration WHILE IT SHARES THE CUs.  The same kernel alone (a second context without the overlap,
+            # 32 frames per launch as in rounds 2-3), bracketed the same way, for comparison with earlier rounds:
+            roofline_isolated = None
+            if args.config == 2 and job["batched"] and not args.no_extras:
+                os.environ["JXLGPU_NO_BATCH_OVERLAP"] = "1"
+                ctx2 = runtime.Context(local_rank)
+                del os.environ["JXLGPU_NO_BATCH_OVERLAP"]
+                fr2 = [job["upload"](ctx2, wls[mine[i % len(mine)] % args.distinct]) for i in range(32)]
+                for _ in range(2):
+                    job["render"](ctx2, fr2)
+                ctx2.synchronize()
+                ctx2.profile_select(dominant)
+                for _ in range(6):
+                    job["render"](ctx2, fr2)
+                ms2, n2 = ctx2.profile_read()
+                ctx2.profile_select(-1)
+                for f in fr2:
+                    f.free()
+                ctx2.close()
+                if n2 and ms2 > 0:
+                    a2 = alg_frame * 32 / (ms2 / n2 * 1e-3) / 1e9
+                    roofline_isolated = {"achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a2 / HBM_PEAK_GBS, 4),
+                                         "avg_launch_ms": round(ms2 / n2, 4), "frames_per_launch": 32,
+                                         "what": "the dominant kernel group with JXLGPU_NO_BATCH_OVERLAP=1 (one stream, stage after stage): "
+                                                 "nothing else on the CUs while it runs; NOT how the timed region ran"}
             roofline_valu = None
             if args.config == 2 and dominant == 2:
                 # the streaming kernel's region and segmentation, as fused_prepare() lays them out
@@ -363,6 +395,7 @@ def main():
                     "launches": "jxlgpu_vardct_render_batch: one launch per stage for <= 32 frames" if job["batched"] else "one frame at a time",
                 },
                 "roofline": roofline,
+                "roofline_isolated": roofline_isolated,
                 "roofline_valu": roofline_valu,
                 "verified": verified,
                 "gather_ms": None if gather_ms is None else round(gather_ms, 3),
@@ -395,9 +428,9 @@ def make_job(config, distinct, transport="grouped", nz=0.15):
 
     def pmc_traffic(pattern_names):
         def fn(dominant, frames_per_launch):
-            src = os.path.join("profiles", "r03_pmc_hbm_traffic.json")
+            src = os.path.join("profiles", "r04_pmc_hbm_traffic.json")
             if not os.path.exists(os.path.join(ROOT, src)):
-                src = os.path.join("profiles", "r02_pmc_hbm_traffic.json")
+                src = os.path.join("profiles", "r03_pmc_hbm_traffic.json")
             try:
                 pmc = json.load(open(os.path.join(ROOT, src)))
                 kb = 0.0

@@ -28,12 +28,14 @@ def main():
     root, frames = sys.argv[1], int(sys.argv[2])
     fetch = mean_per_kernel(os.path.join(root, "fetch"), "FETCH_SIZE")
     write = mean_per_kernel(os.path.join(root, "write"), "WRITE_SIZE")
-    pf = mean_per_kernel(os.path.join(root, "probe_fetch"), "FETCH_SIZE")
+    pf = mean_per_kernel(os.path.join(root, "probe_fetch"), "FETCH_SIZE")   # optional: the calibration passes
     pw = mean_per_kernel(os.path.join(root, "probe_write"), "WRITE_SIZE")
     plane_mb = 3840 * 2176 * 12 / 1e6
     calib = {k: {"bytes_read_MB": round(plane_mb, 2), "FETCH_SIZE_MB": round(pf[k] * 1024 / 1e6, 2),
                  "bytes_written_MB": round(plane_mb, 2), "WRITE_SIZE_MB": round(pw[k] * 1024 / 1e6, 2)}
-             for k in ("copy16", "walk_rowmajor", "walk_tiled") if k in pf}
+             for k in ("copy16", "walk_rowmajor", "walk_tiled") if k in pf and k in pw}
+    if not calib:
+        calib = "not repeated in this session: see profiles/r03_pmc_hbm_traffic.json (same image, same counters)"
     out = {"units": "FETCH_SIZE / WRITE_SIZE are KB per dispatch (mean); MB = 1e6 bytes",
            "correction": "HBM bytes = 2 x FETCH_SIZE + 1 x WRITE_SIZE (calibration below: a 100.27 MB copy reports FETCH 50.1 MB, WRITE 100.3 MB, for 16 B/lane and for 4 B/lane loads alike)",
            "calibration_on_tools_mem_probe": calib, "frames_per_dispatch": frames, "kernels": {}}
