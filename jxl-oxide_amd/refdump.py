@@ -21,6 +21,8 @@ Layout of a dump directory (all arrays .npy, C order):
   stage_transform_{x,y,b}.npy    f32 [height, width]: after "Dequant and transform" (:375)
   stage_filters_{x,y,b}.npy      f32: after apply_gabor_like / apply_epf (render.rs:131)
   stage_out_{0,1,2}.npy          f32 [out_h, out_w]: after upsampling + colour transform (lib.rs:998)
+  ec{i}_int.npy / ec{i}_out.npy  extra channel i: the integer grid before convert_to_float_modular and the f32 grid after
+                                 features::upsample (image.rs:487-557); meta.json["extra_channels"][i] has its bit depth and shift
 Stage files are optional: whatever is present is compared.
 """
 import ctypes as C
@@ -67,6 +69,24 @@ def _dict_to_struct(d, s):
         else:
             setattr(s, name, v)
     return s
+
+
+def save_extra_channel(path, index, ec, data, oracle=None):
+    """Adds extra channel `index` (an abi.ExtraChannel and its integer plane) to a dump directory; with `oracle` also
+    the f32 plane the reference would produce from it."""
+    m = json.load(open(os.path.join(path, "meta.json")))
+    ecs = m.setdefault("extra_channels", {})
+    ecs[str(index)] = {"bit_depth": int(ec.bit_depth), "float_sample": int(ec.float_sample), "exp_bits": int(ec.exp_bits),
+                       "upsampling_log2": int(ec.upsampling_log2)}
+    json.dump(m, open(os.path.join(path, "meta.json"), "w"), indent=1)
+    np.save(os.path.join(path, f"ec{index}_int.npy"), data)
+    up = [os.path.join(path, f"up{n}_weight.npy") for n in (2, 4, 8)]
+    if not all(os.path.exists(f) for f in up):
+        from .synth import _load_up_weights
+        for f, w in zip(up, _load_up_weights()):
+            np.save(f, w)
+    if oracle is not None:
+        np.save(os.path.join(path, f"ec{index}_out.npy"), oracle.extra_channel(ec))
 
 
 def save(wl, path, oracle=None):
@@ -156,6 +176,30 @@ class Dump:
         if not all(os.path.exists(f) for f in files):
             return None
         return np.stack([np.load(f).astype(np.float32, copy=False) for f in files])
+
+    def extra_channels(self):
+        """[(index, abi.ExtraChannel, expected f32 plane or None)] for every ec{i}_int.npy of the directory."""
+        out = []
+        for key, em in sorted(self.meta.get("extra_channels", {}).items()):
+            i = int(key)
+            data = np.load(os.path.join(self.path, f"ec{i}_int.npy"))
+            if data.dtype not in (np.int16, np.int32):
+                data = data.astype(np.int32)
+            data = np.ascontiguousarray(data)
+            self._keep.append(data)
+            ec = abi.ExtraChannel()
+            ec.data = data.ctypes.data
+            ec.height, ec.width = data.shape
+            ec.sample_type = abi.SAMPLE_I16 if data.dtype == np.int16 else abi.SAMPLE_I32
+            ec.bit_depth, ec.float_sample, ec.exp_bits = em["bit_depth"], em["float_sample"], em["exp_bits"]
+            ec.upsampling_log2 = em["upsampling_log2"]
+            for k, n in enumerate((2, 4, 8)):
+                f = os.path.join(self.path, f"up{n}_weight.npy")
+                if os.path.exists(f):
+                    setattr(ec.weights, f"up{n}_weight", self._load(f"up{n}_weight.npy", np.float32).ctypes.data_as(abi.f32p))
+            exp = os.path.join(self.path, f"ec{i}_out.npy")
+            out.append((i, ec, np.load(exp).astype(np.float32, copy=False) if os.path.exists(exp) else None))
+        return out
 
     def desc(self):
         m = self.meta

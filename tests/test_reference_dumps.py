@@ -29,6 +29,13 @@ def _dump_dirs(tmp_path_factory, oracle):
     for i, kw in enumerate((dict(), dict(epf_iters=3, upsampling=2, hdr_pq=True, intensity_target=4000.0))):
         p = str(tmp_path_factory.mktemp(f"selfdump{i}"))
         refdump.save(VardctWorkload(264, 200, seed=40 + i, **kw), p, oracle)
+        if i == 0:   # an RGBA image: alpha at half resolution, and a 16-bit float depth channel at full resolution
+            from jxl_oxide_amd.synth import make_extra_channel
+            for idx, ekw in ((0, dict(w=132, h=100, bit_depth=8, upsampling_log2=1)),
+                             (1, dict(w=264, h=200, bit_depth=16, float_sample=True, exp_bits=5))):
+                e = dict(ekw)
+                ec, keep = make_extra_channel(e.pop("w"), e.pop("h"), seed=idx, **e)
+                refdump.save_extra_channel(p, idx, ec, keep[0], oracle)
         dirs.append(p)
     return dirs
 
@@ -58,6 +65,17 @@ def test_oracle_matches_every_dumped_stage(oracle, dumps):
             assert_ulp(_render(oracle, dump, d, name), ref, MAX_ULP, f"{dump.path}: oracle vs dumped stage '{name}'")
             checked += 1
         assert checked, f"{dump.path}: no stage files"
+
+
+def test_oracle_matches_every_dumped_extra_channel(oracle, dumps):
+    seen = 0
+    for dump in dumps:
+        for i, ec, exp in dump.extra_channels():
+            if exp is None:
+                continue
+            assert_ulp(oracle.extra_channel(ec)[None], exp[None], MAX_ULP, f"{dump.path}: oracle vs dumped extra channel {i}")
+            seen += 1
+    assert seen >= 2   # the self-made RGBA dump
 
 
 def test_loaded_descriptor_equals_the_one_it_was_saved_from(oracle, tmp_path):
