@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 20u
+#define JXLGPU_ABI_VERSION 21u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -474,6 +474,9 @@ int jxlgpu_ipc_close(jxlgpu_ctx* ctx, void* dev_ptr);
 /* Device-to-host copy of `bytes` from a device pointer (e.g. the stitched output on its owner), after everything
  * queued on the ctx's streams: for hosts without another GPU runtime binding.                                   */
 int jxlgpu_device_download(jxlgpu_ctx* ctx, const void* dev_ptr, void* host, size_t bytes);
+/* Host-to-device copy into a device pointer (own memory or a peer mapping), blocking: e.g. a probe pattern written
+ * through a fresh jxlgpu_ipc_open mapping before kernels are allowed to store through it.                        */
+int jxlgpu_device_upload(jxlgpu_ctx* ctx, void* dev_ptr, const void* host, size_t bytes);
 
 /* Bytes the algorithm must move per render for the given stages (compulsory HBM traffic:
  * coefficient read + final write + side data), used by bench.py for the roofline.                 */

@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -326,6 +326,7 @@ _SYMBOLS = [
     ("jxlgpu_ipc_open", C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_void_p)]),
     ("jxlgpu_ipc_close", C.c_int, [C.c_void_p, C.c_void_p]),
     ("jxlgpu_device_download", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("jxlgpu_device_upload", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     ("jxlgpu_frame_algorithmic_bytes", C.c_uint64, [C.c_void_p, C.c_uint32]),
     ("jxlgpu_modular_upload", C.c_int, [C.c_void_p, C.POINTER(ModularDesc), C.POINTER(C.c_void_p)]),
     ("jxlgpu_modular_inverse", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -180,3 +180,10 @@ extern "C" int jxlgpu_device_download(jxlgpu_ctx* ctx, const void* dev_ptr, void
     HIP_TRY(ctx, hipMemcpy(host, dev_ptr, bytes, hipMemcpyDeviceToHost));
     return JXLGPU_OK;
 }
+
+extern "C" int jxlgpu_device_upload(jxlgpu_ctx* ctx, void* dev_ptr, const void* host, size_t bytes) {
+    if (!ctx || !dev_ptr || !host) return JXLGPU_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(dev_ptr, host, bytes, hipMemcpyHostToDevice));
+    return JXLGPU_OK;
+}

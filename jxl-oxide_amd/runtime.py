@@ -288,6 +288,10 @@ class Context:
         self._check(self.lib.jxlgpu_device_download(self.handle, ptr, out.ctypes.data, out.nbytes))
         return out
 
+    def device_upload(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._check(self.lib.jxlgpu_device_upload(self.handle, ptr, arr.ctypes.data, arr.nbytes))
+
     def format_output_to(self, frame, sample_format, dev_ptr, orientation=1):
         """format_output with a device destination (own memory or a peer mapping from ipc_open); asynchronous."""
         fmt = abi.FormatDesc(sample_format, orientation)

@@ -281,16 +281,65 @@ class PeerWriteGather:
         self.bytes_to_dst = 0
         self.base = None
         self.owned = False
+        # Every step below is collective-safe: a rank that fails still takes part in the exchanges, and ALL ranks
+        # raise together (the caller falls back to another gather on every rank, or on none).
+        import numpy as np
+        err = None
         obj = [None]
         if self.is_dst:
-            self.base = ctx.device_alloc(self.world * self.slots * self.slot_bytes)
-            self.owned = True
-            obj = [ctx.ipc_export(self.base)] if self.multi else [None]
+            try:
+                self.base = ctx.device_alloc(self.world * self.slots * self.slot_bytes)
+                self.owned = True
+                obj = [ctx.ipc_export(self.base)] if self.multi else [None]
+            except Exception as e:  # noqa: BLE001
+                err = f"owner: {type(e).__name__}: {e}"
+                obj = [None]
         if self.multi:
             dist.broadcast_object_list(obj, src=dst, group=group)
             if not self.is_dst:
-                self.base = ctx.ipc_open(obj[0])
+                if obj[0] is None:
+                    err = "the owner could not allocate / export the buffer"
+                else:
+                    try:
+                        self.base = ctx.ipc_open(obj[0])
+                    except Exception as e:  # noqa: BLE001
+                        err = f"rank {self.rank}: {type(e).__name__}: {e}"
+            # probe: every writer puts a pattern at the start of its first slot THROUGH the mapping, the owner reads it back
+            probe = np.full(64, 0xA0 + (self.rank & 0xF), dtype=np.uint8)
+            if err is None and not self.is_dst and self.slot_bytes >= 64:
+                try:
+                    ctx.device_upload(self.base + self.rank * self.slots * self.slot_bytes, probe)
+                except Exception as e:  # noqa: BLE001
+                    err = f"rank {self.rank} probe write: {type(e).__name__}: {e}"
+            errs = [None] * self.world
+            dist.all_gather_object(errs, err, group=group)
+            if self.is_dst and not any(errs) and self.slot_bytes >= 64:
+                got = ctx.device_download(self.base, (self.world, self.slots * self.slot_bytes), np.uint8)
+                for r in range(self.world):
+                    if r != self.rank and not (got[r, :64] == 0xA0 + (r & 0xF)).all():
+                        err = f"probe pattern of rank {r} did not arrive through its peer mapping"
+                for r in range(self.world):   # the probe bytes are not output: back to zero
+                    ctx.device_upload(self.base + r * self.slots * self.slot_bytes, np.zeros(64, dtype=np.uint8))
+            verdict = [err if self.is_dst else None]
+            dist.broadcast_object_list(verdict, src=dst, group=group)
+            errs = [e for e in errs if e] + ([verdict[0]] if verdict[0] else [])
+            if errs:
+                self._abort()
+                raise RuntimeError("PeerWriteGather unavailable: " + "; ".join(sorted(set(errs))))
+        elif err:
+            raise RuntimeError("PeerWriteGather unavailable: " + err)
         self.mine = self.base + self.rank * self.slots * self.slot_bytes
+
+    def _abort(self):
+        """Local clean-up after a failed set-up (no collective: every rank is on its way out)."""
+        try:
+            if self.base is not None and self.multi and not self.is_dst:
+                self.ctx.ipc_close(self.base)
+            if self.owned and self.base is not None:
+                self.ctx.device_free(self.base)
+        except Exception:  # noqa: BLE001
+            pass
+        self.base = None
 
     def write(self, frames, sample_format, orientation=1, first_slot=0):
         """Formats the last render of every frame into this rank's slots first_slot, ... in dst's buffer (asynchronous)."""
