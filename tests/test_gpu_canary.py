@@ -50,6 +50,9 @@ def test_library_under_the_guard_page_allocator(tmp_path):
     for mode in ("1", "2"):
         env = dict(os.environ, JXLGPU_GUARD=mode)
         r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+        if r.returncode == 1 and "hipMem" in r.stderr and "fault" not in r.stderr.lower():
+            # the debug allocator itself could not be set up (a runtime without the virtual-memory API): not a finding
+            pytest.skip("HIP virtual-memory API unavailable on this box: " + r.stderr.strip()[-200:])
         assert r.returncode == 0 and r.stdout.strip() == "ok", (mode, r.returncode, r.stdout, r.stderr[-600:])
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0 and "guarded ok" in r.stdout, (mode, r.returncode, r.stdout[-300:], r.stderr[-600:])
