@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 from jxl_oxide_amd import abi, runtime  # noqa: E402
-from jxl_oxide_amd.synth import VardctWorkload  # noqa: E402
+from jxl_oxide_amd.synth import VardctWorkload, make_extra_channel  # noqa: E402
 from jxl_oxide_amd.synth_modular import ModularWorkload  # noqa: E402
 from oracle import pyoracle  # noqa: E402
 
@@ -78,7 +78,10 @@ def run_vardct(ctx, rng):
     ow, oh = wl.out_size(stages)
     exp, _ = pyoracle.vardct_render(wl.desc(), stages, ow, oh)
     transport = str(rng.choice(["grouped", "grouped", "dense_i32", "sparse_i16"]))
-    f = ctx.vardct_upload(wl.desc(coeff_transport=transport))
+    shifts = None
+    if transport == "grouped" and rng.random() < 0.3:   # a progressive frame: two or three passes
+        shifts = [int(rng.integers(1, 5)), 0] if rng.random() < 0.5 else [int(rng.integers(3, 6)), int(rng.integers(1, 3)), 0]
+    f = ctx.vardct_upload(wl.desc(coeff_transport=transport, pass_shifts=shifts) if shifts else wl.desc(coeff_transport=transport))
     try:
         got = ctx.vardct_render(f, stages)
         ok = np.array_equal(got.view(np.uint32), exp.view(np.uint32))
@@ -88,7 +91,28 @@ def run_vardct(ctx, rng):
         ok_r = np.array_equal(reg.view(np.uint32), np.ascontiguousarray(exp[:, ry:ry + rh, rx:rx + rw]).view(np.uint32))
     finally:
         f.free()
-    return ok and ok_r, ("vardct", w, h, dict(kw, transport=transport, region=(rx, ry, rw, rh), full_ok=bool(ok)))
+    return ok and ok_r, ("vardct", w, h, dict(kw, transport=transport, passes=shifts, region=(rx, ry, rw, rh), full_ok=bool(ok)))
+
+
+def run_extra(ctx, rng):
+    """An extra channel of random size, bit depth, sample type and upsampling shift on a small rendered frame."""
+    wl = VardctWorkload(64, 40, seed=int(rng.integers(0, 1000)))
+    log2 = int(rng.choice([0, 0, 1, 2, 3, 4]))
+    w, h = int(rng.integers(2, 200 >> min(log2, 3))) + 1, int(rng.integers(2, 120 >> min(log2, 3))) + 1
+    kw = dict(seed=int(rng.integers(0, 1000)), i16=bool(rng.integers(0, 2)), upsampling_log2=log2)
+    if rng.random() < 0.25:
+        kw.update(i16=False, bit_depth=32, float_sample=True, exp_bits=8) if rng.random() < 0.5 else kw.update(i16=True, bit_depth=16, float_sample=True, exp_bits=5)
+    else:
+        kw["bit_depth"] = int(rng.integers(1, 15 if kw["i16"] else 31))
+    ec, keep = make_extra_channel(w, h, **kw)
+    exp = pyoracle.extra_channel(ec)
+    f = ctx.vardct_upload(wl.desc())
+    try:
+        ctx.vardct_render(f, abi.STAGE_ALL, to_host=False)
+        got = ctx.render_extra(f, int(rng.integers(0, abi.MAX_EXTRA)), ec)
+    finally:
+        f.free()
+    return bool(np.array_equal(got.view(np.uint32), exp.view(np.uint32))), ("extra", w, h, kw)
 
 
 def main():
@@ -98,9 +122,10 @@ def main():
     print("CANARY", runtime.gpu_canary())
     ctx = runtime.Context(0)
     t_end = time.time() + seconds
-    n, bad = {"modular": 0, "vardct": 0}, []
+    n, bad = {"modular": 0, "vardct": 0, "extra": 0}, []
     while time.time() < t_end:
-        fn = run_modular if rng.random() < 0.65 else run_vardct
+        r = rng.random()
+        fn = run_modular if r < 0.55 else (run_vardct if r < 0.9 else run_extra)
         try:
             ok, what = fn(ctx, rng)
         except runtime.JxlGpuError as e:
