@@ -144,3 +144,115 @@ def test_two_rank_gloo_shard_and_gather(oracle):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert results == {0: True, 1: True}
+
+
+class _FakeCtx:
+    """Stands in for runtime.Context in the CPU test of shard.PeerWriteGather: "device memory" is a file every rank
+    maps, the IPC handle its name.  What is under test is the PROTOCOL — who allocates, who opens, the probe, and above
+    all that a failure on ONE rank makes EVERY rank raise (a rank left inside a collective would hang the job)."""
+    BASE = 1 << 40
+
+    def __init__(self, tmpdir, rank, fail=None):
+        self.tmpdir, self.rank, self.fail = tmpdir, rank, fail
+        self.mm = None
+
+    def device_alloc(self, nbytes):
+        import numpy as np
+        if self.fail == "alloc":
+            raise RuntimeError("simulated allocation failure")
+        self.path = os.path.join(self.tmpdir, "buf.bin")
+        self.mm = np.memmap(self.path, dtype=np.uint8, mode="w+", shape=(nbytes,))
+        return self.BASE
+
+    def device_free(self, ptr):
+        self.mm = None
+
+    def ipc_export(self, ptr):
+        return self.path.encode().ljust(64, b"\0")[:64] if len(self.path) <= 64 else b"x" * 64
+
+    def ipc_open(self, handle):
+        import numpy as np
+        if self.fail == "open":
+            raise RuntimeError("simulated hipIpcOpenMemHandle failure")
+        self.mm = np.memmap(os.path.join(self.tmpdir, "buf.bin"), dtype=np.uint8, mode="r+")
+        return self.BASE
+
+    def ipc_close(self, ptr):
+        self.mm = None
+
+    def device_upload(self, ptr, arr):
+        import numpy as np
+        if self.fail == "probe":
+            return                      # the bytes silently go nowhere: the owner must notice
+        a = np.ascontiguousarray(arr).view(np.uint8).ravel()
+        self.mm[ptr - self.BASE:ptr - self.BASE + a.size] = a
+        self.mm.flush()
+
+    def device_download(self, ptr, shape, dtype):
+        import numpy as np
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        fresh = np.memmap(os.path.join(self.tmpdir, "buf.bin"), dtype=np.uint8, mode="r")
+        return np.array(fresh[ptr - self.BASE:ptr - self.BASE + n]).view(dtype).reshape(shape)
+
+    def format_output_to(self, frame, sample_format, dev_ptr, orientation=1):
+        self.device_upload(dev_ptr, frame)          # a "frame" is its formatted bytes here
+        return 0, 0
+
+    def synchronize(self):
+        pass
+
+
+def _peer_worker(rank, world, port, tmpdir, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import numpy as np
+    import torch.distributed as dist
+    from jxl_oxide_amd import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    try:
+        slot = 4096
+        # (1) the happy path: rank r's two "frames" land in slots [r][0..1] of the owner's buffer
+        ctx = _FakeCtx(tmpdir, rank)
+        pw = shard.PeerWriteGather(ctx, slot, 2, dst=0)
+        frames = [np.full(slot, 16 * rank + k + 1, dtype=np.uint8) for k in range(2)]
+        pw.write(frames, 0)
+        pw.finish()
+        if rank == 0:
+            got = pw.result()
+            for r in range(world):
+                for k in range(2):
+                    ok &= bool((got[r, k] == 16 * r + k + 1).all())
+        else:
+            ok &= pw.result() is None
+        pw.close()
+        # (2) a failure on ONE rank — the owner's allocation, a writer's open, a probe that never arrives — must raise
+        #     on EVERY rank (and leave nobody inside a collective: the barrier below would hang otherwise)
+        for who, what in ((0, "alloc"), (1, "open"), (1, "probe")):
+            ctx = _FakeCtx(tmpdir, rank, fail=what if rank == who else None)
+            try:
+                shard.PeerWriteGather(ctx, slot, 2, dst=0)
+                ok = False
+            except RuntimeError as e:
+                ok &= "PeerWriteGather unavailable" in str(e)
+            dist.barrier()
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_write_gather_protocol_and_collective_failures(tmp_path):
+    """shard.PeerWriteGather's set-up under gloo with two processes and a fake context (no GPU): data lands where it
+    should, and every single-rank failure turns into the same exception on all ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_peer_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results == {0: True, 1: True}
