@@ -19,10 +19,13 @@ def pytest_collection_modifyitems(config, items):
     """The box canary (tests/test_gpu_canary.py) runs before any other GPU test: with `-x`, a box whose GPU kills
     even a pure-HIP program stops the session THERE, with "BOX FAULT" in the record, instead of at whichever
     library test happened to come first."""
-    first = [it for it in items if it.nodeid.startswith("tests/test_gpu_canary.py") or "/test_gpu_canary.py" in it.nodeid]
-    if first:
-        rest = [it for it in items if it not in first]
-        items[:] = first + rest
+    first = [it for it in items if "test_gpu_canary.py" in it.nodeid and "test_box_canary" in it.nodeid]
+    # ... and the guard-allocator regression gate runs LAST: it leans on the HIP virtual-memory API, a debug facility —
+    # should that misbehave on some box, every parity test has been counted by then
+    last = [it for it in items if "test_gpu_canary.py" in it.nodeid and "guard_page_allocator" in it.nodeid]
+    if first or last:
+        rest = [it for it in items if it not in first and it not in last]
+        items[:] = first + rest + last
 
 
 @pytest.fixture(scope="session")
