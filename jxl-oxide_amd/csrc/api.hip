@@ -530,6 +530,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     ctx->tune.no_sparse_tr = getenv("JXLGPU_NO_SPARSE_TR") != nullptr;
     ctx->tune.debug_sync = getenv("JXLGPU_DEBUG_SYNC") != nullptr;
     ctx->tune.no_batch_overlap = getenv("JXLGPU_NO_BATCH_OVERLAP") != nullptr;
+    if (const char* v = getenv("JXLGPU_BATCH_HEAVY")) ctx->tune.batch_heavy = (uint32_t)strtoul(v, nullptr, 0) & 31u;
     if (const char* v = getenv("JXLGPU_GUARD")) {
         const int m = atoi(v);
         if (m == 1 || m == 2) ctx->guard_mode = m;
@@ -576,11 +577,11 @@ void jxlgpu_destroy(jxlgpu_ctx* ctx) {
         unsigned long long h[64];
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h, ctx->tr_prof, sizeof(h), hipMemcpyDeviceToHost);
-        static const char* kPh[9] = {"n", "entries", "coef+lut", "barrier0", "llf+dequant", "ydq+barrier1", "cfl+rows", "cols+stores", "drain"};
+        static const char* kPh[11] = {"n", "entries", "coef+lut", "barrier0", "zero", "scatter", "llf+dequant", "ydq+barrier1", "cfl+rows", "cols+stores", "drain"};
         for (int fam = 0; fam < 4; ++fam) {
             if (!h[fam * 16]) continue;
             fprintf(stderr, "[tr_prof] family %d: %llu wave-items;", fam, h[fam * 16]);
-            for (int i = 1; i < 9; ++i) fprintf(stderr, " %s %.0f", kPh[i], (double)h[fam * 16 + i] / (double)h[fam * 16]);
+            for (int i = 1; i < 11; ++i) fprintf(stderr, " %s %.0f", kPh[i], (double)h[fam * 16 + i] / (double)h[fam * 16]);
             fprintf(stderr, " (cycles / wave-item)\n");
         }
         (void)hipFree(ctx->tr_prof);
@@ -717,6 +718,7 @@ static void frame_collect(jxlgpu_frame* f, std::vector<void*>* ptrs, std::vector
     ptrs->insert(ptrs->end(), f->allocs.begin(), f->allocs.end());
     if (f->modular && f->modular_free) mods->emplace_back(f->modular, f->modular_free);
     if (f->ev_last) (void)hipEventDestroy(f->ev_last);
+    if (f->ev_fmt) (void)hipEventDestroy(f->ev_fmt);
     delete f;
 }
 
@@ -1018,15 +1020,15 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
         uint64_t nz_k = 0;   // their list words
         static const uint16_t kNone[3] = {0, 0, 0};
         for (uint32_t y = gy * gcells; y < y1; ++y) {
-            const uint8_t* krow = lg.block_kind + (size_t)(y - cy0) * lbw - cx0;
-            const int32_t* mrow = lg.hf_mul + (size_t)(y - cy0) * lbw - cx0;
+            const uint8_t* krow = lg.block_kind + (size_t)(y - cy0) * lbw;   // in-bounds row pointers, indexed with x - cx0
+            const int32_t* mrow = lg.hf_mul + (size_t)(y - cy0) * lbw;
             for (uint32_t x = gx * gcells; x < x1; ++x) {
-                const uint8_t t = krow[x];
+                const uint8_t t = krow[x - cx0];
                 if (t > 26) continue;
                 const uint32_t bw = kSize[t][0], bh = kSize[t][1];
                 // hf_metadata.rs:144-158: a varblock never crosses a group; keep the device safe
                 if (x + bw > x1 || y + bh > y1) return "varblock crosses a group border";
-                const int32_t mul = mrow[x];
+                const int32_t mul = mrow[x - cx0];
                 if (mul <= 0) return "non-positive HfMul";
                 if (!d->dequant[t][0] || !d->dequant[t][1] || !d->dequant[t][2]) return "missing dequant matrix for a used transform";
                 uint4 e = make_uint4(x | (y << 16), t, (uint32_t)mul, 0);
@@ -2062,7 +2064,7 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
         FrameBatch b;
         memset(&b, 0, sizeof(b));
         uint32_t max_w8 = 0, max_h8 = 0, max_wgs[4] = {}, max_special = 0, max_stream = 0, max_ring = 0;
-        bool any_smooth = false;
+        bool any_smooth = false, no_event = false;
         for (uint32_t i = 0; i < m; ++i) {
             jxlgpu_frame* f = frames[i0 + i];
             b.f[i] = f->dev_args;
@@ -2073,12 +2075,34 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
             max_ring = std::max(max_ring, f->n_ring_tiles);
             any_smooth |= !f->desc.skip_adaptive_lf_smoothing;
             if (overlap && f->ev_last && f->ev_last_set) HIP_TRY(ctx, hipStreamWaitEvent(st, f->ev_last, 0));
+            else if (overlap) no_event = true;   // (event creation / record failed earlier: order behind the render stream instead)
+        }
+        if (no_event) {
+            // a frame without a usable "last operation" event: everything queued on the render and upload streams so far
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, sp));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0));
+            if (ctx->stream_up) {
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream_up));
+                HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+            }
         }
         ctx->prof_begin(PROF_LF, st);
         HIP_TRY(ctx, launch_lf_batch(st, b, m, max_w8, max_h8, any_smooth));
         ctx->prof_end(PROF_LF, st);
         ctx->prof_begin(PROF_TRANSFORM, st);
-        if ((int)m <= ctx->tune.tr_side_max) {
+        const uint32_t heavy = overlap ? ctx->tune.batch_heavy : 0u;
+        if (heavy) {
+            // the families of `heavy` on the render stream, behind post(k-1) and in front of post(k) (they need the LF
+            // stage of this chunk: an event); the others on the transform stream, beside post(k-1)
+            hipEvent_t& evl = ctx->ev_tr[ctx->ev_tr_next++ % 8];
+            if (!evl) HIP_TRY(ctx, hipEventCreateWithFlags(&evl, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventRecord(evl, st));
+            HIP_TRY(ctx, hipStreamWaitEvent(sp, evl, 0));
+            HIP_TRY(ctx, sparse_tr ? launch_transform_batch_sparse(sp, nullptr, b, m, max_wgs, max_special, heavy)
+                                   : launch_transform_batch(sp, nullptr, b, m, max_wgs, max_special, heavy));
+            HIP_TRY(ctx, sparse_tr ? launch_transform_batch_sparse(st, nullptr, b, m, max_wgs, max_special, 31u & ~heavy)
+                                   : launch_transform_batch(st, nullptr, b, m, max_wgs, max_special, 31u & ~heavy));
+        } else if ((int)m <= ctx->tune.tr_side_max) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
             HIP_TRY(ctx, sparse_tr ? launch_transform_batch_sparse(st, ctx->stream2, b, m, max_wgs, max_special)

@@ -212,6 +212,9 @@ struct Tuning {
     bool no_sparse_tr = false;   // JXLGPU_NO_SPARSE_TR: grouped lists are expanded to dense cells first (dense kernels)
     bool debug_sync = false;     // JXLGPU_DEBUG_SYNC: synchronise + report after every launch group
     bool no_batch_overlap = false; // JXLGPU_NO_BATCH_OVERLAP: batched renders on one stream, stage after stage (round-3 form)
+    uint32_t batch_heavy = 0;    // JXLGPU_BATCH_HEAVY: mask of transform families (bit F = family F, bit 4 = special 8x8) of chunk k that
+                                 // run on the RENDER stream between post(k-1) and post(k) instead of on the transform stream beside
+                                 // post(k-1): families whose waves do not fit beside two post waves per SIMD displace them
     int tr_wgs_per_cu[4] = {0, 0, 0, 0};  // JXLGPU_TR_WGS_PER_CU="a,b,c,d": persistent transform workgroups per CU
                                  // for the 8-, 16-, 32- and 64-px launch (0: one workgroup per item, no run-ahead)
     int sqz_seg = 64;            // JXLGPU_SQZ_SEG: pairs per inverse-Squeeze segment
@@ -387,6 +390,8 @@ struct jxlgpu_frame {
     float* deq_lut = nullptr;            // quant_bias_numerator / k, k < 256 (dequant_one_lut)
     hipEvent_t ev_last = nullptr;        // behind the last asynchronous operation queued for this frame (jxlgpu_frame_wait)
     bool ev_last_set = false;
+    hipEvent_t ev_fmt = nullptr;         // behind the last download-stream copy that reads fmt_buf (JXLGPU_MEM_HOST_PINNED): the next
+    bool ev_fmt_set = false;             // formatting kernel into fmt_buf waits for it
     FrameDev* dev_args = nullptr;        // device copy of the default pipeline's arguments (batched launches)
     bool dev_args_ready = false;
     bool batch_ok = false;               // the frame qualifies for the batched default pipeline (V1-V8 and post)
@@ -432,8 +437,9 @@ void launch_transform_class(hipStream_t s, int cls, const TransformArgs& a, cons
 void build_class_table(int family, const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT],
                        uint32_t num_cus, int wgs_per_cu, ClassTable* ct);
 hipError_t launch_lf_batch(hipStream_t s, const FrameBatch& b, uint32_t n, uint32_t max_w8, uint32_t max_h8, bool any_smooth);
+// `mask`: bit F = launch family F (0: 8-px ... 3: 64-px), bit 4 = the special 8x8 family
 hipError_t launch_transform_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, const uint32_t max_wgs[4],
-                                  uint32_t max_special);
+                                  uint32_t max_special, uint32_t mask = 31u);
 hipError_t launch_post_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, uint32_t max_stream_wgs,
                              uint32_t max_ring, bool pk);
 hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs& a, const uint4* entries,
@@ -446,7 +452,7 @@ hipError_t launch_transform_items_sparse(hipStream_t s, int family, const Transf
 void launch_transform_special_sparse(hipStream_t s, const TransformArgs& a, const uint4* entries, const uint32_t* nzc,
                                      uint32_t count);
 hipError_t launch_transform_batch_sparse(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n,
-                                         const uint32_t max_wgs[4], uint32_t max_special);
+                                         const uint32_t max_wgs[4], uint32_t max_special, uint32_t mask = 31u);
 // grouped lists -> dense cell-tiled coefficients (fallback for frames with >= 128-px varblocks; `coeff` zeroed first)
 void launch_grouped_to_dense(hipStream_t s, const uint4* entries, const uint32_t* nzc, uint32_t n_entries,
                              const uint32_t* nz, uint32_t w8, int32_t* coeff, bool accumulate);

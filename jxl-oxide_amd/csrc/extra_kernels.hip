@@ -1,6 +1,8 @@
 // Extra channels (alpha, depth, spot colours): int -> float with the channel's own bit depth, then the image's
 // non-separable upsampling — what `ImageWithRegion::upsample_nonseparable` (jxl-render/src/image.rs:487-557) does to
 // every channel that is not a colour channel.  The upsampling kernels are the colour path's (upsample_kernels.hip).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -35,11 +37,24 @@ int fail(jxlgpu_ctx* ctx, int code, const char* msg) {
     return code;
 }
 
+// Buffers of one jxlgpu_frame_render_extra call: everything but the final plane goes back to the pool (deferred: behind
+// the work queued so far) when the call ends, on success and on failure alike.
+struct ExtraScratch {
+    jxlgpu_ctx* ctx;
+    std::vector<void*> bufs;
+    void* keep = nullptr;
+    ~ExtraScratch() {
+        std::vector<void*> rel;
+        for (void* p : bufs)
+            if (p != keep) rel.push_back(p);
+        if (!rel.empty()) ctx_defer_release(ctx, std::move(rel));
+    }
+};
 template <typename T>
-int alloc_on_frame(jxlgpu_ctx* ctx, jxlgpu_frame* f, T** out, size_t bytes) {
+int alloc_scratch(jxlgpu_ctx* ctx, ExtraScratch* sc, T** out, size_t bytes) {
     void* p = nullptr;
     HIP_TRY(ctx, ctx_dev_malloc(ctx, &p, std::max<size_t>(bytes, 16)));
-    f->allocs.push_back(p);
+    sc->bufs.push_back(p);
     *out = static_cast<T*>(p);
     return JXLGPU_OK;
 }
@@ -72,9 +87,10 @@ extern "C" int jxlgpu_frame_render_extra(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint3
     const size_t n = (size_t)ec->width * ec->height, esz = ec->sample_type == JXLGPU_SAMPLE_I16 ? 2 : 4;
     void* d_int = nullptr;
     float* cur = nullptr;
-    int rc = alloc_on_frame(ctx, f, &d_int, n * esz);
+    ExtraScratch sc{ctx};
+    int rc = alloc_scratch(ctx, &sc, &d_int, n * esz);
     if (rc) return rc;
-    if ((rc = alloc_on_frame(ctx, f, &cur, n * 4))) return rc;
+    if ((rc = alloc_scratch(ctx, &sc, &cur, n * 4))) return rc;
     HIP_TRY(ctx, hipMemcpy(d_int, ec->data, n * esz, hipMemcpyHostToDevice));  // pageable source: returns when it has been read
     ec_to_float_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(d_int, ec->sample_type == JXLGPU_SAMPLE_I16, n, ec->bit_depth,
                                                                    ec->float_sample, ec->exp_bits, cur);
@@ -85,10 +101,10 @@ extern "C" int jxlgpu_frame_render_extra(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint3
         std::vector<float> wq = expand_up_weights_public(coded, k);
         float* d_w = nullptr;
         float* nxt = nullptr;
-        int r = alloc_on_frame(ctx, f, &d_w, wq.size() * 4);
+        int r = alloc_scratch(ctx, &sc, &d_w, wq.size() * 4);
         if (r) return r;
         HIP_TRY(ctx, hipMemcpy(d_w, wq.data(), wq.size() * 4, hipMemcpyHostToDevice));
-        if ((r = alloc_on_frame(ctx, f, &nxt, (size_t)w * k * h * k * 4))) return r;
+        if ((r = alloc_scratch(ctx, &sc, &nxt, (size_t)w * k * h * k * 4))) return r;
         launch_upsample(s, cur, w, w, h, nxt, w * k, k, d_w);
         cur = nxt; w *= k; h *= k;
         return JXLGPU_OK;
@@ -98,6 +114,17 @@ extern "C" int jxlgpu_frame_render_extra(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint3
     if (last == 1 && (rc = pass(2, ec->weights.up2_weight))) return rc;
     if (last == 2 && (rc = pass(4, ec->weights.up4_weight))) return rc;
     HIP_TRY(ctx, hipGetLastError());
+    // the final plane stays with the frame; the plane of an earlier render of this index is released (deferred)
+    if (f->extra[index]) {
+        void* old = f->extra[index];
+        auto it = std::find(f->allocs.begin(), f->allocs.end(), old);
+        if (it != f->allocs.end()) {
+            f->allocs.erase(it);
+            ctx_defer_release(ctx, std::vector<void*>{old});
+        }
+    }
+    sc.keep = cur;
+    f->allocs.push_back(cur);
     f->extra[index] = cur; f->extra_w[index] = w; f->extra_h[index] = h;
     frame_mark(ctx, f, s);
     if (!out) return JXLGPU_OK;

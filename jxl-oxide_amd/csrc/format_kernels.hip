@@ -101,6 +101,8 @@ extern "C" int jxlgpu_frame_format_output(jxlgpu_ctx* ctx, jxlgpu_frame* f, cons
             f->fmt_bytes = bytes;
         }
         dst = f->fmt_buf;
+        // an earlier JXLGPU_MEM_HOST_PINNED output of this frame may still be reading fmt_buf on the download stream
+        if (f->ev_fmt_set) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, f->ev_fmt, 0));
     }
     FormatArgs a;
     memset(&a, 0, sizeof(a));
@@ -135,6 +137,9 @@ extern "C" int jxlgpu_frame_format_output(jxlgpu_ctx* ctx, jxlgpu_frame* f, cons
         HIP_TRY(ctx, hipEventRecord(ev, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_down, ev, 0));
         HIP_TRY(ctx, hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, ctx->stream_down));
+        if (!f->ev_fmt) HIP_TRY(ctx, hipEventCreateWithFlags(&f->ev_fmt, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(f->ev_fmt, ctx->stream_down));
+        f->ev_fmt_set = true;
         frame_mark(ctx, f, ctx->stream_down);
     } else if (out_mem != JXLGPU_MEM_DEVICE) {
         if (ctx->pinned_size < bytes) {

@@ -114,16 +114,16 @@ void launch_transform_special_sparse(hipStream_t s, const TransformArgs& a, cons
 }
 
 hipError_t launch_transform_batch_sparse(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n,
-                                         const uint32_t max_wgs[4], uint32_t max_special) {
+                                         const uint32_t max_wgs[4], uint32_t max_special, uint32_t mask) {
     if (!side) side = s;
 #define LAUNCHB(F, ST)                                                                                              \
-    if (max_wgs[F]) {                                                                                              \
+    if (max_wgs[F] && (mask >> F & 1u)) {                                                                          \
         set_lds_attr_sparse<F>();                                                                                  \
         transform_items_batch_kernel<F, true><<<dim3(max_wgs[F], n), 192, FamCfg<F>::WORDS_S * sizeof(float), ST>>>(b); \
     }
     LAUNCHB(3, side)
     LAUNCHB(2, side)
-    if (max_special)
+    if (max_special && (mask & 16u))
         transform_special_sparse_batch_kernel<<<dim3(ceil_div(max_special, kSpecialPerWave), n), 64, 0, side>>>(b);
     LAUNCHB(1, s)
     LAUNCHB(0, s)

@@ -314,12 +314,15 @@ class PeerWriteGather:
             errs = [None] * self.world
             dist.all_gather_object(errs, err, group=group)
             if self.is_dst and not any(errs) and self.slot_bytes >= 64:
-                got = ctx.device_download(self.base, (self.world, self.slots * self.slot_bytes), np.uint8)
-                for r in range(self.world):
-                    if r != self.rank and not (got[r, :64] == 0xA0 + (r & 0xF)).all():
-                        err = f"probe pattern of rank {r} did not arrive through its peer mapping"
-                for r in range(self.world):   # the probe bytes are not output: back to zero
-                    ctx.device_upload(self.base + r * self.slots * self.slot_bytes, np.zeros(64, dtype=np.uint8))
+                try:   # dst must reach the verdict broadcast whatever happens here: the other ranks are waiting in it
+                    got = ctx.device_download(self.base, (self.world, self.slots * self.slot_bytes), np.uint8)
+                    for r in range(self.world):
+                        if r != self.rank and not (got[r, :64] == 0xA0 + (r & 0xF)).all():
+                            err = f"probe pattern of rank {r} did not arrive through its peer mapping"
+                    for r in range(self.world):   # the probe bytes are not output: back to zero
+                        ctx.device_upload(self.base + r * self.slots * self.slot_bytes, np.zeros(64, dtype=np.uint8))
+                except Exception as e:  # noqa: BLE001
+                    err = f"owner's probe read-back: {type(e).__name__}: {e}"
             verdict = [err if self.is_dst else None]
             dist.broadcast_object_list(verdict, src=dst, group=group)
             errs = [e for e in errs if e] + ([verdict[0]] if verdict[0] else [])
