@@ -530,6 +530,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     ctx->tune.no_sparse_tr = getenv("JXLGPU_NO_SPARSE_TR") != nullptr;
     ctx->tune.debug_sync = getenv("JXLGPU_DEBUG_SYNC") != nullptr;
     ctx->tune.no_batch_overlap = getenv("JXLGPU_NO_BATCH_OVERLAP") != nullptr;
+    if (const char* v = getenv("JXLGPU_RING_MODE")) ctx->tune.ring_mode = std::min(2, std::max(0, atoi(v)));
     if (const char* v = getenv("JXLGPU_BATCH_HEAVY")) ctx->tune.batch_heavy = (uint32_t)strtoul(v, nullptr, 0) & 31u;
     if (const char* v = getenv("JXLGPU_GUARD")) {
         const int m = atoi(v);
@@ -558,6 +559,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         create_tr_stream(ctx) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream_tr2, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_down, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -587,7 +589,7 @@ void jxlgpu_destroy(jxlgpu_ctx* ctx) {
         (void)hipFree(ctx->tr_prof);
     }
 #endif
-    for (hipStream_t st : {ctx->stream_tr, ctx->stream, ctx->stream2, ctx->stream_up, ctx->stream_down})
+    for (hipStream_t st : {ctx->stream_tr2, ctx->stream_tr, ctx->stream, ctx->stream2, ctx->stream_up, ctx->stream_down})
         if (st) (void)hipStreamSynchronize(st);
     ctx_reap(ctx, true);
     delete ctx->workers;
@@ -604,6 +606,7 @@ void jxlgpu_destroy(jxlgpu_ctx* ctx) {
     for (hipEvent_t e : ctx->ev_h2d) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream_tr2) (void)hipStreamDestroy(ctx->stream_tr2);
     if (ctx->stream_tr) (void)hipStreamDestroy(ctx->stream_tr);
     for (hipEvent_t e : ctx->ev_tr) if (e) (void)hipEventDestroy(e);
     if (ctx->stream_up) (void)hipStreamDestroy(ctx->stream_up);
@@ -2000,8 +2003,10 @@ static int ensure_dev_args(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
         const float* in[3] = {f->pix_t, nullptr, nullptr};
         bool stream = false, plain_srgb = false;
         // batched launches have waves to spare: taller wave segments (less halo-row recompute)
+        const int launch_frames = ctx->tune.batch_chunk > 0 ? std::min<int>(ctx->tune.batch_chunk, JXLGPU_MAX_BATCH)
+                                                             : (ctx->tune.no_batch_overlap ? (int)JXLGPU_MAX_BATCH : 16);
         HIP_TRY(ctx, fused_prepare(ctx, f, in, f->wr, f->w8, f->buf_a, f->wr, true, 2, true, &h.post, &stream, &plain_srgb,
-                                   ctx->tune.batch_stream_rows));
+                                   ctx->tune.batch_stream_rows > 0 ? ctx->tune.batch_stream_rows : -launch_frames));
         f->batch_pk = h.post.pk != 0;
         // one kernel per batched launch: a frame that needs the other streaming kernel renders its post stage alone
         post_ok = stream && plain_srgb && f->batch_pk != ctx->tune.no_pk;
@@ -2104,10 +2109,11 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
                                    : launch_transform_batch(st, nullptr, b, m, max_wgs, max_special, 31u & ~heavy));
         } else if ((int)m <= ctx->tune.tr_side_max) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            HIP_TRY(ctx, sparse_tr ? launch_transform_batch_sparse(st, ctx->stream2, b, m, max_wgs, max_special)
-                                   : launch_transform_batch(st, ctx->stream2, b, m, max_wgs, max_special));
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+            hipStream_t side = overlap ? ctx->stream_tr2 : ctx->stream2;
+            HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
+            HIP_TRY(ctx, sparse_tr ? launch_transform_batch_sparse(st, side, b, m, max_wgs, max_special)
+                                   : launch_transform_batch(st, side, b, m, max_wgs, max_special));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, side));
             HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
         } else {
             HIP_TRY(ctx, sparse_tr ? launch_transform_batch_sparse(st, nullptr, b, m, max_wgs, max_special)
@@ -2134,12 +2140,19 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
             continue;
         }
         ctx->prof_begin(PROF_POST, sp);
-        // one fork / join per launch: the border rings run beside the streaming kernel
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, sp));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        HIP_TRY(ctx, launch_post_batch(sp, ctx->stream2, b, m, max_stream, max_ring, !ctx->tune.no_pk));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-        HIP_TRY(ctx, hipStreamWaitEvent(sp, ctx->ev_join, 0));
+        if (overlap && ctx->tune.ring_mode != 0) {
+            // the border rings on the render stream itself, at full occupancy, in front of / behind the streaming kernel
+            if (ctx->tune.ring_mode == 1) HIP_TRY(ctx, launch_post_batch(sp, nullptr, b, m, 0, max_ring, !ctx->tune.no_pk));
+            HIP_TRY(ctx, launch_post_batch(sp, nullptr, b, m, max_stream, 0, !ctx->tune.no_pk));
+            if (ctx->tune.ring_mode == 2) HIP_TRY(ctx, launch_post_batch(sp, nullptr, b, m, 0, max_ring, !ctx->tune.no_pk));
+        } else {
+            // one fork / join per launch: the border rings run beside the streaming kernel
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, sp));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            HIP_TRY(ctx, launch_post_batch(sp, ctx->stream2, b, m, max_stream, max_ring, !ctx->tune.no_pk));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+            HIP_TRY(ctx, hipStreamWaitEvent(sp, ctx->ev_join, 0));
+        }
         ctx->prof_end(PROF_POST, sp);
         for (uint32_t i = 0; i < m; ++i) {
             jxlgpu_frame* f = frames[i0 + i];

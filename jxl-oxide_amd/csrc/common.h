@@ -200,9 +200,17 @@ enum ProfGroup : int { PROF_LF = 0, PROF_TRANSFORM = 1, PROF_POST = 2, PROF_MODU
 
 // Tuning / debug switches.  Read from the environment ONCE, at jxlgpu_create, into the context:
 // the library keeps no process-global mutable state (include/jxlgpu.h "Threading").
+// Issue priority of the waves of the batched V1-V8 launches (s_setprio 0..3): they share their SIMDs with the waves of the
+// post kernel of the previous chunk, which always have a VALU instruction ready.  Measured (round 5): 109.2 us per frame with
+// priority 3, 110.7 with 1, 108.0 with 0 — no effect, so it stays off; the switch remains for experiments.
+#ifndef JXL_TR_PRIO
+#define JXL_TR_PRIO 0
+#endif
+#define JXL_SET_TR_PRIO() do { if (JXL_TR_PRIO > 0) __builtin_amdgcn_s_setprio(JXL_TR_PRIO); } while (0)
+
 struct Tuning {
     int stream_rows = 48;        // JXLGPU_STREAM_ROWS: rows per wave segment of post_stream_kernel
-    int batch_stream_rows = 96;  // JXLGPU_BATCH_STREAM_ROWS: the same for batched launches (waves to spare)
+    int batch_stream_rows = 0;   // JXLGPU_BATCH_STREAM_ROWS: the same for batched launches (0: one resident round of waves per launch)
     int batch_chunk = 0;         // JXLGPU_BATCH_CHUNK: > 0: frames per launch of a batch (default: JXLGPU_MAX_BATCH)
     int tr_side_max = 16;        // JXLGPU_TR_SIDE_MAX: launches of <= this many frames run the big-shape transforms on the side stream
                                  // (short launches: their tails overlap; +2.7 % at 8 frames per launch, nothing at 32)
@@ -212,6 +220,11 @@ struct Tuning {
     bool no_sparse_tr = false;   // JXLGPU_NO_SPARSE_TR: grouped lists are expanded to dense cells first (dense kernels)
     bool debug_sync = false;     // JXLGPU_DEBUG_SYNC: synchronise + report after every launch group
     bool no_batch_overlap = false; // JXLGPU_NO_BATCH_OVERLAP: batched renders on one stream, stage after stage (round-3 form)
+    int ring_mode = 0;           // JXLGPU_RING_MODE: border-ring launch of a batched chunk: 0 = on the side stream beside the streaming post launch,
+                                 // 1 = on the render stream in front of it, 2 = behind it.  (Round 5 kernel trace: beside it the ring launch, an
+                                 // LDS tile kernel of 56 VGPRs, takes the registers two post waves per SIMD leave over for ~0.65 ms and the LF
+                                 // launch of the next chunk waits behind it; in front of it the transform launches start earlier but the post
+                                 // launch they then share the chip with runs 20 % longer: 111 / 114-125 us per frame, mode 0 stays.)
     uint32_t batch_heavy = 0;    // JXLGPU_BATCH_HEAVY: mask of transform families (bit F = family F, bit 4 = special 8x8) of chunk k that
                                  // run on the RENDER stream between post(k-1) and post(k) instead of on the transform stream beside
                                  // post(k-1): families whose waves do not fit beside two post waves per SIMD displace them
@@ -260,6 +273,8 @@ struct jxlgpu_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: 64-pixel varblock kernels overlap the <=32 kernel
     hipStream_t stream_tr = nullptr;    // batched renders: V1-V8 of chunk k+1 beside the post stage of chunk k
+    hipStream_t stream_tr2 = nullptr;   // ... its 32 / 64-px and special launches (forked from and joined into stream_tr: never stream2, where
+                                        // the border-ring launch of chunk k would sit in front of the heavy transforms of chunk k+1)
     hipEvent_t ev_tr[8] = {};
     uint32_t ev_tr_next = 0;
     hipStream_t stream_up = nullptr;    // H2D of the upload arenas: overlaps the kernels of earlier frames

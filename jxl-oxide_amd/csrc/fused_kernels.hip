@@ -658,6 +658,17 @@ hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in
         a.sx0 = sx0; a.sx1 = sx1; a.sy0 = sy0; a.sy1 = sy1;
         a.n_ring_h = f->n_ring_h;
         a.rows_per_seg = rows_per_seg > 0 ? rows_per_seg : (ctx ? ctx->tune.stream_rows : 48);
+        if (rows_per_seg < 0 && ctx) {
+            // batched launches of -rows_per_seg frames: ONE resident round of waves (JXL_POST_WAVES per SIMD) per launch — the
+            // tallest segments (8 run-in rows each) that still fill the chip, and no half-empty last round
+            // (measured, 16 frames of 4K per launch: 5.5 rounds of 100-row segments 118 us per frame, one round of
+            // 536-row segments 107)
+            const int fpl = -rows_per_seg;
+            const int strips_pk = (sx1 - sx0 + 119) / 120;   // packed kernel's strips (PW, defined below)
+            const int slots = (int)ctx->num_cus * 4 * JXL_POST_WAVES;
+            const int segs = std::max(1, (slots + fpl * strips_pk / 2) / (fpl * strips_pk));
+            a.rows_per_seg = std::max(32, (sy1 - sy0 + segs - 1) / segs);
+        }
         {   // equal segments (a short last one would pay the 8 run-in rows for little output)
             const int total = sy1 - sy0;
             const int n = std::max(1, (total + a.rows_per_seg / 2) / a.rows_per_seg);

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(64) void transform_special_kernel(TransformArgs a, 
 
 __global__ __launch_bounds__(64) void transform_special_batch_kernel(FrameBatch b) {
     __shared__ float lut[kLutWords];
+    JXL_SET_TR_PRIO();
     const FrameDevC fd = (FrameDevC)b.f[blockIdx.y];
     const uint32_t count = fd->special_count;
     if (blockIdx.x * kSpecialPerWave >= count) return;

@@ -22,6 +22,7 @@ __global__ __launch_bounds__(64) void transform_special_sparse_kernel(TransformA
 
 __global__ __launch_bounds__(64) void transform_special_sparse_batch_kernel(FrameBatch b) {
     __shared__ __attribute__((aligned(16))) int tile[kSpecialTileWords];
+    JXL_SET_TR_PRIO();
     const FrameDevC fd = (FrameDevC)b.f[blockIdx.y];
     const uint32_t count = fd->special_count;
     if (blockIdx.x * kSpecialPerWave >= count) return;

@@ -26,6 +26,7 @@ __device__ __forceinline__ void lf_dequant_cfl_body(const LfArgs& a) {
 
 __global__ __launch_bounds__(256) void lf_dequant_cfl_kernel(LfArgs a) { lf_dequant_cfl_body(a); }
 __global__ __launch_bounds__(256) void lf_dequant_cfl_batch_kernel(FrameBatch b) {
+    JXL_SET_TR_PRIO();
     const LfArgs a = load_const(&((FrameDevC)b.f[blockIdx.z])->lf);
     lf_dequant_cfl_body(a);
 }
@@ -73,6 +74,7 @@ __device__ __forceinline__ void lf_smooth_body(const SmoothArgs& a) {
 
 __global__ __launch_bounds__(256) void lf_smooth_kernel(SmoothArgs a) { lf_smooth_body(a); }
 __global__ __launch_bounds__(256) void lf_smooth_batch_kernel(FrameBatch b) {
+    JXL_SET_TR_PRIO();
     const FrameDevC fd = (FrameDevC)b.f[blockIdx.z];
     if (fd->skip_smooth) return;
     const SmoothArgs a = load_const(&fd->smooth);
