@@ -48,7 +48,22 @@ VALU_PEAK_GINSTR = 614.4    # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 f32 ins
 # static VALU count of one row step of the streaming post kernel and its strip width (tools/isa_blocks.sh):
 # packed kernel (two columns per lane, the default) / scalar kernel (JXLGPU_NO_PK)
 POST_VALU_PER_ROW, POST_STRIP = (354, 56) if os.environ.get("JXLGPU_NO_PK") else (428, 120)
-POST_ROWS_PER_SEG, POST_HALO_ROWS = int(os.environ.get("JXLGPU_BATCH_STREAM_ROWS", "96")), 8
+POST_HALO_ROWS = 8
+
+
+def post_rows_per_seg(ih, iw, num_cus):
+    """Rows per wave segment of the batched streaming post launch, as fused_prepare() (csrc/fused_kernels.hip) picks them:
+    JXLGPU_BATCH_STREAM_ROWS if set, otherwise ONE resident round of waves (two per SIMD) per launch of 16 frames."""
+    env = os.environ.get("JXLGPU_BATCH_STREAM_ROWS")
+    if env and int(env) > 0:
+        rows = int(env)
+    else:
+        fpl = int(os.environ.get("JXLGPU_BATCH_CHUNK", "0")) or (32 if os.environ.get("JXLGPU_NO_BATCH_OVERLAP") else 16)
+        strips = -(-iw // 120)
+        segs = max(1, (num_cus * 8 + fpl * strips // 2) // (fpl * strips))
+        rows = max(32, -(-ih // segs))
+    nseg = max(1, (ih + rows // 2) // rows)
+    return (-(-ih // nseg) + 3) // 4 * 4
 
 
 def main():
@@ -298,8 +313,7 @@ def main():
             if args.config == 2 and dominant == 2:
                 # the streaming kernel's region and segmentation, as fused_prepare() lays them out
                 iw, ih = (W4K - 4) // 8 * 8 - 16, (H4K - 4) // 8 * 8 - 16
-                nseg = max(1, (ih + POST_ROWS_PER_SEG // 2) // POST_ROWS_PER_SEG)
-                rows = (-(-ih // nseg) + 3) // 4 * 4
+                rows = post_rows_per_seg(ih, iw, torch.cuda.get_device_properties(local_rank).multi_processor_count)
                 segs = -(-ih // rows)
                 strips = -(-iw // POST_STRIP)
                 winstr = strips * segs * (rows + POST_HALO_ROWS) * POST_VALU_PER_ROW * frames_per_launch
@@ -309,7 +323,8 @@ def main():
                                  "note": "streaming post kernel, f32 in the reference's operation order (no FMA contraction, "
                                          "correctly rounded division); a packed v_pk_*_f32 instruction counts once; halo rows "
                                          "and columns are recomputed (%d/%d x %d/%d)" % (
-                                             POST_STRIP + 8, POST_STRIP, rows + POST_HALO_ROWS, rows)}
+                                             POST_STRIP + 8, POST_STRIP, rows + POST_HALO_ROWS, rows),
+                                 "rows_per_segment": rows, "valu_per_row_step": POST_VALU_PER_ROW}
             verified = None
             if not args.no_verify and not band_sharded:
                 vw = dict(list(wls.items())[:max(1, args.verify_frames)])
@@ -359,6 +374,9 @@ def main():
             cpu = None
             if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (bounded CPU sample)
                 cpu = cpu_baseline(args.config, args.cpu_seconds)
+            others = None
+            if not args.no_extras and args.config == 2 and world == 1:
+                others = other_configs()
             out = {
                 "metric": job["metric"],
                 "value": round(value, 1),
@@ -402,6 +420,7 @@ def main():
                 "value_with_gather": None if gather_ms is None else round(
                     n_total * passes * mp_per_frame / (elapsed / args.steps + passes * gather_ms * 1e-3), 1),
                 "end_to_end": e2e,
+                "other_configs": others,
                 "cpu_baseline": cpu,
             }
         if gather is not None and gather_mode == "p2p":
@@ -428,9 +447,8 @@ def make_job(config, distinct, transport="grouped", nz=0.15):
 
     def pmc_traffic(pattern_names):
         def fn(dominant, frames_per_launch):
-            src = os.path.join("profiles", "r04_pmc_hbm_traffic.json")
-            if not os.path.exists(os.path.join(ROOT, src)):
-                src = os.path.join("profiles", "r03_pmc_hbm_traffic.json")
+            src = next((os.path.join("profiles", n) for n in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json")
+                        if os.path.exists(os.path.join(ROOT, "profiles", n))), os.path.join("profiles", "r05_pmc_hbm_traffic.json"))
             try:
                 pmc = json.load(open(os.path.join(ROOT, src)))
                 kb = 0.0
@@ -448,7 +466,7 @@ def make_job(config, distinct, transport="grouped", nz=0.15):
 
         def verify(ctx, frames, mine, wls, distinct):
             from oracle import pyoracle
-            worst, ok = 0, True
+            worst, ok, hist = 0, True, {}
             for d, wl in wls.items():
                 f = frames[[i % distinct for i in mine].index(d)]
                 got = ctx.download_result(f, stages)
@@ -456,10 +474,24 @@ def make_job(config, distinct, transport="grouped", nz=0.15):
                 same = np.array_equal(got.view(np.uint32), exp.view(np.uint32))
                 ok &= bool(same)
                 if not same:
-                    a = got.view(np.int32).astype(np.int64); b = exp.view(np.int32).astype(np.int64)
-                    worst = max(worst, int(np.abs(a - b).max()))
-            return {"ok": ok, "frames_checked": len(wls), "max_raw_bit_distance": worst,
-                    "against": "oracle/ (C restatement of the reference's generic path), whole 3840x2160 frames, after the timed region"}
+                    # distance in units in the last place: floats mapped to integers that order like the reals
+                    def ordered(x):
+                        i = x.view(np.int32).astype(np.int64)
+                        return np.where(i < 0, -(i & 0x7fffffff), i)
+                    dist = np.abs(ordered(got) - ordered(exp))
+                    worst = max(worst, int(dist.max()))
+                    edges = [0, 1, 2, 3, 5, 9, 17, 65, 1 << 62]
+                    names = ["0", "1", "2", "3-4", "5-8", "9-16", "17-64", ">64"]
+                    for nme, lo, hi in zip(names, edges[:-1], edges[1:]):
+                        hist[nme] = hist.get(nme, 0) + int(((dist >= lo) & (dist < hi)).sum())
+            res = {"ok": ok, "frames_checked": len(wls), "max_raw_bit_distance": worst,
+                   "against": "oracle/ (C restatement of the reference's generic path), whole 3840x2160 frames, after the timed region"}
+            if hist:
+                res["ulp_histogram"] = hist
+            if os.environ.get("JXLGPU_POST_FAST", "0") not in ("", "0"):
+                res["post_fast"] = ("JXLGPU_POST_FAST=1: the NON-bit-exact post kernel (products with one refined reciprocal instead of the "
+                                    "correctly rounded divisions, fma-contracted sums / polynomials); a measured option, never the default")
+            return res
 
         def alg_bytes(f, group):
             npx, ncell = W4K * H4K, (W4K // 8) * (H4K // 8)
@@ -545,6 +577,30 @@ def make_job(config, distinct, transport="grouped", nz=0.15):
         "alg_bytes": lambda f, g: W8K * H8K * (6 + 12),  # 3 x i16 in + 3 x f32 out per pixel
         "verify": verify, "traffic": lambda d, n: (None, None),
     }
+
+
+def other_configs():
+    """BASELINE configs 3 and 5 on this box, in the default line (N = 1): `bench.py --config C` as a child process on a short
+    job (4 frames, one distinct workload, 5 timed steps), its value / verification / roofline fraction copied here."""
+    res = {}
+    for c in (3, 5):
+        key = "config%d" % c
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(c), "--frames", "4", "--distinct", "1",
+                                "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extras"],
+                               capture_output=True, text=True, timeout=300, env=dict(os.environ, JXLGPU_NO_CANARY="1"))
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            rf = d.get("roofline") or {}
+            res[key] = {"metric": d.get("metric"), "value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"),
+                        "frames_per_step": (d.get("config") or {}).get("frames_per_gpu_per_step"), "dtype": d.get("dtype"),
+                        "workload": (d.get("config") or {}).get("workload"),
+                        "verified": d.get("verified"),
+                        "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms",
+                                                            "pipeline_algorithmic_frac")},
+                        "command": "python bench.py --config %d --frames 4 --distinct 1 --steps 5 --warmup 2" % c}
+        except Exception as e:  # noqa: BLE001
+            res[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
 
 
 def end_to_end(ctx, wl, mp_per_frame):

@@ -530,6 +530,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     ctx->tune.no_sparse_tr = getenv("JXLGPU_NO_SPARSE_TR") != nullptr;
     ctx->tune.debug_sync = getenv("JXLGPU_DEBUG_SYNC") != nullptr;
     ctx->tune.no_batch_overlap = getenv("JXLGPU_NO_BATCH_OVERLAP") != nullptr;
+    ctx->tune.post_fast = getenv("JXLGPU_POST_FAST") != nullptr && atoi(getenv("JXLGPU_POST_FAST")) != 0;
     if (const char* v = getenv("JXLGPU_RING_MODE")) ctx->tune.ring_mode = std::min(2, std::max(0, atoi(v)));
     if (const char* v = getenv("JXLGPU_BATCH_HEAVY")) ctx->tune.batch_heavy = (uint32_t)strtoul(v, nullptr, 0) & 31u;
     if (const char* v = getenv("JXLGPU_GUARD")) {
@@ -2143,13 +2144,13 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
         if (overlap && ctx->tune.ring_mode != 0) {
             // the border rings on the render stream itself, at full occupancy, in front of / behind the streaming kernel
             if (ctx->tune.ring_mode == 1) HIP_TRY(ctx, launch_post_batch(sp, nullptr, b, m, 0, max_ring, !ctx->tune.no_pk));
-            HIP_TRY(ctx, launch_post_batch(sp, nullptr, b, m, max_stream, 0, !ctx->tune.no_pk));
+            HIP_TRY(ctx, launch_post_batch(sp, nullptr, b, m, max_stream, 0, !ctx->tune.no_pk, ctx->tune.post_fast));
             if (ctx->tune.ring_mode == 2) HIP_TRY(ctx, launch_post_batch(sp, nullptr, b, m, 0, max_ring, !ctx->tune.no_pk));
         } else {
             // one fork / join per launch: the border rings run beside the streaming kernel
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, sp));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            HIP_TRY(ctx, launch_post_batch(sp, ctx->stream2, b, m, max_stream, max_ring, !ctx->tune.no_pk));
+            HIP_TRY(ctx, launch_post_batch(sp, ctx->stream2, b, m, max_stream, max_ring, !ctx->tune.no_pk, ctx->tune.post_fast));
             HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
             HIP_TRY(ctx, hipStreamWaitEvent(sp, ctx->ev_join, 0));
         }

@@ -225,6 +225,7 @@ struct Tuning {
                                  // LDS tile kernel of 56 VGPRs, takes the registers two post waves per SIMD leave over for ~0.65 ms and the LF
                                  // launch of the next chunk waits behind it; in front of it the transform launches start earlier but the post
                                  // launch they then share the chip with runs 20 % longer: 111 / 114-125 us per frame, mode 0 stays.)
+    bool post_fast = false;      // JXLGPU_POST_FAST: batched default pipeline through post_pk_fast_batch_kernel (NOT bit-exact: a measured option)
     uint32_t batch_heavy = 0;    // JXLGPU_BATCH_HEAVY: mask of transform families (bit F = family F, bit 4 = special 8x8) of chunk k that
                                  // run on the RENDER stream between post(k-1) and post(k) instead of on the transform stream beside
                                  // post(k-1): families whose waves do not fit beside two post waves per SIMD displace them
@@ -456,7 +457,7 @@ hipError_t launch_lf_batch(hipStream_t s, const FrameBatch& b, uint32_t n, uint3
 hipError_t launch_transform_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, const uint32_t max_wgs[4],
                                   uint32_t max_special, uint32_t mask = 31u);
 hipError_t launch_post_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, uint32_t max_stream_wgs,
-                             uint32_t max_ring, bool pk);
+                             uint32_t max_ring, bool pk, bool fast = false);
 hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs& a, const uint4* entries,
                                   const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT],
                                   uint32_t num_cus, int wgs_per_cu);
