@@ -22,7 +22,8 @@
 // granule on each side, so that an access outside the buffer is a GPU page fault with the kernel's
 // name on it (AMD_LOG_LEVEL=3) instead of a silent read of a neighbour.  Mode 1: the buffer ENDS at
 // the end of the mapping (bytes rounded up to 16: the kernels' widest access) — overruns fault;
-// mode 2: it STARTS at the start of the mapping — underruns fault.  No pooling: a freed buffer is
+// mode 2: it STARTS at the start of the mapping — underruns fault; mode 3: mode 1 with the end rounded
+// up to 4 bytes only.  No pooling: a freed buffer is
 // unmapped at once, so a use-after-free faults too.
 static hipError_t guard_malloc(jxlgpu_ctx* ctx, void** out, size_t bytes) {
     hipMemAllocationProp prop;
@@ -37,7 +38,9 @@ static hipError_t guard_malloc(jxlgpu_ctx* ctx, void** out, size_t bytes) {
         ctx->guard_gran = g ? g : 4096;
     }
     const size_t gran = ctx->guard_gran;
-    const size_t user = (bytes + 15) & ~(size_t)15;
+    // mode 3: as mode 1 with the end rounded up to 4 bytes only — an access of 4 or 8 bytes past the end of a buffer whose
+    // size is not a multiple of 16 faults too (the buffer then starts 4-byte aligned only)
+    const size_t user = ctx->guard_mode == 3 ? (bytes + 3) & ~(size_t)3 : (bytes + 15) & ~(size_t)15;
     GuardRec r;
     r.mapped = (user + gran - 1) / gran * gran;
     r.reserved = r.mapped + 2 * gran;
@@ -235,9 +238,9 @@ void ctx_defer_release(jxlgpu_ctx* ctx, std::vector<void*>&& ptrs, void* modular
     Deferred d;
     d.ptrs = std::move(ptrs);
     d.modular = modular; d.modular_free = modular_free;
-    hipStream_t st[5] = {ctx->stream, ctx->stream2, ctx->stream_up, ctx->stream_down, ctx->stream_tr};
+    hipStream_t st[6] = {ctx->stream, ctx->stream2, ctx->stream_up, ctx->stream_down, ctx->stream_tr, ctx->stream_tr2};
     bool ok = true;
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < 6; ++i) {
         d.ev[i] = ctx_event(ctx);
         ok = ok && d.ev[i] && hipEventRecord(d.ev[i], st[i]) == hipSuccess;
     }
@@ -531,11 +534,12 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     ctx->tune.debug_sync = getenv("JXLGPU_DEBUG_SYNC") != nullptr;
     ctx->tune.no_batch_overlap = getenv("JXLGPU_NO_BATCH_OVERLAP") != nullptr;
     ctx->tune.post_fast = getenv("JXLGPU_POST_FAST") != nullptr && atoi(getenv("JXLGPU_POST_FAST")) != 0;
+    if (const char* v = getenv("JXLGPU_TR_STREAMS")) ctx->tune.tr_streams = std::min(5, std::max(2, atoi(v)));
     if (const char* v = getenv("JXLGPU_RING_MODE")) ctx->tune.ring_mode = std::min(2, std::max(0, atoi(v)));
     if (const char* v = getenv("JXLGPU_BATCH_HEAVY")) ctx->tune.batch_heavy = (uint32_t)strtoul(v, nullptr, 0) & 31u;
     if (const char* v = getenv("JXLGPU_GUARD")) {
         const int m = atoi(v);
-        if (m == 1 || m == 2) ctx->guard_mode = m;
+        if (m >= 1 && m <= 3) ctx->guard_mode = m;
     }
     if (const char* v = getenv("JXLGPU_GUARD_ZERO")) ctx->guard_zero = strcmp(v, "all") == 0 ? -2 : atoi(v);
     ctx->guard_log = getenv("JXLGPU_GUARD_LOG") != nullptr;
@@ -552,6 +556,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     if (const char* v = getenv("JXLGPU_SQZ_RUNIN")) ctx->tune.sqz_runin = (uint32_t)atoi(v);
     ctx->tune.pred_wg = getenv("JXLGPU_PRED_WG") != nullptr;
     ctx->tune.pred_wide = getenv("JXLGPU_PRED_WIDE") != nullptr;
+    if (const char* v = getenv("JXLGPU_PRED_LATE_STEPS")) ctx->tune.pred_late_steps = std::max(0, atoi(v));
     ctx->tune.sqz_h_rows = getenv("JXLGPU_SQZ_H_ROWS") != nullptr;
     if (const char* v = getenv("JXLGPU_UP2_VARIANT")) ctx->tune.up2_variant = atoi(v);
     if (const char* v = getenv("JXLGPU_UP2_ROWS")) ctx->tune.up2_rows = atoi(v);
@@ -608,6 +613,8 @@ void jxlgpu_destroy(jxlgpu_ctx* ctx) {
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream_tr2) (void)hipStreamDestroy(ctx->stream_tr2);
+    for (hipStream_t q : ctx->stream_tr_extra) if (q) (void)hipStreamDestroy(q);
+    for (hipEvent_t e : ctx->ev_tr_join) if (e) (void)hipEventDestroy(e);
     if (ctx->stream_tr) (void)hipStreamDestroy(ctx->stream_tr);
     for (hipEvent_t e : ctx->ev_tr) if (e) (void)hipEventDestroy(e);
     if (ctx->stream_up) (void)hipStreamDestroy(ctx->stream_up);
@@ -630,6 +637,7 @@ int jxlgpu_synchronize(jxlgpu_ctx* ctx) {
     if (!ctx) return JXLGPU_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_up));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_tr2));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_tr));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
@@ -2111,11 +2119,33 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
         } else if ((int)m <= ctx->tune.tr_side_max) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
             hipStream_t side = overlap ? ctx->stream_tr2 : ctx->stream2;
+            if (overlap && ctx->tune.tr_streams > 2) {
+                // experiment (JXLGPU_TR_STREAMS = 3..5): every family on a stream of its own behind the LF stage, joined into `st`
+                static const uint32_t kOrder[5] = {8u, 4u, 16u, 2u, 1u};   // 64-px, 32-px, special, 16-px, 8-px
+                const int ns = std::min(5, ctx->tune.tr_streams);
+                hipStream_t pool5[5] = {st, side, nullptr, nullptr, nullptr};
+                for (int k = 2; k < ns; ++k) {
+                    if (!ctx->stream_tr_extra[k - 2]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_tr_extra[k - 2], hipStreamNonBlocking));
+                    pool5[k] = ctx->stream_tr_extra[k - 2];
+                }
+                for (int k = 1; k < ns; ++k) HIP_TRY(ctx, hipStreamWaitEvent(pool5[k], ctx->ev_fork, 0));
+                for (int i = 0; i < 5; ++i) {
+                    hipStream_t q = pool5[(4 - i) % ns];   // the 8-px family (last) stays on `st`
+                    HIP_TRY(ctx, sparse_tr ? launch_transform_batch_sparse(q, nullptr, b, m, max_wgs, max_special, kOrder[i])
+                                           : launch_transform_batch(q, nullptr, b, m, max_wgs, max_special, kOrder[i]));
+                }
+                for (int k = 1; k < ns; ++k) {
+                    if (!ctx->ev_tr_join[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_tr_join[k], hipEventDisableTiming));
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_tr_join[k], pool5[k]));
+                    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_tr_join[k], 0));
+                }
+            } else {
             HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
             HIP_TRY(ctx, sparse_tr ? launch_transform_batch_sparse(st, side, b, m, max_wgs, max_special)
                                    : launch_transform_batch(st, side, b, m, max_wgs, max_special));
             HIP_TRY(ctx, hipEventRecord(ctx->ev_join, side));
             HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+            }
         } else {
             HIP_TRY(ctx, sparse_tr ? launch_transform_batch_sparse(st, nullptr, b, m, max_wgs, max_special)
                                    : launch_transform_batch(st, nullptr, b, m, max_wgs, max_special));

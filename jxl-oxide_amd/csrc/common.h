@@ -226,6 +226,8 @@ struct Tuning {
                                  // launch of the next chunk waits behind it; in front of it the transform launches start earlier but the post
                                  // launch they then share the chip with runs 20 % longer: 111 / 114-125 us per frame, mode 0 stays.)
     bool post_fast = false;      // JXLGPU_POST_FAST: batched default pipeline through post_pk_fast_batch_kernel (NOT bit-exact: a measured option)
+    int tr_streams = 2;          // JXLGPU_TR_STREAMS: streams the transform families of a batched chunk are spread over (2: the 8 / 16-px families
+                                 // on the transform stream, the rest on its side stream; up to 5: one stream per family — an experiment)
     uint32_t batch_heavy = 0;    // JXLGPU_BATCH_HEAVY: mask of transform families (bit F = family F, bit 4 = special 8x8) of chunk k that
                                  // run on the RENDER stream between post(k-1) and post(k) instead of on the transform stream beside
                                  // post(k-1): families whose waves do not fit beside two post waves per SIMD displace them
@@ -235,6 +237,8 @@ struct Tuning {
     uint32_t sqz_runin = 1;      // JXLGPU_SQZ_RUNIN: 0 forces the Squeeze fix-up path (tests)
     bool sqz_h_rows = false;     // JXLGPU_SQZ_H_ROWS: horizontal Squeeze steps through the lane-per-row segment kernel
     bool pred_wide = false;      // JXLGPU_PRED_WIDE: the self-correcting predictor in 64-bit arithmetic only
+    int pred_late_steps = 3;     // JXLGPU_PRED_LATE_STEPS: residuals of the first so many (forward) Squeeze steps get their predictor waves on a
+                                 // side stream, beside the deep Squeeze levels; the inverse step that reads them waits (0: everything in front)
     bool pred_wg = false;        // JXLGPU_PRED_WG: predictor subgrids through the workgroup-per-subgrid kernel only
     int up2_variant = 0;         // JXLGPU_UP2_VARIANT: 1 = register-ring form of the 2x upsampling kernel, 2 = LDS ring with the
                                  // general colour code only (0: LDS ring, packed colour chain for the HDR PQ op list)
@@ -262,7 +266,7 @@ struct StageBuf {
 // frame was freed: jxlgpu_frame_free never blocks, the buffers go back to the pool once `ev` have all fired.
 struct Deferred {
     std::vector<void*> ptrs;
-    hipEvent_t ev[5] = {};
+    hipEvent_t ev[6] = {};
     void* modular = nullptr;
     void (*modular_free)(void*) = nullptr;
 };
@@ -274,6 +278,8 @@ struct jxlgpu_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: 64-pixel varblock kernels overlap the <=32 kernel
     hipStream_t stream_tr = nullptr;    // batched renders: V1-V8 of chunk k+1 beside the post stage of chunk k
+    hipStream_t stream_tr_extra[3] = {};   // JXLGPU_TR_STREAMS > 2 (created on first use; forked from / joined into stream_tr)
+    hipEvent_t ev_tr_join[5] = {};
     hipStream_t stream_tr2 = nullptr;   // ... its 32 / 64-px and special launches (forked from and joined into stream_tr: never stream2, where
                                         // the border-ring launch of chunk k would sit in front of the heavy transforms of chunk k+1)
     hipEvent_t ev_tr[8] = {};

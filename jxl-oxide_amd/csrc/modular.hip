@@ -1912,6 +1912,7 @@ struct Grid {
     // channel) and the size of the untransformed channel, which fixes the number of groups
     int hshift = 0, vshift = 0;
     uint32_t orig_w = 0, orig_h = 0;
+    int fwd_step = -1;       // residual rectangle: the (forward) Squeeze step that produced it — step 0's are the largest and the last to be consumed
 };
 
 struct ModularState {
@@ -1943,6 +1944,13 @@ struct ModularState {
     uint32_t* pred_flags = nullptr;            // per wave: left the 32-bit range (redone by the 64-bit kernel)
     void* pred_sink = nullptr;                 // 1 KB nobody reads: where off-grid lanes store
     uint32_t n_pred_vec_waves = 0;             // the first so many waves take four-sample accesses
+    // "late" subgrids: residuals of the first JXLGPU_PRED_LATE_STEPS forward Squeeze steps (the top levels: half / three
+    // quarters of the samples), consumed by the LAST inverse steps — their predictor waves run on a side stream beside the
+    // deep Squeeze levels (serial chains beside HBM-bound launches) and the first step that reads them waits for ev_late.
+    // Wave order: [early vec][early rest][late vec][late rest]
+    uint32_t n_pred_early = 0, n_pred_late_vec = 0;
+    hipEvent_t ev_late = nullptr;
+    ~ModularState() { if (ev_late) (void)hipEventDestroy(ev_late); }
     bool pred_narrow = false;
     float* fpix[3] = {};
 };
@@ -2086,6 +2094,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     // the in-place passes (predictor, RCT, palette) need a writable copy first.
     m->work[3] = m->orig;
     const bool predict = m->desc.residual_predictor <= 13;
+    bool late_pending = false;   // predictor waves of the top-level residuals still running on the side stream (ModularState::ev_late)
 
     // forward bookkeeping (transform_channel_info): which rectangle is which transformed channel
     std::vector<Grid> l;
@@ -2136,6 +2145,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     Grid& g = l[i];
                     if (g.w == 0 || g.h == 0 || g.buf < 0) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "cannot squeeze this channel");
                     Grid r = g;
+                    r.fwd_step = (int)(&st - sp.data());
                     if (g.hshift > 30 || g.vshift > 30) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "channel squeezed too much");
                     if (st.horizontal) {
                         uint32_t len = g.w; g.w = (len + 1) / 2; r.w = len / 2; r.x0 = g.x0 + g.w;
@@ -2176,6 +2186,8 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
         bool global_phase = true;
         std::vector<PredTile> tiles;
         std::unordered_map<const void*, const void*> tile_src;   // PredTile.base -> the subgrid in the read-only upload
+        std::unordered_map<const void*, int> tile_late;          // PredTile.base -> residual of one of the first `late_steps` Squeeze steps
+        const int late_steps = ctx->tune.pred_late_steps;
         uint32_t max_w = 1;
         for (size_t i = 0; i < l.size() && !m->pred_tiles; ++i) {
             const Grid& g = l[i];
@@ -2214,6 +2226,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     if (gw == 0 || gh == 0) continue;
                     tiles.push_back(PredTile{base + ((size_t)y0 * stride + x0) * esz, stride, gw, gh, lanes_ok ? 1u : 0u});
                     tile_src[tiles.back().base] = src_base + ((size_t)y0 * stride + x0) * esz;
+                    tile_late[tiles.back().base] = (lanes_ok && g.fwd_step >= 0 && g.fwd_step < late_steps) ? 1 : 0;
                     if (!lanes_ok) max_w = std::max(max_w, gw);
                 }
         }
@@ -2233,6 +2246,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             std::stable_sort(tiles.begin(), tiles.end(), [&](const PredTile& x, const PredTile& y) {
                 if (x.packed != y.packed) return x.packed < y.packed;
                 if (x.packed) {
+                    if (tile_late[x.base] != tile_late[y.base]) return tile_late[x.base] < tile_late[y.base];
                     if (vec_of(x) != vec_of(y)) return vec_of(x) > vec_of(y);
                     if (lanes_of(x) != lanes_of(y)) return lanes_of(x) > lanes_of(y);
                     if (dp_of(x) != dp_of(y)) return dp_of(x) > dp_of(y);
@@ -2247,8 +2261,9 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 const uint32_t P = lanes_of(tiles[i]), DP = dp_of(tiles[i]), T = 64 / P;
                 PredWave w{};
                 w.first = i; w.log2p = log2u(P); w.log2dp = log2u(DP); w.vec = vec_of(tiles[i]) ? 1u : 0u;
+                w.pad[0] = (uint32_t)tile_late[tiles[i].base];
                 while (i < tiles.size() && w.count < T && lanes_of(tiles[i]) == P && dp_of(tiles[i]) == DP &&
-                       (vec_of(tiles[i]) ? 1u : 0u) == w.vec) {
+                       (vec_of(tiles[i]) ? 1u : 0u) == w.vec && (uint32_t)tile_late[tiles[i].base] == w.pad[0]) {
                     w.steps = std::max(w.steps, steps_of(tiles[i]));
                     ++w.count; ++i;
                 }
@@ -2257,11 +2272,15 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             }
             // the four-sample waves first (a launch of their own), longest waves first inside each part
             std::stable_sort(waves.begin(), waves.end(), [](const PredWave& x, const PredWave& y) {
+                if (x.pad[0] != y.pad[0]) return x.pad[0] < y.pad[0];
                 if (x.vec != y.vec) return x.vec > y.vec;
                 return x.steps > y.steps;
             });
-            m->n_pred_vec_waves = 0;
-            for (const PredWave& w : waves) m->n_pred_vec_waves += w.vec;
+            m->n_pred_vec_waves = m->n_pred_early = m->n_pred_late_vec = 0;
+            for (const PredWave& w : waves) {
+                if (!w.pad[0]) { ++m->n_pred_early; m->n_pred_vec_waves += w.vec; }
+                else m->n_pred_late_vec += w.vec;
+            }
             m->n_pred_tiles = (uint32_t)tiles.size();
             m->n_pred_wide = n_wide;
             m->n_pred_waves = (uint32_t)waves.size();
@@ -2310,52 +2329,87 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 const size_t lds = (size_t)5 * m->pred_lane_err_w * 4;
                 if (m->pred_narrow) {
                     // 32-bit pass over everything, then the 64-bit kernel for the waves that left the 32-bit range (none, for
-                    // images of up to 16 bits)
-                    const uint32_t nv = m->n_pred_vec_waves, ns = m->n_pred_waves - nv;
+                    // images of up to 16 bits).  Wave ranges: [0, nv) early four-sample, [nv, ne) early rest, [ne, ne + lv) late
+                    // four-sample, [ne + lv, n) late rest.
+                    const uint32_t ne = m->n_pred_early, nv = m->n_pred_vec_waves, ns = ne - nv;
+                    const uint32_t lv = m->n_pred_late_vec, ls = m->n_pred_waves - ne - lv;
+                    auto narrow = [&](hipStream_t st, uint32_t first, uint32_t count, bool vec) {
+                        if (!count) return;
+                        if (i16) {
+                            if (vec) predict_lanes_narrow_kernel<int16_t, true><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
+                            else predict_lanes_narrow_kernel<int16_t, false><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
+                        } else {
+                            if (vec) predict_lanes_narrow_kernel<int32_t, true><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
+                            else predict_lanes_narrow_kernel<int32_t, false><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
+                        }
+                    };
+                    auto redo = [&](hipStream_t st, uint32_t first, uint32_t count, bool vec) {
+                        if (!count) return;
+                        if (i16) {
+                            if (vec) predict_lanes_kernel<int16_t, true><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
+                            else predict_lanes_kernel<int16_t, false><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
+                        } else {
+                            if (vec) predict_lanes_kernel<int32_t, true><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
+                            else predict_lanes_kernel<int32_t, false><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
+                        }
+                    };
                     // the few waves of misaligned subgrids (deep Squeeze levels: long chains, three waves of an 8K frame)
                     // run beside the others on the side stream instead of behind them
                     const bool side = nv && ns;
+                    const bool late = (lv || ls) && ctx->stream_tr2;
                     hipStream_t s2 = side ? ctx->stream2 : s;
-                    if (side) {
-                        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
-                        HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-                    }
-                    if (i16) {
-                        if (ns) predict_lanes_narrow_kernel<int16_t, false><<<ns, 64, lds, s2>>>(pa, m->pred_waves + nv, m->pred_srcs, m->pred_flags + nv);
-                        if (nv) predict_lanes_narrow_kernel<int16_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                    if (side || late) HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+                    if (late) {
+                        // the top levels' residuals: on their own stream, beside everything up to the Squeeze step that reads them
+                        hipStream_t sl = ctx->stream_tr2;
+                        if (!m->ev_late) HIP_TRY(ctx, hipEventCreateWithFlags(&m->ev_late, hipEventDisableTiming));
+                        HIP_TRY(ctx, hipStreamWaitEvent(sl, ctx->ev_fork, 0));
+                        narrow(sl, ne, lv, true);
+                        narrow(sl, ne + lv, ls, false);
+                        redo(sl, ne, lv, true);
+                        redo(sl, ne + lv, ls, false);
+                        HIP_TRY(ctx, hipEventRecord(m->ev_late, sl));
+                        late_pending = true;
                     } else {
-                        if (ns) predict_lanes_narrow_kernel<int32_t, false><<<ns, 64, lds, s2>>>(pa, m->pred_waves + nv, m->pred_srcs, m->pred_flags + nv);
-                        if (nv) predict_lanes_narrow_kernel<int32_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
+                        narrow(s, ne, lv, true);
+                        narrow(s, ne + lv, ls, false);
                     }
+                    if (side) HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+                    narrow(s2, nv, ns, false);
+                    narrow(s, 0, nv, true);
                     if (side) {
                         HIP_TRY(ctx, hipEventRecord(ctx->ev_join, s2));
                         HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
                     }
-                    // the 64-bit kernel for the waves that left the 32-bit range (none, for images of up to 16 bits)
-                    if (i16) {
-                        if (nv) predict_lanes_kernel<int16_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
-                        if (ns) predict_lanes_kernel<int16_t, false><<<ns, 64, lds, s>>>(pa, m->pred_waves + nv, m->pred_srcs, m->pred_flags + nv);
-                    } else {
-                        if (nv) predict_lanes_kernel<int32_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, m->pred_srcs, m->pred_flags);
-                        if (ns) predict_lanes_kernel<int32_t, false><<<ns, 64, lds, s>>>(pa, m->pred_waves + nv, m->pred_srcs, m->pred_flags + nv);
+                    redo(s, 0, nv, true);
+                    redo(s, nv, ns, false);
+                    if (!late) {
+                        redo(s, ne, lv, true);
+                        redo(s, ne + lv, ls, false);
                     }
                     if (ctx->tune.debug_sync) {
                         std::vector<uint32_t> fl(m->n_pred_waves);
                         HIP_TRY(ctx, hipStreamSynchronize(s));
+                        if (ctx->stream_tr2) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_tr2));
                         HIP_TRY(ctx, hipMemcpy(fl.data(), m->pred_flags, fl.size() * 4, hipMemcpyDeviceToHost));
                         size_t nfl = 0;
                         for (uint32_t v : fl) nfl += v != 0;
                         fprintf(stderr, "predictor waves redone in 64-bit arithmetic: %zu of %u\n", nfl, m->n_pred_waves);
                     }
                 } else {
-                    // any other predictor (or JXLGPU_PRED_WIDE): in place on the working copy
-                    const uint32_t nv = m->n_pred_vec_waves, ns = m->n_pred_waves - nv;
-                    if (i16) {
-                        if (nv) predict_lanes_kernel<int16_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, nullptr, nullptr);
-                        if (ns) predict_lanes_kernel<int16_t, false><<<ns, 64, lds, s>>>(pa, m->pred_waves + nv, nullptr, nullptr);
-                    } else {
-                        if (nv) predict_lanes_kernel<int32_t, true><<<nv, 64, lds, s>>>(pa, m->pred_waves, nullptr, nullptr);
-                        if (ns) predict_lanes_kernel<int32_t, false><<<ns, 64, lds, s>>>(pa, m->pred_waves + nv, nullptr, nullptr);
+                    // any other predictor (or JXLGPU_PRED_WIDE): in place on the working copy, the four wave ranges one after the other
+                    const uint32_t ne = m->n_pred_early, nv = m->n_pred_vec_waves, lv = m->n_pred_late_vec;
+                    const uint32_t first[4] = {0, nv, ne, ne + lv}, count[4] = {nv, ne - nv, lv, m->n_pred_waves - ne - lv};
+                    for (int r = 0; r < 4; ++r) {
+                        if (!count[r]) continue;
+                        const bool vec = (r & 1) == 0;
+                        if (i16) {
+                            if (vec) predict_lanes_kernel<int16_t, true><<<count[r], 64, lds, s>>>(pa, m->pred_waves + first[r], nullptr, nullptr);
+                            else predict_lanes_kernel<int16_t, false><<<count[r], 64, lds, s>>>(pa, m->pred_waves + first[r], nullptr, nullptr);
+                        } else {
+                            if (vec) predict_lanes_kernel<int32_t, true><<<count[r], 64, lds, s>>>(pa, m->pred_waves + first[r], nullptr, nullptr);
+                            else predict_lanes_kernel<int32_t, false><<<count[r], 64, lds, s>>>(pa, m->pred_waves + first[r], nullptr, nullptr);
+                        }
                     }
                 }
             }
@@ -2375,6 +2429,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     // inverse, last transform first (transform.rs:75-86)
     for (int t = (int)m->transforms.size() - 1; t >= 0; --t) {
         const JxlGpuTransform& tr = m->transforms[t];
+        if (late_pending && tr.kind != JXLGPU_TR_SQUEEZE) { HIP_TRY(ctx, hipStreamWaitEvent(s, m->ev_late, 0)); late_pending = false; }
         if (tr.kind == JXLGPU_TR_SQUEEZE) {
             const std::vector<JxlGpuSqueezeStep>& sp = m->steps[t];
             SqueezePlan plan;
@@ -2385,6 +2440,16 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 const int from = st.in_place ? end : (int)l.size() - count;
                 std::vector<Grid> res(l.begin() + from, l.begin() + from + count);
                 l.erase(l.begin() + from, l.begin() + from + count);
+                if (late_pending) {
+                    bool reads_late = false;
+                    for (const Grid& r : res) reads_late |= r.fwd_step >= 0 && r.fwd_step < ctx->tune.pred_late_steps;
+                    if (reads_late) {
+                        // (the chain of small levels queued so far is flushed first: it does not depend on the late residuals)
+                        if (i16) flush_chain<int16_t>(s, plan); else flush_chain<int32_t>(s, plan);
+                        HIP_TRY(ctx, hipStreamWaitEvent(s, m->ev_late, 0));
+                        late_pending = false;
+                    }
+                }
                 // the channels of a step are independent: up to three per launch
                 for (int k0 = 0; k0 < count; k0 += 3) {
                     const int nk = std::min(3, count - k0);
@@ -2417,6 +2482,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 }
             }
             if (i16) flush_chain<int16_t>(s, plan); else flush_chain<int32_t>(s, plan);
+            if (late_pending) { HIP_TRY(ctx, hipStreamWaitEvent(s, m->ev_late, 0)); late_pending = false; }
         } else if (tr.kind == JXLGPU_TR_RCT) {
             RctArgs a;
             for (int k = 0; k < 3; ++k) HIP_TRY(ctx, ensure_writable(l[tr.begin_c + k]));
@@ -2510,6 +2576,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
         (void)hipMemset(m->d_redo, 0, sizeof(int));
         fprintf(stderr, "[jxlgpu] squeeze lines redone serially in this run: %d\n", redo);
     }
+    if (late_pending) { HIP_TRY(ctx, hipStreamWaitEvent(s, m->ev_late, 0)); late_pending = false; }
     m->final_loc.assign(nch, 0);
     for (const Grid& g : l)
         if (g.buf >= 0 && g.x0 == 0 && g.y0 == 0 && g.w == m->cw[g.buf] && g.h == m->ch[g.buf]) m->final_loc[g.buf] = g.loc;

@@ -133,6 +133,44 @@ def test_c_caller_renders_on_the_gpu(tmp_path):
     assert r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)
 
 
+def _build_ipc_caller(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "ipc_two_process")
+    libdir = os.path.join(ROOT, "jxl-oxide_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "ipc_two_process.c"), "-o", exe, "-L", libdir, "-ljxlgpu",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+    return exe
+
+
+def test_c_ipc_caller_compiles_and_fails_loudly_without_a_gpu(tmp_path):
+    """tests/c/ipc_two_process.c: the multi-GPU plumbing (device_alloc / ipc_export / ipc_open / device destination of
+    format_output / device_download) driven from plain C by two forked processes; without a GPU both leave with the
+    'no device' code, nothing hangs."""
+    import subprocess
+    import torch
+    exe = _build_ipc_caller(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked variant")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_c_ipc_two_processes_peer_stores(tmp_path):
+    """Two C processes (no Python, no torch, no RCCL in them): the writer's formatting kernel stores through an IPC mapping
+    into the owner's buffer; the owner finds both slots identical to the frame formatted the ordinary way.  On a one-GPU
+    box both processes sit on device 0 (the same export / open / peer-store code path); JXLGPU_IPC_TEST_DEV moves the writer."""
+    import subprocess
+    import torch
+    exe = _build_ipc_caller(tmp_path)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if torch.cuda.device_count() > 1:
+        env["JXLGPU_IPC_TEST_DEV"] = "1"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)
+
+
 def test_shared_reciprocal_division_is_exact(tmp_path):
     """tests/c/sdiv_check.c: the fma chain of div3_shared (csrc/post_pk.inc) equals IEEE division in its
     guard range for every reciprocal estimate within 1 ulp — the CPU proof-by-test behind the packed post
