@@ -233,7 +233,9 @@ typedef struct {
     uint32_t num_passes;
     /* A truncated stream rendered as far as it goes (`allow_partial`, jxl-render/src/vardct/mod.rs:275-305:
      * a pass group whose decode failed part-way keeps what was decoded): with JXLGPU_COEFF_GROUPED a group
-     * may then list FEWER varblocks than its block map holds — the rest have no HF coefficients.        */
+     * may then list FEWER varblocks than its block map holds — the rest have no HF coefficients.  With several
+     * passes every (pass, group) list may stop on its own (a progressive stream cut short: later passes
+     * typically stop earlier); the device sums what each pass did deliver.                              */
     uint32_t allow_partial;
     /* frame_header.flags.use_lf_frame(): the LF image is the blended render of a previously decoded LF
      * frame (lf_level = 1), used as it is — no LF dequantisation, CfL-LF or adaptive smoothing

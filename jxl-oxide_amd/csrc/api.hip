@@ -916,7 +916,8 @@ int vardct_upload_impl(jxlgpu_ctx* ctx, const JxlGpuVardctDesc* d, const UploadO
     // progressive frames: one list set per pass, pass-major (hf_groups[p * n_groups + g])
     const uint32_t n_passes = grouped ? std::max(1u, d->num_passes) : 1u;
     if (n_passes > 11) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "more than 11 passes");  // jxl-frame/src/header.rs Passes: num_passes <= 11
-    if (n_passes > 1 && d->allow_partial) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "allow_partial with a multi-pass grouped frame");
+    // (allow_partial with several passes: every (pass, group) list may stop before its block map does, each on its own —
+    //  a truncated progressive stream, vardct/mod.rs:275-305; scan_group treats the missing varblocks of a list as empty)
     const uint32_t n_lists = n_groups * n_passes;
     std::vector<uint64_t> nz_base((size_t)n_lists + 1, 0);  // list words in front of each (pass, group)
     if (grouped) {

@@ -359,7 +359,7 @@ class VardctWorkload:
                 d.lf_frame[c] = self.lf_frame[c].ctypes.data_as(abi.f32p)
             d.lf_frame_stride = self.lf_stride
         coeff_planes = self.coeff
-        if partial is not None:
+        if partial is not None and not pass_shifts:
             # a truncated stream (allow_partial): `partial` = {group index: varblocks decoded before the stream ended}.
             # Dense transports hold what the decoder wrote: zeros for the varblocks it never reached.
             d.allow_partial = 1
@@ -383,13 +383,18 @@ class VardctWorkload:
                 # a progressive frame: pass p carries the part of every coefficient above bit pass_shifts[p] that the
                 # earlier passes have not sent (`unpack_signed(ucoeff) << coeff_shift`, hf_coeff.rs:235); the parts sum
                 # to the coefficient
-                assert pass_shifts[-1] == 0 and partial is None
+                # `partial` (a truncated progressive stream): {(pass, group): varblocks of that pass group decoded before its
+                # section ended}; what the decoder leaves is the sum of the truncated parts (progressive_truncated_coeff)
+                assert pass_shifts[-1] == 0
+                if partial is not None:
+                    d.allow_partial = 1
                 rest = self.coeff.astype(np.int64)
                 per_pass = []
-                for sft in pass_shifts:
+                for pi, sft in enumerate(pass_shifts):
                     part = (rest >> sft) << sft
                     rest = rest - part
-                    per_pass.append(self.grouped_lists(None, coeff=part.astype(np.int32)))
+                    ppart = None if partial is None else {g: k for (p, g), k in partial.items() if p == pi}
+                    per_pass.append(self.grouped_lists(ppart or None, coeff=part.astype(np.int32)))
                 n = len(per_pass[0][0])
                 hf_groups = (abi.HfGroup * (n * len(per_pass)))()
                 for pi, (hf, arrays) in enumerate(per_pass):
@@ -490,10 +495,21 @@ class VardctWorkload:
         order = np.lexsort((xs, ys, gid))          # group, then raster inside the group
         return ys[order], xs[order], gid[order]
 
-    def truncated_coeff(self, partial):
+    def progressive_truncated_coeff(self, pass_shifts, partial):
+        """The dense planes a decoder leaves for a multi-pass frame whose pass group (p, g) ended after partial[(p, g)]
+        varblocks: the sum over the passes of each pass's part, truncated per (pass, group) (hf_coeff.rs:207-244)."""
+        rest = self.coeff.astype(np.int64)
+        total = np.zeros_like(rest)
+        for pi, sft in enumerate(pass_shifts):
+            part = (rest >> sft) << sft
+            rest = rest - part
+            total += self.truncated_coeff({g: k for (p, g), k in partial.items() if p == pi}, coeff=part)
+        return total.astype(np.int32)
+
+    def truncated_coeff(self, partial, coeff=None):
         """The dense planes a decoder leaves when group g's stream ends after partial[g] varblocks."""
         ys, xs, gid = self._decode_order()
-        out = self.coeff.copy()
+        out = (self.coeff if coeff is None else coeff).copy()
         for g, keep in partial.items():
             idx = np.flatnonzero(gid == g)[keep:]
             for i in idx:

@@ -231,6 +231,39 @@ def test_progressive_passes_accumulate(gpu_ctx, oracle, size, shifts):
         f.free()
 
 
+@pytest.mark.parametrize("shifts", [[2, 0], [3, 1, 0]])
+def test_truncated_progressive_stream(gpu_ctx, oracle, shifts):
+    """`allow_partial` together with several passes (the case partial decoding exists for: a progressive stream cut
+    short): every (pass, group) section may end after any number of varblocks, later passes typically earlier.  The
+    oracle sees the sum of the truncated parts."""
+    import copy
+    w, h = 600, 520            # 3 x 3 pass groups
+    wl = VardctWorkload(w, h, seed=29, nz_fraction=0.2)
+    last = len(shifts) - 1
+    partial = {(0, 4): 61, (last, 0): 0, (last, 1): 17, (last, 4): 5, (last, 8): 10 ** 6}
+    if last > 1:
+        partial.update({(1, 1): 40, (1, 7): 0})
+    wl_sum = copy.copy(wl)
+    wl_sum.coeff = wl.progressive_truncated_coeff(shifts, partial)
+    exp, _ = oracle.vardct_render(wl_sum.desc(), S_ALL, w, h)
+    full, _ = oracle.vardct_render(wl.desc(), S_ALL, w, h)
+    assert not np.array_equal(exp.view(np.uint32), full.view(np.uint32)), "the truncation removed nothing"
+    f = gpu_ctx.vardct_upload(wl.desc(coeff_transport="grouped", pass_shifts=shifts, partial=partial))
+    try:
+        _same(gpu_ctx.vardct_render(f, S_ALL), exp, f"truncated progressive {shifts}")
+        gpu_ctx.vardct_render_batch([f], S_ALL)
+        gpu_ctx.synchronize()
+        _same(gpu_ctx.download_result(f), exp, f"truncated progressive {shifts}, batched")
+    finally:
+        f.free()
+    # without allow_partial the same lists are refused
+    from jxl_oxide_amd.runtime import JxlGpuError
+    d = wl.desc(coeff_transport="grouped", pass_shifts=shifts, partial=partial)
+    d.allow_partial = 0
+    with pytest.raises(JxlGpuError):
+        gpu_ctx.vardct_upload(d)
+
+
 def test_pass_lists_are_validated(gpu_ctx):
     from jxl_oxide_amd.runtime import JxlGpuError
     wl = VardctWorkload(264, 200, seed=5)

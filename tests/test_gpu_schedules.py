@@ -1,0 +1,119 @@
+"""The tuning switches of the batched render (csrc/common.h `Tuning`) change WHERE and WHEN launches run, never what they
+compute: under every one of them a batch must give the oracle's bits.  Also: the Modular predictor waves on the side stream
+(JXLGPU_PRED_LATE_STEPS), the guard allocator's 4-byte mode, and the one switch that is allowed to differ — JXLGPU_POST_FAST,
+a measured, non-bit-exact option, which must stay close and must stay off by default."""
+import numpy as np
+import pytest
+
+from jxl_oxide_amd import abi, runtime
+from jxl_oxide_amd.synth import VardctWorkload
+from jxl_oxide_amd.synth_modular import ModularWorkload
+
+pytestmark = pytest.mark.gpu
+
+# sizes with several strips / segments of the streaming post kernel and every transform family in the draw
+_WLS = [(776, 520, 31), (520, 776, 32), (264, 200, 33)]
+
+
+def _render_batch(ctx, wls, copies):
+    frames = [ctx.vardct_upload(w.desc(coeff_transport="grouped")) for w in wls for _ in range(copies)]
+    try:
+        for _ in range(2):   # twice: the second pass runs behind the first one's events
+            ctx.vardct_render_batch(frames, abi.STAGE_ALL)
+        ctx.synchronize()
+        return [ctx.download_result(f) for f in frames]
+    finally:
+        for f in frames:
+            f.free()
+
+
+@pytest.fixture(scope="module")
+def expected(oracle):
+    wls = [VardctWorkload(w, h, seed=s, nz_fraction=0.15) for w, h, s in _WLS]
+    exp = [oracle.vardct_render(w.desc(), abi.STAGE_ALL, w.width, w.height)[0] for w in wls]
+    return wls, exp
+
+
+@pytest.mark.parametrize("env", [
+    {},                                                   # the default schedule
+    {"JXLGPU_BATCH_STREAM_ROWS": "96"},                   # round-4 segment height
+    {"JXLGPU_BATCH_STREAM_ROWS": "32"},
+    {"JXLGPU_BATCH_CHUNK": "4"},                          # several chunks per batch: transform(k+1) beside post(k)
+    {"JXLGPU_BATCH_CHUNK": "4", "JXLGPU_BATCH_HEAVY": "24"},
+    {"JXLGPU_BATCH_CHUNK": "4", "JXLGPU_BATCH_HEAVY": "8", "JXLGPU_RING_MODE": "1"},
+    {"JXLGPU_BATCH_CHUNK": "4", "JXLGPU_BATCH_HEAVY": "31"},
+    {"JXLGPU_BATCH_CHUNK": "4", "JXLGPU_RING_MODE": "2"},
+    {"JXLGPU_BATCH_CHUNK": "4", "JXLGPU_TR_STREAMS": "5"},
+    {"JXLGPU_BATCH_CHUNK": "4", "JXLGPU_TR_STREAMS": "3", "JXLGPU_TR_SIDE_MAX": "0"},
+    {"JXLGPU_BATCH_CHUNK": "4", "JXLGPU_TR_SIDE_MAX": "0"},
+    {"JXLGPU_NO_BATCH_OVERLAP": "1"},
+], ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
+def test_every_schedule_gives_the_same_bits(expected, monkeypatch, env):
+    wls, exp = expected
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ctx = runtime.Context(0)
+    try:
+        got = _render_batch(ctx, wls, copies=3)   # 9 frames: with chunks of 4, three launches per stage
+    finally:
+        ctx.close()
+    for i, g in enumerate(got):
+        e = exp[i // 3]
+        assert np.array_equal(g.view(np.uint32), e.view(np.uint32)), (env, _WLS[i // 3])
+
+
+def test_post_fast_is_off_by_default_and_close_when_on(expected, monkeypatch):
+    """JXLGPU_POST_FAST=1 selects the non-bit-exact post kernel of the batched default pipeline (csrc/post_pk.inc): it has to
+    be asked for, and what it returns stays within 1e-4 of the oracle in display-referred sRGB (it differs by several ULP)."""
+    wls, exp = expected
+    monkeypatch.setenv("JXLGPU_POST_FAST", "1")
+    ctx = runtime.Context(0)
+    try:
+        got = _render_batch(ctx, wls[:1], copies=1)[0]
+    finally:
+        ctx.close()
+    assert not np.array_equal(got.view(np.uint32), exp[0].view(np.uint32)), "the fast kernel did not run (or became exact)"
+    assert np.nanmax(np.abs(got.astype(np.float64) - exp[0].astype(np.float64))) < 1e-4
+    monkeypatch.setenv("JXLGPU_POST_FAST", "0")
+    ctx = runtime.Context(0)
+    try:
+        got = _render_batch(ctx, wls[:1], copies=1)[0]
+    finally:
+        ctx.close()
+    assert np.array_equal(got.view(np.uint32), exp[0].view(np.uint32))
+
+
+@pytest.mark.parametrize("late", ["0", "1", "3", "9"])
+def test_predictor_waves_on_the_side_stream(oracle, monkeypatch, late):
+    """Residuals of the first JXLGPU_PRED_LATE_STEPS forward Squeeze steps are predicted on a side stream while the deep
+    levels are already being un-squeezed; the first inverse step that reads them waits.  Any split gives the same samples."""
+    monkeypatch.setenv("JXLGPU_PRED_LATE_STEPS", late)
+    ctx = runtime.Context(0)
+    try:
+        for (w, h, i16) in ((1100, 700, True), (523, 517, False)):
+            wl = ModularWorkload(w, h, kind="squeeze", lossy=True, xyb=True, residual=6, i16=i16, seed=11)
+            d = wl.desc()
+            exp = oracle.modular_inverse(d, wl.shapes(), wl.dtype)
+            f = ctx.modular_upload(d)
+            try:
+                for _ in range(2):
+                    got = ctx.modular_inverse(f, wl.shapes(), wl.dtype)
+                for c in range(len(exp)):
+                    assert np.array_equal(got[c], exp[c]), (late, w, h, c)
+            finally:
+                f.free()
+    finally:
+        ctx.close()
+
+
+def test_guard_mode_3(expected, monkeypatch):
+    """JXLGPU_GUARD=3: every device buffer ends at an unmapped page with its size rounded up to 4 bytes only."""
+    wls, exp = expected
+    monkeypatch.setenv("JXLGPU_GUARD", "3")
+    ctx = runtime.Context(0)
+    try:
+        got = _render_batch(ctx, wls[2:], copies=2)
+    finally:
+        ctx.close()
+    for g in got:
+        assert np.array_equal(g.view(np.uint32), exp[2].view(np.uint32))
