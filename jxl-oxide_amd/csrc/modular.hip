@@ -894,8 +894,10 @@ __global__ __launch_bounds__(256) void palette_kernel(PalArgs g) {
 // (predictor.rs:312-441) statement by statement; its two error rows live in LDS and are
 // overwritten in place exactly like the reference's `true_err_row` / `subpred_err_row`.
 constexpr uint32_t kPredMaxTileW = 1024;  // the self-correcting predictor's error rows live in LDS
-constexpr uint32_t kPredLaneMaxW = 512;   // widest subgrid of the lane-packed kernel (row r - 2 is 2 D <= 16 ring columns ahead)
+constexpr uint32_t kPredLaneMaxW = 1024;  // widest subgrid of the lane-packed kernel: row r - 2 is 2 D ring columns ahead, D <= 8 with the
+                                          // 16-column sample ring (subgrids up to 512 columns), D = 16 with the 64-column one (group_dim 1024)
 constexpr int kRing = 16;                 // columns per row in the LDS rings (power of two, > 6 + look-ahead)
+constexpr int kBigRing = 64;              // sample ring of the lane kernels when a subgrid is wider than 512 columns (2 D = 32 columns between rows r and r - 2)
 struct PredTile {
     void* base;              // first sample of the subgrid: residuals in, samples out (in place)
     uint32_t stride, gw, gh; // elements
@@ -1159,13 +1161,13 @@ struct PredSrc {
 // `srcs` / `wave_flags` non-null: the redo pass behind predict_lanes_narrow_kernel — only flagged waves run, and
 // they read the residuals from `srcs` (the narrow pass has written over `base`).
 // VEC: four-sample global accesses, as in predict_lanes_narrow_kernel below.
-template <typename S, bool VEC>
+template <typename S, bool VEC, int RO>
 __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const PredWave* waves, const PredSrc* srcs,
                                                            const uint32_t* wave_flags) {
     if (wave_flags && wave_flags[blockIdx.x] == 0) return;
     extern __shared__ int32_t s_err[];          // 5 x err_w words: true_err, sub_err[4]; a subgrid's columns start at slot * (err_w * P / 64)
     __shared__ uint32_t s_div[65];
-    __shared__ int32_t s_out[64][kRing + 1];    // finished samples of the lane's current / previous rows, stream position & 15
+    __shared__ int32_t s_out[64][RO + 1];    // finished samples of the lane's current / previous rows, stream position & 15
     __shared__ int32_t s_in[64][kRing + 1];     // residuals requested ahead, stream position & 15
     const PredWave wv = waves[blockIdx.x];
     const uint32_t lane = threadIdx.x;
@@ -1242,8 +1244,8 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
                 const int32_t x = (int32_t)ux;
                 const uint32_t round = (uint32_t)u >> log2dp;
                 // ring positions of column 0 of rows r, r - 1, r - 2 (stream position of their lane & 15)
-                const uint32_t ob = (round << log2dp) & (kRing - 1);
-                const uint32_t pb1 = ((round - wrap1) << log2dp) & (kRing - 1), pb2 = ((round - wrap2) << log2dp) & (kRing - 1);
+                const uint32_t ob = (round << log2dp) & (RO - 1);
+                const uint32_t pb1 = ((round - wrap1) << log2dp) & (RO - 1), pb2 = ((round - wrap2) << log2dp) & (RO - 1);
                 if (x == 0) {
                     if (r == 0) {
                         w = n = nw = 0;
@@ -1268,9 +1270,9 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
                     }
                 }
                 const bool no_prev = r == 0;
-                const int32_t ne = (no_prev || x + 1 >= (int32_t)gw) ? n : prev[(pb1 + x + 1) & (kRing - 1)];
-                const int32_t nee = (no_prev || x + 2 >= (int32_t)gw) ? ne : prev[(pb1 + x + 2) & (kRing - 1)];
-                const int32_t nn = r >= 2 ? prev2[(pb2 + x) & (kRing - 1)] : n;
+                const int32_t ne = (no_prev || x + 1 >= (int32_t)gw) ? n : prev[(pb1 + x + 1) & (RO - 1)];
+                const int32_t nee = (no_prev || x + 2 >= (int32_t)gw) ? ne : prev[(pb1 + x + 2) & (RO - 1)];
+                const int32_t nn = r >= 2 ? prev2[(pb2 + x) & (RO - 1)] : n;
                 const int32_t ww = x >= 2 ? ww2 : w;
 
                 int64_t sc_prediction = 0, subpred[4] = {0, 0, 0, 0};
@@ -1343,7 +1345,7 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
                 st_value = value;
                 st_ptr = as_global((S*)t.base + (size_t)r * t.stride + ux);
                 const int32_t sample = (int32_t)value;
-                s_out[lane][(ob + ux) & (kRing - 1)] = sample;
+                s_out[lane][(ob + ux) & (RO - 1)] = sample;
 
                 if (sc_on) {
                     const int64_t s8 = (int64_t)sample * 8;
@@ -1386,7 +1388,7 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
                         n = sample;
                     } else {
                         nw = n;
-                        n = prev[(pb1 + x + 1) & (kRing - 1)];
+                        n = prev[(pb1 + x + 1) & (RO - 1)];
                     }
                 }
             }
@@ -1423,12 +1425,12 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
 // arithmetic, set the step time (same kernel without its global accesses: 0.8 instead of 2.0 ms per 8K frame).
 // A lane's stream position is congruent to the step index modulo 4 (D is a multiple of 4), so the group boundaries
 // are compile-time positions of the unrolled loop: request + park at steps 0 and 4, store at steps 3 and 7.
-template <typename S, bool VEC>
+template <typename S, bool VEC, int RO>
 __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, const PredWave* waves, const PredSrc* srcs,
                                                                   uint32_t* wave_flags) {
     extern __shared__ int32_t s_err[];
     __shared__ uint32_t s_div[65];
-    __shared__ int32_t s_out[64][kRing + 1];
+    __shared__ int32_t s_out[64][RO + 1];
     __shared__ int32_t s_in[64][kRing + 1];
     const PredWave wv = waves[blockIdx.x];
     const uint32_t lane = threadIdx.x;
@@ -1509,8 +1511,8 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
                 const int32_t gwi = (int32_t)gw;
                 if (x == 0) {
                     const uint32_t round = (uint32_t)u >> log2dp;
-                    pb1 = ((round - wrap1) << log2dp) & (kRing - 1);
-                    pb2 = ((round - wrap2) << log2dp) & (kRing - 1);
+                    pb1 = ((round - wrap1) << log2dp) & (RO - 1);
+                    pb2 = ((round - wrap2) << log2dp) & (RO - 1);
                     if (r == 0) {
                         w = n = nw = 0;
                     } else {
@@ -1528,8 +1530,8 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
                 }
                 // LDS reads that do not depend on this step's arithmetic
                 const int32_t res = s_in[lane][u & (kRing - 1)];
-                const int32_t p_ne = prev[(pb1 + ux + 1) & (kRing - 1)];
-                const int32_t p_nn = prev2[(pb2 + ux) & (kRing - 1)];
+                const int32_t p_ne = prev[(pb1 + ux + 1) & (RO - 1)];
+                const int32_t p_nn = prev2[(pb2 + ux) & (RO - 1)];
                 const int32_t x2 = min(x + 2, gwi - 1);
                 const int32_t l_te = s_true_err[x2];
                 uint32_t l_se[4];
@@ -1571,7 +1573,7 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
                 st_value = value;
                 st_ptr = as_global((S*)t.base + (size_t)r * t.stride + ux);
                 const int32_t sample = (int32_t)value;
-                s_out[lane][u & (kRing - 1)] = sample;
+                s_out[lane][u & (RO - 1)] = sample;
 
                 const int32_t s8 = sample * 8;
                 const int32_t true_err = prediction - s8;
@@ -1952,6 +1954,7 @@ struct ModularState {
     hipEvent_t ev_late = nullptr;
     ~ModularState() { if (ev_late) (void)hipEventDestroy(ev_late); }
     bool pred_narrow = false;
+    bool pred_big_ring = false;   // a subgrid wider than 512 columns: rows trail by D = 16, the lane kernels with the 64-column sample ring
     float* fpix[3] = {};
 };
 
@@ -2267,7 +2270,8 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     w.steps = std::max(w.steps, steps_of(tiles[i]));
                     ++w.count; ++i;
                 }
-                if (DP > 256) lane_err_w = 512;
+                if (DP > 256) lane_err_w = std::max(lane_err_w, 512u);
+                if (DP > 512) { lane_err_w = 1024; m->pred_big_ring = true; }
                 waves.push_back(w);
             }
             // the four-sample waves first (a launch of their own), longest waves first inside each part
@@ -2327,31 +2331,45 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             if (m->n_pred_waves) {
                 pa.err_w = m->pred_lane_err_w;
                 const size_t lds = (size_t)5 * m->pred_lane_err_w * 4;
+                auto lanes_launch = [&](hipStream_t st, uint32_t first, uint32_t count, bool vec, const PredSrc* srcs, const uint32_t* flags) {
+                    auto go = [&](auto kern) { kern<<<count, 64, lds, st>>>(pa, m->pred_waves + first, srcs, flags); };
+                    const int sel = (i16 ? 4 : 0) | (vec ? 2 : 0) | (m->pred_big_ring ? 1 : 0);
+                    switch (sel) {
+                        case 0: go(predict_lanes_kernel<int32_t, false, kRing>); break;
+                        case 1: go(predict_lanes_kernel<int32_t, false, kBigRing>); break;
+                        case 2: go(predict_lanes_kernel<int32_t, true, kRing>); break;
+                        case 3: go(predict_lanes_kernel<int32_t, true, kBigRing>); break;
+                        case 4: go(predict_lanes_kernel<int16_t, false, kRing>); break;
+                        case 5: go(predict_lanes_kernel<int16_t, false, kBigRing>); break;
+                        case 6: go(predict_lanes_kernel<int16_t, true, kRing>); break;
+                        default: go(predict_lanes_kernel<int16_t, true, kBigRing>); break;
+                    }
+                };
                 if (m->pred_narrow) {
                     // 32-bit pass over everything, then the 64-bit kernel for the waves that left the 32-bit range (none, for
                     // images of up to 16 bits).  Wave ranges: [0, nv) early four-sample, [nv, ne) early rest, [ne, ne + lv) late
                     // four-sample, [ne + lv, n) late rest.
                     const uint32_t ne = m->n_pred_early, nv = m->n_pred_vec_waves, ns = ne - nv;
                     const uint32_t lv = m->n_pred_late_vec, ls = m->n_pred_waves - ne - lv;
+                    // kernel of a launch by (sample type, four-sample accesses, sample ring): 16 ring columns unless a subgrid is wider than 512
                     auto narrow = [&](hipStream_t st, uint32_t first, uint32_t count, bool vec) {
                         if (!count) return;
-                        if (i16) {
-                            if (vec) predict_lanes_narrow_kernel<int16_t, true><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
-                            else predict_lanes_narrow_kernel<int16_t, false><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
-                        } else {
-                            if (vec) predict_lanes_narrow_kernel<int32_t, true><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
-                            else predict_lanes_narrow_kernel<int32_t, false><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
+                        auto go = [&](auto kern) { kern<<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first); };
+                        const int sel = (i16 ? 4 : 0) | (vec ? 2 : 0) | (m->pred_big_ring ? 1 : 0);
+                        switch (sel) {
+                            case 0: go(predict_lanes_narrow_kernel<int32_t, false, kRing>); break;
+                            case 1: go(predict_lanes_narrow_kernel<int32_t, false, kBigRing>); break;
+                            case 2: go(predict_lanes_narrow_kernel<int32_t, true, kRing>); break;
+                            case 3: go(predict_lanes_narrow_kernel<int32_t, true, kBigRing>); break;
+                            case 4: go(predict_lanes_narrow_kernel<int16_t, false, kRing>); break;
+                            case 5: go(predict_lanes_narrow_kernel<int16_t, false, kBigRing>); break;
+                            case 6: go(predict_lanes_narrow_kernel<int16_t, true, kRing>); break;
+                            default: go(predict_lanes_narrow_kernel<int16_t, true, kBigRing>); break;
                         }
                     };
                     auto redo = [&](hipStream_t st, uint32_t first, uint32_t count, bool vec) {
                         if (!count) return;
-                        if (i16) {
-                            if (vec) predict_lanes_kernel<int16_t, true><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
-                            else predict_lanes_kernel<int16_t, false><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
-                        } else {
-                            if (vec) predict_lanes_kernel<int32_t, true><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
-                            else predict_lanes_kernel<int32_t, false><<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first);
-                        }
+                        lanes_launch(st, first, count, vec, m->pred_srcs, m->pred_flags + first);
                     };
                     // the few waves of misaligned subgrids (deep Squeeze levels: long chains, three waves of an 8K frame)
                     // run beside the others on the side stream instead of behind them
@@ -2400,17 +2418,8 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     // any other predictor (or JXLGPU_PRED_WIDE): in place on the working copy, the four wave ranges one after the other
                     const uint32_t ne = m->n_pred_early, nv = m->n_pred_vec_waves, lv = m->n_pred_late_vec;
                     const uint32_t first[4] = {0, nv, ne, ne + lv}, count[4] = {nv, ne - nv, lv, m->n_pred_waves - ne - lv};
-                    for (int r = 0; r < 4; ++r) {
-                        if (!count[r]) continue;
-                        const bool vec = (r & 1) == 0;
-                        if (i16) {
-                            if (vec) predict_lanes_kernel<int16_t, true><<<count[r], 64, lds, s>>>(pa, m->pred_waves + first[r], nullptr, nullptr);
-                            else predict_lanes_kernel<int16_t, false><<<count[r], 64, lds, s>>>(pa, m->pred_waves + first[r], nullptr, nullptr);
-                        } else {
-                            if (vec) predict_lanes_kernel<int32_t, true><<<count[r], 64, lds, s>>>(pa, m->pred_waves + first[r], nullptr, nullptr);
-                            else predict_lanes_kernel<int32_t, false><<<count[r], 64, lds, s>>>(pa, m->pred_waves + first[r], nullptr, nullptr);
-                        }
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if (count[r]) lanes_launch(s, first[r], count[r], (r & 1) == 0, nullptr, nullptr);
                 }
             }
         }
@@ -2602,7 +2611,7 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "residual_predictor is neither 0xFFFFFFFF nor a Predictor (0..13)");
     if (d->xyb_encoded)
         if (const char* why = color_params_unsupported(d->color)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, why);
-    if (d->residual_predictor <= 13 && d->group_dim > kPredLaneMaxW) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tiles wider than 512");
+    if (d->residual_predictor <= 13 && d->group_dim > kPredLaneMaxW) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tiles wider than 1024");
     if (d->num_transforms && !d->transforms) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null transform list");
     if (d->num_meta_channels && !d->meta_channels) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null meta channel list");
     for (uint32_t c = 0; c < d->num_meta_channels; ++c)

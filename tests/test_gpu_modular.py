@@ -126,6 +126,27 @@ def test_lane_packed_subgrid_shapes(gpu_ctx, oracle, predictor, size):
     _inverse_both(gpu_ctx, oracle, wl)
 
 
+@pytest.mark.parametrize("predictor", [6, 13, 5])
+@pytest.mark.parametrize("size", [(1100, 1060), (1024, 300), (777, 1500)])
+def test_group_dim_1024_subgrids(gpu_ctx, oracle, predictor, size):
+    """`group_dim` 1024 (jxl-frame/src/header.rs:299-301, group_size_shift 3): predictor subgrids of up to 1024 x 1024.  A
+    subgrid wider than 512 columns takes all 64 lanes of a wave with rows trailing by D = 16 columns, so row r - 2 is
+    32 ring columns ahead: the lane kernels run with the 64-column sample ring (and 1024-column error rows).  Sizes: a
+    full 1024 x 1024 subgrid with 76- and 36-wide edge subgrids beside it (mixed D in one launch), one 1024-wide
+    subgrid of 300 rows, a 777-wide one (idle columns in every round) over two rows of groups.  Random residuals,
+    device against oracle, i32 and i16 buffers, narrow (32-bit) and reference (64-bit) forms of predictor 6."""
+    w, h = size
+    wl = ModularWorkload(w, h, kind="predictor", predictor=1, i16=False, seed=3, group_dim=1024)
+    rng = np.random.default_rng(w * 17 + h + predictor)
+    wl.buffers = [rng.integers(-40, 40, size=(h, w)).astype(np.int32) for _ in range(3)]
+    wl.residual_predictor, wl.residual_multiplier, wl.residual_offset = predictor, 2, 1
+    wl.expected = None
+    _inverse_both(gpu_ctx, oracle, wl)
+    wl.sample_type, wl.dtype = abi.SAMPLE_I16, np.int16
+    wl.buffers = [b.astype(np.int16) for b in wl.buffers]
+    _inverse_both(gpu_ctx, oracle, wl)
+
+
 @pytest.mark.parametrize("amp", [40, 1 << 15, 1 << 21])
 def test_self_correcting_predictor_leaves_the_32_bit_range(oracle, amp):
     """The self-correcting predictor runs in 32-bit arithmetic while |sample| < 2^17 and |true_err| < 2^19 and is
@@ -392,6 +413,21 @@ def test_predictor_on_transformed_channels(gpu_ctx, oracle, case, size):
     the original image where the chain is lossless (residuals from the independent numpy forward)."""
     w, h = size
     wl = ModularWorkload(w, h, seed=3, **case)
+    got = _inverse_both(gpu_ctx, oracle, wl)
+    if wl.expected is not None:
+        for c in range(3):
+            assert np.array_equal(got[c], wl.expected[c]), f"channel {c} differs from the original image"
+
+
+@pytest.mark.parametrize("case", [
+    dict(kind="squeeze", lossy=False, xyb=False, residual=6),
+    dict(kind="squeeze", lossy=True, residual=6, i16=False),
+    dict(kind="squeeze", lossy=False, xyb=False, residual=5, i16=False, rct_type=6),
+])
+def test_group_dim_1024_on_squeeze_subchannels(gpu_ctx, oracle, case):
+    """`group_dim` 1024 with a Squeeze chain: the shift-0 residual sub-channels are cut into 1024-wide subgrids, the deeper
+    ones into (1024 >> shift) subgrids and 8192-sample LF groups (image.rs:258-306), all in one set of launches."""
+    wl = ModularWorkload(2100, 1100, seed=4, group_dim=1024, **case)
     got = _inverse_both(gpu_ctx, oracle, wl)
     if wl.expected is not None:
         for c in range(3):
