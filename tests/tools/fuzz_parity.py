@@ -38,6 +38,11 @@ def modular_case(rng):
         w, h = max(w, 2), max(h, 2)
     if kind == "raw":
         w, h = max(w, 9), max(h, 9)
+    if kind in ("squeeze", "palette", "gray") and rng.random() < 0.4:
+        # group_size_shift 0 / 2 / 3 (jxl-frame/src/header.rs:299-301); with 1024 sometimes a size that has subgrids wider than 512
+        kw["group_dim"] = int(rng.choice([128, 512, 1024, 1024]))
+        if kw["group_dim"] == 1024 and rng.random() < 0.5:
+            w, h = int(rng.integers(513, 2300)), int(rng.integers(300, 1300))
     return w, h, kw
 
 
@@ -81,7 +86,26 @@ def run_vardct(ctx, rng):
     shifts = None
     if transport == "grouped" and rng.random() < 0.3:   # a progressive frame: two or three passes
         shifts = [int(rng.integers(1, 5)), 0] if rng.random() < 0.5 else [int(rng.integers(3, 6)), int(rng.integers(1, 3)), 0]
-    f = ctx.vardct_upload(wl.desc(coeff_transport=transport, pass_shifts=shifts) if shifts else wl.desc(coeff_transport=transport))
+    partial = None
+    if transport == "grouped" and rng.random() < 0.3:
+        # a truncated stream (allow_partial): some pass groups end early — with several passes every (pass, group) on its own
+        import copy
+        n_groups = ((w + 255) // 256) * ((h + 255) // 256)
+        cut = {int(g): int(rng.integers(0, 200)) for g in rng.choice(n_groups, size=min(n_groups, int(rng.integers(1, 4))), replace=False)}
+        wl_t = copy.copy(wl)
+        if shifts:
+            partial = {(int(rng.integers(0, len(shifts))), g): k for g, k in cut.items()}
+            wl_t.coeff = wl.progressive_truncated_coeff(shifts, partial)
+        else:
+            partial = cut
+            wl_t.coeff = wl.truncated_coeff(partial)
+        exp, _ = pyoracle.vardct_render(wl_t.desc(), stages, ow, oh)
+    dkw = dict(coeff_transport=transport)
+    if shifts:
+        dkw["pass_shifts"] = shifts
+    if partial is not None:
+        dkw["partial"] = partial
+    f = ctx.vardct_upload(wl.desc(**dkw))
     try:
         got = ctx.vardct_render(f, stages)
         ok = np.array_equal(got.view(np.uint32), exp.view(np.uint32))
@@ -91,7 +115,7 @@ def run_vardct(ctx, rng):
         ok_r = np.array_equal(reg.view(np.uint32), np.ascontiguousarray(exp[:, ry:ry + rh, rx:rx + rw]).view(np.uint32))
     finally:
         f.free()
-    return ok and ok_r, ("vardct", w, h, dict(kw, transport=transport, passes=shifts, region=(rx, ry, rw, rh), full_ok=bool(ok)))
+    return ok and ok_r, ("vardct", w, h, dict(kw, transport=transport, passes=shifts, partial=partial, region=(rx, ry, rw, rh), full_ok=bool(ok)))
 
 
 def run_extra(ctx, rng):
