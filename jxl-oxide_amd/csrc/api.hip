@@ -536,6 +536,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     ctx->tune.post_fast = getenv("JXLGPU_POST_FAST") != nullptr && atoi(getenv("JXLGPU_POST_FAST")) != 0;
     if (const char* v = getenv("JXLGPU_TR_STREAMS")) ctx->tune.tr_streams = std::min(5, std::max(2, atoi(v)));
     if (const char* v = getenv("JXLGPU_RING_MODE")) ctx->tune.ring_mode = std::min(2, std::max(0, atoi(v)));
+    if (const char* v = getenv("JXLGPU_BATCH_TR_MULT")) ctx->tune.batch_tr_mult = std::min(4, std::max(1, atoi(v)));
     if (const char* v = getenv("JXLGPU_BATCH_HEAVY")) ctx->tune.batch_heavy = (uint32_t)strtoul(v, nullptr, 0) & 31u;
     if (const char* v = getenv("JXLGPU_GUARD")) {
         const int m = atoi(v);
@@ -2074,11 +2075,14 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
     const uint32_t chunk = ctx->tune.batch_chunk > 0 ? std::min<uint32_t>((uint32_t)ctx->tune.batch_chunk, JXLGPU_MAX_BATCH)
                                                      : (overlap ? std::min<uint32_t>(16u, JXLGPU_MAX_BATCH) : JXLGPU_MAX_BATCH);
     hipStream_t st = overlap ? ctx->stream_tr : ctx->stream, sp = ctx->stream;
-    for (uint32_t i0 = 0; i0 < n; i0 += chunk) {
-        const uint32_t m = std::min<uint32_t>(chunk, n - i0);
+    // JXLGPU_BATCH_TR_MULT = k (experiment): the LF / transform launches take k chunks at once (their tails and the serial
+    // head of their chain amortised over k times the frames), the post launches stay one chunk = one resident round of waves
+    const uint32_t tchunk = (overlap && batched) ? std::min<uint32_t>(chunk * (uint32_t)std::max(1, ctx->tune.batch_tr_mult), JXLGPU_MAX_BATCH) : chunk;
+    for (uint32_t i0 = 0; i0 < n; i0 += tchunk) {
+        const uint32_t m = std::min<uint32_t>(tchunk, n - i0);
         FrameBatch b;
         memset(&b, 0, sizeof(b));
-        uint32_t max_w8 = 0, max_h8 = 0, max_wgs[4] = {}, max_special = 0, max_stream = 0, max_ring = 0;
+        uint32_t max_w8 = 0, max_h8 = 0, max_wgs[4] = {}, max_special = 0;
         bool any_smooth = false, no_event = false;
         for (uint32_t i = 0; i < m; ++i) {
             jxlgpu_frame* f = frames[i0 + i];
@@ -2086,8 +2090,6 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
             max_w8 = std::max(max_w8, f->w8); max_h8 = std::max(max_h8, f->h8);
             for (int fam = 0; fam < 4; ++fam) max_wgs[fam] = std::max(max_wgs[fam], f->batch_wgs[fam]);
             max_special = std::max(max_special, f->list_count[CLS_SPECIAL8]);
-            max_stream = std::max(max_stream, f->batch_stream_wgs);
-            max_ring = std::max(max_ring, f->n_ring_tiles);
             any_smooth |= !f->desc.skip_adaptive_lf_smoothing;
             if (overlap && f->ev_last && f->ev_last_set) HIP_TRY(ctx, hipStreamWaitEvent(st, f->ev_last, 0));
             else if (overlap) no_event = true;   // (event creation / record failed earlier: order behind the render stream instead)
@@ -2171,26 +2173,38 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
             }
             continue;
         }
-        ctx->prof_begin(PROF_POST, sp);
-        if (overlap && ctx->tune.ring_mode != 0) {
-            // the border rings on the render stream itself, at full occupancy, in front of / behind the streaming kernel
-            if (ctx->tune.ring_mode == 1) HIP_TRY(ctx, launch_post_batch(sp, nullptr, b, m, 0, max_ring, !ctx->tune.no_pk));
-            HIP_TRY(ctx, launch_post_batch(sp, nullptr, b, m, max_stream, 0, !ctx->tune.no_pk, ctx->tune.post_fast));
-            if (ctx->tune.ring_mode == 2) HIP_TRY(ctx, launch_post_batch(sp, nullptr, b, m, 0, max_ring, !ctx->tune.no_pk));
-        } else {
-            // one fork / join per launch: the border rings run beside the streaming kernel
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, sp));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            HIP_TRY(ctx, launch_post_batch(sp, ctx->stream2, b, m, max_stream, max_ring, !ctx->tune.no_pk, ctx->tune.post_fast));
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-            HIP_TRY(ctx, hipStreamWaitEvent(sp, ctx->ev_join, 0));
-        }
-        ctx->prof_end(PROF_POST, sp);
-        for (uint32_t i = 0; i < m; ++i) {
-            jxlgpu_frame* f = frames[i0 + i];
-            for (int c = 0; c < 3; ++c) f->result[c] = f->buf_a[c];
-            f->result_stride = f->wr; f->result_w = f->width; f->result_h = f->height;
-            frame_mark(ctx, f, sp);
+        for (uint32_t j0 = 0; j0 < m; j0 += chunk) {
+            const uint32_t mp = std::min<uint32_t>(chunk, m - j0);
+            FrameBatch bp;
+            memset(&bp, 0, sizeof(bp));
+            uint32_t p_stream = 0, p_ring = 0;
+            for (uint32_t i = 0; i < mp; ++i) {
+                const jxlgpu_frame* f = frames[i0 + j0 + i];
+                bp.f[i] = f->dev_args;
+                p_stream = std::max(p_stream, f->batch_stream_wgs);
+                p_ring = std::max(p_ring, f->n_ring_tiles);
+            }
+            ctx->prof_begin(PROF_POST, sp);
+            if (overlap && ctx->tune.ring_mode != 0) {
+                // the border rings on the render stream itself, at full occupancy, in front of / behind the streaming kernel
+                if (ctx->tune.ring_mode == 1) HIP_TRY(ctx, launch_post_batch(sp, nullptr, bp, mp, 0, p_ring, !ctx->tune.no_pk));
+                HIP_TRY(ctx, launch_post_batch(sp, nullptr, bp, mp, p_stream, 0, !ctx->tune.no_pk, ctx->tune.post_fast));
+                if (ctx->tune.ring_mode == 2) HIP_TRY(ctx, launch_post_batch(sp, nullptr, bp, mp, 0, p_ring, !ctx->tune.no_pk));
+            } else {
+                // one fork / join per launch: the border rings run beside the streaming kernel
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, sp));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+                HIP_TRY(ctx, launch_post_batch(sp, ctx->stream2, bp, mp, p_stream, p_ring, !ctx->tune.no_pk, ctx->tune.post_fast));
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+                HIP_TRY(ctx, hipStreamWaitEvent(sp, ctx->ev_join, 0));
+            }
+            ctx->prof_end(PROF_POST, sp);
+            for (uint32_t i = 0; i < mp; ++i) {
+                jxlgpu_frame* f = frames[i0 + j0 + i];
+                for (int c = 0; c < 3; ++c) f->result[c] = f->buf_a[c];
+                f->result_stride = f->wr; f->result_w = f->width; f->result_h = f->height;
+                frame_mark(ctx, f, sp);
+            }
         }
     }
     HIP_TRY(ctx, hipGetLastError());

@@ -212,6 +212,7 @@ struct Tuning {
     int stream_rows = 48;        // JXLGPU_STREAM_ROWS: rows per wave segment of post_stream_kernel
     int batch_stream_rows = 0;   // JXLGPU_BATCH_STREAM_ROWS: the same for batched launches (0: one resident round of waves per launch)
     int batch_chunk = 0;         // JXLGPU_BATCH_CHUNK: > 0: frames per launch of a batch (default: JXLGPU_MAX_BATCH)
+    int batch_tr_mult = 1;       // JXLGPU_BATCH_TR_MULT: chunks per LF / transform launch of a batched render (post launches: one chunk)
     int tr_side_max = 16;        // JXLGPU_TR_SIDE_MAX: launches of <= this many frames run the big-shape transforms on the side stream
                                  // (short launches: their tails overlap; +2.7 % at 8 frames per launch, nothing at 32)
     bool no_pk = false;          // JXLGPU_NO_PK: scalar streaming kernel (one column per lane)

@@ -46,6 +46,8 @@ def expected(oracle):
     {"JXLGPU_BATCH_CHUNK": "4", "JXLGPU_TR_STREAMS": "5"},
     {"JXLGPU_BATCH_CHUNK": "4", "JXLGPU_TR_STREAMS": "3", "JXLGPU_TR_SIDE_MAX": "0"},
     {"JXLGPU_BATCH_CHUNK": "4", "JXLGPU_TR_SIDE_MAX": "0"},
+    {"JXLGPU_BATCH_CHUNK": "4", "JXLGPU_BATCH_TR_MULT": "2"},                       # transform launches of two chunks, post launches of one
+    {"JXLGPU_BATCH_CHUNK": "2", "JXLGPU_BATCH_TR_MULT": "4", "JXLGPU_TR_SIDE_MAX": "32"},
     {"JXLGPU_NO_BATCH_OVERLAP": "1"},
 ], ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
 def test_every_schedule_gives_the_same_bits(expected, monkeypatch, env):
