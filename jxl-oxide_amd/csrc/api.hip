@@ -536,6 +536,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     ctx->tune.post_fast = getenv("JXLGPU_POST_FAST") != nullptr && atoi(getenv("JXLGPU_POST_FAST")) != 0;
     if (const char* v = getenv("JXLGPU_TR_STREAMS")) ctx->tune.tr_streams = std::min(5, std::max(2, atoi(v)));
     if (const char* v = getenv("JXLGPU_RING_MODE")) ctx->tune.ring_mode = std::min(2, std::max(0, atoi(v)));
+    ctx->tune.int_post = getenv("JXLGPU_INT_POST") != nullptr && atoi(getenv("JXLGPU_INT_POST")) != 0;
     if (const char* v = getenv("JXLGPU_BATCH_TR_MULT")) ctx->tune.batch_tr_mult = std::min(4, std::max(1, atoi(v)));
     if (const char* v = getenv("JXLGPU_BATCH_HEAVY")) ctx->tune.batch_heavy = (uint32_t)strtoul(v, nullptr, 0) & 31u;
     if (const char* v = getenv("JXLGPU_GUARD")) {

@@ -151,6 +151,11 @@ struct FusedArgs {
     int sx0, sx1, sy0, sy1, rows_per_seg, strips, segs;
     uint32_t n_ring_h;       // ring tile list: the first n_ring_h tiles are 32 x 16, the rest 16 x 32
     uint32_t pk;             // the geometry is the packed kernel's (strips of 120 columns, two per lane)
+    // Modular XYB frames: in[] = the INTEGER planes of the inverse transforms in channel order (Y, X, B), in_stride in samples;
+    // the loaders convert on the fly (convert_to_float_modular_xyb, jxl-render/src/image.rs:148-189) — no float copy of the
+    // frame is made.  0: f32 input; 1: int16 planes; 2: int32 planes.  in_m = m_lf_unscaled (X, Y, B).
+    uint32_t in_int;
+    float in_m[3];
 };
 
 // Workgroups of one transform launch: class k owns workgroups [wg_begin[k], wg_begin[k + 1]).
@@ -212,6 +217,8 @@ struct Tuning {
     int stream_rows = 48;        // JXLGPU_STREAM_ROWS: rows per wave segment of post_stream_kernel
     int batch_stream_rows = 0;   // JXLGPU_BATCH_STREAM_ROWS: the same for batched launches (0: one resident round of waves per launch)
     int batch_chunk = 0;         // JXLGPU_BATCH_CHUNK: > 0: frames per launch of a batch (default: JXLGPU_MAX_BATCH)
+    bool int_post = false;       // JXLGPU_INT_POST=1: the post stage of Modular XYB frames reads the integer planes (no float copy by to_float_kernel);
+                                 // measured on config 3: 14.7 vs 15.2-15.4 GP/s (the VALU-bound post kernel pays more for the conversion than the copy costs): off
     int batch_tr_mult = 1;       // JXLGPU_BATCH_TR_MULT: chunks per LF / transform launch of a batched render (post launches: one chunk)
     int tr_side_max = 16;        // JXLGPU_TR_SIDE_MAX: launches of <= this many frames run the big-shape transforms on the side stream
                                  // (short launches: their tails overlap; +2.7 % at 8 frames per launch, nothing at 32)
@@ -349,6 +356,9 @@ struct DevBuf {
 };
 
 struct jxlgpu_frame {
+    // set around run_post_stages by the Modular render: the post stage's input planes are integers (FusedArgs::in_int / in_m)
+    uint32_t post_in_int = 0;
+    float post_in_m[3] = {0.0f, 0.0f, 0.0f};
     int kind_of_frame = 0;      // 0 = VarDCT, 1 = Modular
     // geometry
     uint32_t width = 0, height = 0, w8 = 0, h8 = 0, wr = 0, hr = 0, w64 = 0, h64 = 0;

@@ -38,10 +38,33 @@ struct PostCfg {
 // and 16 x 32 along the sides (same LDS plane size); the streaming kernels take everything inside.
 constexpr int kRingT = 16, kRingL = 32;
 
+// Modular XYB planes as the inverse transforms leave them (integers, channel order Y, X, B) -> the float sample of
+// output channel c (X, Y, B): convert_to_float_modular_xyb, jxl-render/src/image.rs:148-189 — B is stored as B - Y,
+// the sum saturates in the sample type, every channel is scaled by m_lf_unscaled.  `i`: element index of the sample.
+__device__ __forceinline__ int32_t int_plane_at(const FusedArgs& a, int plane, size_t i) {
+    return a.in_int == 1 ? (int32_t)reinterpret_cast<const int16_t*>(a.in[plane])[i] : reinterpret_cast<const int32_t*>(a.in[plane])[i];
+}
+__device__ __forceinline__ int32_t xyb_b_plus_y(uint32_t in_int, int32_t bv, int32_t yv) {
+    if (in_int == 1) {
+        const int32_t t = bv + yv;
+        return t > 32767 ? 32767 : (t < -32768 ? -32768 : t);
+    }
+    const int64_t t = (int64_t)bv + yv;
+    return t > 2147483647ll ? 2147483647 : (t < -2147483648ll ? (int32_t)-2147483648ll : (int32_t)t);
+}
+__device__ __forceinline__ float load_in_int(const FusedArgs& a, int c, size_t i) {
+    if (c == 0) return (float)int_plane_at(a, 1, i) * a.in_m[0];
+    if (c == 1) return (float)int_plane_at(a, 0, i) * a.in_m[1];
+    return (float)xyb_b_plus_y(a.in_int, int_plane_at(a, 2, i), int_plane_at(a, 0, i)) * a.in_m[2];
+}
+
 template <bool TILED>
 __device__ __forceinline__ float load_in(const FusedArgs& a, int c, int x, int y) {
     if constexpr (TILED) return a.in[0][coeff_tiled_index((uint32_t)x, (uint32_t)y, (uint32_t)c, a.in_w8)];
-    else return a.in[c][(size_t)y * a.in_stride + x];
+    else {
+        if (a.in_int) return load_in_int(a, c, (size_t)y * a.in_stride + x);
+        return a.in[c][(size_t)y * a.in_stride + x];
+    }
 }
 
 // Refill the out-of-image cells of the region [lo, LWX-lo) x [lo, LWY-lo) of `buf` (3 planes) from their
@@ -558,6 +581,21 @@ bool fused_post_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, bool gab
     return !(ctx && ctx->tune.no_fused);
 }
 
+// Can the post stage of this frame read INTEGER planes (FusedArgs::in_int)?  Exactly when launch_fused_post will take the
+// packed streaming kernel + the ring kernel: the conditions of fused_prepare's `stream` and `pk`, on the planes given.
+bool fused_int_input_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, int epf_iters, const void* const in[3],
+                               uint32_t in_stride, size_t elem) {
+    if (!ctx || ctx->tune.no_fused || ctx->tune.no_stream || ctx->tune.no_pk || !ctx->tune.int_post) return false;
+    if (epf_iters != 2 || f->width < 64 || f->height < 64 || f->width >= 65536 || f->height >= 65536) return false;
+    const JxlGpuFilterParams& fp = f->desc.filter;
+    if (!(fp.epf_channel_scale[0] >= 0 && fp.epf_channel_scale[1] >= 0 && fp.epf_channel_scale[2] >= 0 &&
+          fp.epf_border_sad_mul >= 0 && fp.epf_pass2_sigma_scale >= 0)) return false;
+    if ((in_stride & 1) || (f->wr & 1)) return false;
+    for (int c = 0; c < 3; ++c)
+        if ((reinterpret_cast<uintptr_t>(in[c]) & 7) || (elem != 2 && elem != 4) || !f->buf_a[c] || (reinterpret_cast<uintptr_t>(f->buf_a[c]) & 7)) return false;
+    return true;
+}
+
 // Fills the arguments of the fused post stage of one frame and decides whether the streaming kernel
 // applies (Gabor + 2 EPF steps on a frame with an interior; the ring-tile list is created on first
 // use).  *plain_srgb: the colour tail is the plain XYB -> sRGB list (branch-free epilogue).
@@ -615,6 +653,8 @@ hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in
     for (int c = 0; c < 3; ++c) { a.in[c] = in[c]; a.out[c] = out[c]; }
     a.in_stride = in_stride; a.out_stride = out_stride;
     a.in_w8 = in_tiled_w8;  // != 0: in[0] is the cell-tiled transform output
+    a.in_int = in_tiled_w8 ? 0u : f->post_in_int;   // integer planes of a Modular XYB frame (only with the packed streaming kernel, below)
+    for (int c = 0; c < 3; ++c) a.in_m[c] = f->post_in_m[c];
     a.width = (int)f->width; a.height = (int)f->height;
     a.sigma = f->sigma; a.sigma_stride = f->w8;
     a.fp = f->desc.filter;
@@ -738,6 +778,8 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
     e = fused_prepare(ctx, f, in, in_stride, in_tiled_w8, out, out_stride, gabor, epf_iters, color, &a, &stream,
                       &plain_srgb, 0);
     if (e != hipSuccess) return e;
+    // integer input is read by the packed streaming kernel and the ring kernel only (fused_int_input_supported said so)
+    if (a.in_int && !(stream && a.pk)) return hipErrorInvalidValue;
     if (!stream) {
         if (!rc) return launch_tile_kernel(s, a, gabor, epf_iters, dim3(ceil_div(f->width, T), ceil_div(f->height, T)));
         const std::vector<uint32_t> tl = grid_tiles(*rc, T, T);

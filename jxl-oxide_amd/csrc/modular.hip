@@ -27,6 +27,7 @@
 bool clip_region(const JxlGpuRegion* r, uint32_t w, uint32_t h, PixRect* out);
 int finish_render_region(jxlgpu_ctx* ctx, jxlgpu_frame* f, float* cur[3], uint32_t stride, const PixRect& r, const JxlGpuOut* out);
 bool fused_post_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, bool gabor, int epf_iters);
+bool fused_int_input_supported(const jxlgpu_ctx* ctx, const jxlgpu_frame* f, int epf_iters, const void* const in[3], uint32_t in_stride, size_t elem);
 int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const JxlGpuFilterParams& fp,
                     uint32_t up_factor, float* cur[3], uint32_t* cur_stride, uint32_t* ow, uint32_t* oh,
                     bool tiled_in, const PixRect* region);
@@ -2817,12 +2818,24 @@ static int modular_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages
     a.out_stride = f->wr; a.width = f->width; a.height = f->height;
     a.xyb = m->desc.xyb_encoded; a.is_i16 = m->desc.sample_type == JXLGPU_SAMPLE_I16;
     a.bit_depth = m->desc.bit_depth; a.float_sample = m->desc.float_sample; a.exp_bits = m->desc.exp_bits;
-    to_float_kernel<<<dim3(ceil_div(f->width, 256), f->height), 256, 0, ctx->stream>>>(a);
+    // JXLGPU_INT_POST=1 (measured option, off by default): XYB frames whose post stage is the packed streaming kernel (Gabor /
+    // EPF iters 2: BASELINE config 3): that kernel and the border-ring kernel read the INTEGER planes and convert on the fly —
+    // no float copy of the frame (12 B/px written + read).  Bit-identical; 4 % slower on config 3 (the copy is HBM-bound and
+    // cheap, the conversion lands in a VALU-bound kernel)
+    const int epf_iters_run = (stages & JXLGPU_STAGE_EPF) ? (int)f->desc.filter.epf_iters : 0;
+    const bool int_post = a.xyb && !gray && !subsampled && !region_in && a.in_stride[0] == a.in_stride[1] && a.in_stride[0] == a.in_stride[2] &&
+                          fused_int_input_supported(ctx, f, epf_iters_run, a.in, a.in_stride[0], m->esz);
+    if (!int_post) to_float_kernel<<<dim3(ceil_div(f->width, 256), f->height), 256, 0, ctx->stream>>>(a);
     for (int c = 0; c < 3 && subsampled; ++c)
         if (hs[c] || vs[c])
             launch_upsample_jpeg_rows(ctx->stream, f->buf_a[c], f->wr, m->cw[c], m->ch[c], hs[c], vs[c], m->fpix[c], f->wr, f->width, f->height);
     float* cur[3] = {m->fpix[0], m->fpix[1], m->fpix[2]};
     uint32_t stride = f->wr, ow = f->width, oh = f->height;
+    if (int_post) {
+        for (int c = 0; c < 3; ++c) { cur[c] = reinterpret_cast<float*>(const_cast<void*>(a.in[c])); f->post_in_m[c] = a.m[c]; }
+        stride = a.in_stride[0];
+        f->post_in_int = a.is_i16 ? 1u : 2u;
+    }
     ctx->prof_begin(PROF_POST);
     PixRect region{0, 0, 0, 0};
     bool cut = false;
@@ -2836,6 +2849,7 @@ static int modular_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages
     }
     rc = run_post_stages(ctx, f, stages, f->desc.filter, f->desc.upsampling.factor ? f->desc.upsampling.factor : 1,
                          cur, &stride, &ow, &oh, false, cut ? &region : nullptr);
+    f->post_in_int = 0;
     ctx->prof_end(PROF_POST);
     if (rc) return rc;
     if (region_in) return finish_render_region(ctx, f, cur, stride, region, out);

@@ -244,6 +244,40 @@ def test_render_xyb_tail(gpu_ctx, oracle, cfg):
     assert_ulp(got, exp, 1, f"modular render {cfg}")
 
 
+@pytest.mark.parametrize("i16", [True, False])
+@pytest.mark.parametrize("gabor", [False, True])
+@pytest.mark.parametrize("size", [(520, 300), (200, 136), (331, 260)])
+def test_post_stage_reads_the_integer_planes(oracle, monkeypatch, size, gabor, i16):
+    """JXLGPU_INT_POST=1 (a measured option, off by default: 4 % slower on config 3): XYB Modular frames with EPF iters 2 — the
+    packed streaming post kernel and the border-ring kernel read the integer planes of the inverse transforms and convert on
+    the fly (convert_to_float_modular_xyb, jxl-render/src/image.rs:148-189: B + Y saturating in the sample type, times
+    m_lf_unscaled) instead of reading a float copy made by to_float_kernel.  The same bits as the oracle and as the default
+    float-copy path; an odd plane stride (331) takes the float copy either way."""
+    from jxl_oxide_amd import runtime
+    w, h = size
+    wl = ModularWorkload(w, h, kind="squeeze", lossy=True, i16=i16, epf_iters=2, gabor=gabor, seed=w + h)
+    d = wl.desc()
+    stages = abi.STAGE_ALL | abi.STAGE_MODULAR_TO_FLOAT
+    exp = oracle.modular_render(d, stages, w, h)
+    got = {}
+    for mode in ("float", "int"):
+        if mode == "int":
+            monkeypatch.setenv("JXLGPU_INT_POST", "1")
+        ctx = runtime.Context(0)
+        try:
+            f = ctx.modular_upload(d)
+            try:
+                got[mode] = ctx.modular_render(f, stages)
+                again = ctx.modular_render(f, stages)
+            finally:
+                f.free()
+        finally:
+            ctx.close()
+        assert np.array_equal(again.view(np.uint32), got[mode].view(np.uint32)), f"{mode}: second render differs"
+    assert np.array_equal(got["int"].view(np.uint32), got["float"].view(np.uint32)), "integer-input post stage differs from the float-copy path"
+    assert np.array_equal(got["int"].view(np.uint32), exp.view(np.uint32)), "post stage differs from the oracle"
+
+
 @pytest.mark.parametrize("kind", ["squeeze", "lossless_rgb8"])
 def test_render_with_noise(gpu_ctx, oracle, kind):
     """Noise on Modular frames: base correlations (0, 1) (noise.rs:35), on XYB and on plain RGB."""
