@@ -551,7 +551,7 @@ typedef struct {
     int32_t residual_multiplier; /* MaTreeLeafClustered.multiplier (1 for a default leaf)            */
     int32_t residual_offset;     /* MaTreeLeafClustered.offset                                       */
     int32_t wp_params[11];       /* WpHeader: p1, p2, p3a..p3e, w0..w3 (predictor.rs:8-21)           */
-    uint32_t group_dim;
+    uint32_t group_dim;          /* frame_header.group_dim(): 128, 256, 512 or 1024 (0 = 256)         */
     /* what happens after the inverse transforms (jxl-render/src/image.rs:93-189) */
     uint32_t xyb_encoded;        /* 1: convert_modular_xyb (M5); 0: int -> float by bit depth (C5)    */
     float m_lf_unscaled[3];      /* m_x_lf/128, m_y_lf/128, m_b_lf/128 (lf.rs:37-50)                  */
