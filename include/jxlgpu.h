@@ -302,7 +302,8 @@ void jxlgpu_host_free(jxlgpu_ctx* ctx, void* p);
  * to a byte budget and fails with OutOfMemory beyond it).  `limit_bytes` bounds the device memory the ctx's FRAMES may
  * hold at one time (live buffers; recycled buffers waiting in the ctx's pool are given back first and do not count);
  * an upload or render that would exceed it fails with JXLGPU_ERR_OOM and leaves the ctx usable.  0 = no limit (the
- * default).  jxlgpu_memory_usage reports the bytes held by live frames and by the pool.                            */
+ * default).  jxlgpu_memory_usage reports the bytes held by live frames and by the pool.  Outside the budget: buffers the
+ * caller owns (jxlgpu_device_alloc, jxlgpu_host_alloc) and the ctx's pinned staging arenas (host memory).            */
 int jxlgpu_set_memory_limit(jxlgpu_ctx* ctx, uint64_t limit_bytes);
 int jxlgpu_memory_usage(const jxlgpu_ctx* ctx, uint64_t* live_bytes, uint64_t* pooled_bytes);
 /* Measurement hook: where the host time of the ctx's last jxlgpu_vardct_upload went, in milliseconds —
