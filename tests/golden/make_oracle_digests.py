@@ -37,6 +37,15 @@ def cases():
         wl = ModularWorkload(**kw)
         return lambda: wl_planes(pyoracle.modular_inverse(wl.desc(), wl.shapes(), wl.dtype))
 
+    def truncated():
+        import copy
+        wl = VardctWorkload(width=600, height=520, seed=12, nz_fraction=0.2)
+        shifts = [3, 1, 0]
+        partial = {(0, 4): 61, (1, 1): 40, (1, 7): 0, (2, 0): 0, (2, 1): 17, (2, 4): 5}
+        wl_sum = copy.copy(wl)
+        wl_sum.coeff = wl.progressive_truncated_coeff(shifts, partial)
+        return lambda: pyoracle.vardct_render(wl_sum.desc(), S, 600, 520)[0]
+
     def wl_planes(planes):
         import numpy as np
         return np.concatenate([np.ascontiguousarray(p).reshape(-1).astype(np.int64) for p in planes])
@@ -52,6 +61,10 @@ def cases():
         "modular_squeeze_i16_200x136": modular(width=200, height=136, kind="squeeze", lossy=True, i16=True, seed=8),
         "modular_predictor6_70x33": modular(width=70, height=33, kind="predictor", predictor=6, i16=False, seed=9),
         "modular_palette_delta_37x21": modular(width=37, height=21, kind="palette_delta", predictor=5, i16=True, seed=10),
+        # round 5: group_dim 1024 (subgrids wider than 512 columns; Squeeze sub-channels carved on the 1024 grid) and the sum a
+        # truncated progressive stream leaves (allow_partial with several passes)
+        "modular_squeeze_wp_gd1024_1100x600": modular(width=1100, height=600, kind="squeeze", lossy=False, xyb=False, residual=6, seed=11, group_dim=1024),
+        "vardct_truncated_progressive_600x520": truncated(),
     }
 
 
