@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 21u
+#define JXLGPU_ABI_VERSION 22u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -516,6 +516,13 @@ typedef struct {
     uint32_t width, height;
 } JxlGpuModularChannel;
 
+/* The MA-tree leaf of ONE decode unit (a (group, channel) subgrid), without its entropy-coding cluster:
+ * MaTreeLeafClustered { predictor, offset, multiplier } (jxl-modular/src/ma.rs).                     */
+typedef struct {
+    uint32_t predictor;          /* Predictor id 0..13 (jxl-modular/src/predictor.rs:26-41)          */
+    int32_t multiplier, offset;
+} JxlGpuMaLeaf;
+
 typedef struct {
     uint32_t abi;
     uint32_t sample_type;        /* JXLGPU_SAMPLE_I16 / I32 (modular_16bit_buffers)                  */
@@ -562,6 +569,20 @@ typedef struct {
     JxlGpuUpsampling upsampling;
     JxlGpuNoiseParams noise;
     JxlGpuColorParams color;
+    /* Per-unit leaves (optional).  The reference specialises the MA tree for every decode unit before it decodes it:
+     * `make_flat_tree(channel, stream_index, prev_channels)` (jxl-modular/src/ma.rs:38-41, image.rs:477-490) resolves the
+     * decisions on the static properties 0 (channel index) and 1 (stream index), so a tree that splits on those two only is
+     * a SINGLE NODE for every unit — with that unit's own predictor / multiplier / offset — and takes decode_single_node
+     * (image.rs:553-562, 716-777).  Nothing in such a tree depends on decoded samples, so the entropy decode is still
+     * separable.  num_unit_leaves = 0: every unit uses residual_predictor / residual_multiplier / residual_offset above.
+     * Otherwise residuals are present whatever residual_predictor says, and `unit_leaves` has one entry per unit, in this
+     * order: the TRANSFORMED channels in list order (meta channels first), channels with a zero dimension skipped; a
+     * channel decoded whole (GlobalModular) is one unit; a grouped channel contributes ncols x nrows units in raster order
+     * (gy * ncols + gx) where ncols / nrows = ceil(original size / group_dim), or / (8 group_dim) once both shifts reach 3
+     * (image.rs:258-306) — subgrids that fall outside the (smaller) transformed channel are counted too and ignored.  A
+     * wrong count is JXLGPU_ERR_INVALID_ARG at the first inverse.  The array is copied by jxlgpu_modular_upload.       */
+    const JxlGpuMaLeaf* unit_leaves;
+    uint32_t num_unit_leaves;
 } JxlGpuModularDesc;
 
 #define JXLGPU_STAGE_MODULAR_INVERSE 0x02u /* same bit as TRANSFORM: inverse Squeeze/RCT/Palette    */

@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -261,6 +261,10 @@ class ModularChannel(C.Structure):
     _fields_ = [("data", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
+class MaLeaf(C.Structure):
+    _fields_ = [("predictor", C.c_uint32), ("multiplier", C.c_int32), ("offset", C.c_int32)]
+
+
 class ModularDesc(C.Structure):
     _fields_ = [
         ("abi", C.c_uint32),
@@ -286,6 +290,8 @@ class ModularDesc(C.Structure):
         ("upsampling", Upsampling),
         ("noise", NoiseParams),
         ("color", ColorParams),
+        ("unit_leaves", C.POINTER(MaLeaf)),
+        ("num_unit_leaves", C.c_uint32),
     ]
 
 

@@ -903,13 +903,16 @@ struct PredTile {
     void* base;              // first sample of the subgrid: residuals in, samples out (in place)
     uint32_t stride, gw, gh; // elements
     uint32_t packed;         // 1: handled by the lane-packed kernel (P lanes of a wave), 0: a workgroup of its own
+    // the unit's MA-tree leaf (MaTreeLeafClustered without its cluster): the frame's one leaf, or the unit's own
+    // (JxlGpuModularDesc::unit_leaves: trees that split on the static properties channel / stream index, make_flat_tree)
+    uint32_t predictor;
+    int32_t mul, off;
+    uint32_t pad;
 };
 struct PredArgs {
     const PredTile* tiles;
     void* sink;              // 64 samples nobody reads: where off-grid lanes of the one-wave kernels store
     uint32_t err_w;          // columns of the error rows in dynamic LDS (>= the widest subgrid; 1 when unused)
-    uint32_t predictor;
-    int32_t mul, off;
     int32_t wp[11];
 };
 
@@ -933,7 +936,8 @@ __global__ __launch_bounds__(256) void predict_tiles_kernel(PredArgs a) {
     const uint32_t r = threadIdx.x;
     S* row = (S*)t.base + (size_t)r * t.stride;
     const bool have_row = r < gh;
-    const bool sc_on = a.predictor == 6;
+    const uint32_t predictor = t.predictor;   // one subgrid per workgroup: uniform
+    const bool sc_on = predictor == 6;
     for (uint32_t i = r; i < 5 * a.err_w; i += 256) s_err[i] = 0;
     __syncthreads();
     const int32_t* prev = s_out[r > 0 ? r - 1 : 0];
@@ -1030,7 +1034,7 @@ __global__ __launch_bounds__(256) void predict_tiles_kernel(PredArgs a) {
                     int32_t pred;
                     {
                         const int64_t N = n, W = w, NW = nw;
-                        switch (a.predictor) {
+                        switch (predictor) {
                             case 0: pred = 0; break;
                             case 1: pred = w; break;
                             case 2: pred = n; break;
@@ -1059,7 +1063,7 @@ __global__ __launch_bounds__(256) void predict_tiles_kernel(PredArgs a) {
                     }
                     // decode_one: diff = residual.wrapping_muladd_i32(multiplier, offset); diff.add(prediction)
                     const S res = (S)s_in[r][x & (kRing - 1)];
-                    const S diff = Wrap<S>::add(Wrap<S>::mul(res, (S)a.mul), (S)a.off);
+                    const S diff = Wrap<S>::add(Wrap<S>::mul(res, (S)t.mul), (S)t.off);
                     const S value = Wrap<S>::add(diff, (S)pred);
                     row[x] = value;
                     const int32_t sample = (int32_t)value;
@@ -1188,7 +1192,9 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
     s_div[lane] = div_lookup_dev(lane);
     if (lane == 0) s_div[64] = div_lookup_dev(64);
     __syncthreads();
-    const bool sc_on = a.predictor == 6;
+    // the subgrids of a wave share their predictor (the host forms waves by it); multiplier and offset are the subgrid's own
+    const uint32_t predictor = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tiles[wv.first].predictor);
+    const bool sc_on = predictor == 6;
     // rows r - 1 and r - 2 live in the rings of lanes k - 1 and k - 2 (mod P), one round back where the index wrapped
     const uint32_t lane0 = lane & ~(P - 1);
     uint32_t wrap1 = 0, wrap2 = 0;
@@ -1313,7 +1319,7 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
                 int32_t pred;
                 {
                     const int64_t N = n, W = w, NW = nw;
-                    switch (a.predictor) {
+                    switch (predictor) {
                         case 0: pred = 0; break;
                         case 1: pred = w; break;
                         case 2: pred = n; break;
@@ -1341,7 +1347,7 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
                     }
                 }
                 const S res = (S)s_in[lane][u & (kRing - 1)];
-                const S diff = Wrap<S>::add(Wrap<S>::mul(res, (S)a.mul), (S)a.off);
+                const S diff = Wrap<S>::add(Wrap<S>::mul(res, (S)t.mul), (S)t.off);
                 const S value = Wrap<S>::add(diff, (S)pred);
                 st_value = value;
                 st_ptr = as_global((S*)t.base + (size_t)r * t.stride + ux);
@@ -1569,7 +1575,7 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
                     prediction = prediction < mn ? mn : (prediction > mx ? mx : prediction);
                 }
                 const int32_t pred = (prediction + 3) >> 3;
-                const S diff = Wrap<S>::add(Wrap<S>::mul((S)res, (S)a.mul), (S)a.off);
+                const S diff = Wrap<S>::add(Wrap<S>::mul((S)res, (S)t.mul), (S)t.off);
                 const S value = Wrap<S>::add(diff, (S)pred);
                 st_value = value;
                 st_ptr = as_global((S*)t.base + (size_t)r * t.stride + ux);
@@ -1955,6 +1961,7 @@ struct ModularState {
     hipEvent_t ev_late = nullptr;
     ~ModularState() { if (ev_late) (void)hipEventDestroy(ev_late); }
     bool pred_narrow = false;
+    std::vector<JxlGpuMaLeaf> unit_leaves;   // copy of JxlGpuModularDesc::unit_leaves (empty: the frame's one leaf)
     bool pred_big_ring = false;   // a subgrid wider than 512 columns: rows trail by D = 16, the lane kernels with the 64-column sample ring
     float* fpix[3] = {};
 };
@@ -2097,7 +2104,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
     // are and writes the merged one into a working copy, so nothing has to be copied up front.  Only
     // the in-place passes (predictor, RCT, palette) need a writable copy first.
     m->work[3] = m->orig;
-    const bool predict = m->desc.residual_predictor <= 13;
+    const bool predict = m->desc.residual_predictor <= 13 || !m->unit_leaves.empty();
     bool late_pending = false;   // predictor waves of the top-level residuals still running on the side stream (ModularState::ev_late)
 
     // forward bookkeeping (transform_channel_info): which rectangle is which transformed channel
@@ -2193,6 +2200,11 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
         std::unordered_map<const void*, int> tile_late;          // PredTile.base -> residual of one of the first `late_steps` Squeeze steps
         const int late_steps = ctx->tune.pred_late_steps;
         uint32_t max_w = 1;
+        // per-unit leaves: units in the order of JxlGpuModularDesc::unit_leaves — channels in list order, ncols x nrows subgrids
+        // each (the ones outside the channel included), one for a channel decoded whole
+        size_t unit_base = 0;
+        bool any_wp = false, all_wp = true;
+        const JxlGpuMaLeaf one_leaf{m->desc.residual_predictor, m->desc.residual_multiplier, m->desc.residual_offset};
         for (size_t i = 0; i < l.size() && !m->pred_tiles; ++i) {
             const Grid& g = l[i];
             if (g.w == 0 || g.h == 0) continue;
@@ -2215,8 +2227,14 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             // subgrids up to kPredLaneMaxW columns take the lane-packed kernel (any height); wider ones the
             // workgroup-per-subgrid kernel: a lane per row, at most 256 rows
             const bool lanes_ok = !ctx->tune.pred_wg && tw <= kPredLaneMaxW;
-            if (!lanes_ok && (th > 256 || (m->desc.residual_predictor == 6 && tw > kPredMaxTileW)))
-                return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tile wider than 512 columns with more than 256 rows (or wider than 1024 with the self-correcting predictor)");
+            if (!m->unit_leaves.empty() && unit_base + (size_t)ncols * nrows > m->unit_leaves.size())
+                return fail(ctx, JXLGPU_ERR_INVALID_ARG, "num_unit_leaves is smaller than the number of decode units");
+            const JxlGpuMaLeaf* leaves = m->unit_leaves.empty() ? nullptr : m->unit_leaves.data() + unit_base;
+            unit_base += (size_t)ncols * nrows;
+            bool chan_wp = !leaves && one_leaf.predictor == 6;
+            for (size_t u = 0; leaves && u < (size_t)ncols * nrows; ++u) chan_wp |= leaves[u].predictor == 6;
+            if (!lanes_ok && (th > 256 || (chan_wp && tw > kPredMaxTileW)))
+                return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tile wider than 1024 columns with more than 256 rows (or wider than 1024 with the self-correcting predictor)");
             uint32_t stride = 0;
             char* base = ptr(g, 0, &stride);
             // the same rectangle in the read-only upload (what the narrow kernel reads)
@@ -2228,12 +2246,17 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     const uint32_t x0 = std::min(gx * tw, g.w), y0 = std::min(gy * th, g.h);
                     const uint32_t gw = std::min(tw, g.w - x0), gh = std::min(th, g.h - y0);
                     if (gw == 0 || gh == 0) continue;
-                    tiles.push_back(PredTile{base + ((size_t)y0 * stride + x0) * esz, stride, gw, gh, lanes_ok ? 1u : 0u});
+                    const JxlGpuMaLeaf& lf = leaves ? leaves[(size_t)gy * ncols + gx] : one_leaf;
+                    any_wp |= lf.predictor == 6; all_wp &= lf.predictor == 6;
+                    tiles.push_back(PredTile{base + ((size_t)y0 * stride + x0) * esz, stride, gw, gh, lanes_ok ? 1u : 0u,
+                                             lf.predictor, lf.multiplier, lf.offset, 0u});
                     tile_src[tiles.back().base] = src_base + ((size_t)y0 * stride + x0) * esz;
                     tile_late[tiles.back().base] = (lanes_ok && g.fwd_step >= 0 && g.fwd_step < late_steps) ? 1 : 0;
                     if (!lanes_ok) max_w = std::max(max_w, gw);
                 }
         }
+        if (!m->pred_tiles && !m->unit_leaves.empty() && unit_base != m->unit_leaves.size())
+            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "num_unit_leaves is not the number of decode units");
         if (!m->pred_tiles) {
             auto pow2ceil = [](uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; };
             auto log2u = [](uint32_t v) { uint32_t l = 0; while ((1u << l) < v) ++l; return l; };
@@ -2254,6 +2277,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     if (vec_of(x) != vec_of(y)) return vec_of(x) > vec_of(y);
                     if (lanes_of(x) != lanes_of(y)) return lanes_of(x) > lanes_of(y);
                     if (dp_of(x) != dp_of(y)) return dp_of(x) > dp_of(y);
+                    if (x.predictor != y.predictor) return x.predictor < y.predictor;   // a wave's subgrids share their predictor
                 }
                 return steps_of(x) > steps_of(y);
             });
@@ -2266,7 +2290,8 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 PredWave w{};
                 w.first = i; w.log2p = log2u(P); w.log2dp = log2u(DP); w.vec = vec_of(tiles[i]) ? 1u : 0u;
                 w.pad[0] = (uint32_t)tile_late[tiles[i].base];
-                while (i < tiles.size() && w.count < T && lanes_of(tiles[i]) == P && dp_of(tiles[i]) == DP &&
+                const uint32_t wave_pred = tiles[i].predictor;
+                while (i < tiles.size() && w.count < T && lanes_of(tiles[i]) == P && dp_of(tiles[i]) == DP && tiles[i].predictor == wave_pred &&
                        (vec_of(tiles[i]) ? 1u : 0u) == w.vec && (uint32_t)tile_late[tiles[i].base] == w.pad[0]) {
                     w.steps = std::max(w.steps, steps_of(tiles[i]));
                     ++w.count; ++i;
@@ -2289,12 +2314,13 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             m->n_pred_tiles = (uint32_t)tiles.size();
             m->n_pred_wide = n_wide;
             m->n_pred_waves = (uint32_t)waves.size();
-            m->pred_err_w = m->desc.residual_predictor == 6 ? max_w : 1;
-            m->pred_lane_err_w = m->desc.residual_predictor == 6 ? lane_err_w : 64;
+            m->pred_err_w = any_wp ? max_w : 1;
+            m->pred_lane_err_w = any_wp ? lane_err_w : 64;
             // the 32-bit form of the self-correcting predictor: WpHeader fields in their coded ranges (5 / 4 bits)
             bool wp_coded = true;
             for (int k = 0; k < 11; ++k) wp_coded &= m->desc.wp_params[k] >= 0 && m->desc.wp_params[k] < (k < 7 ? 32 : 16);
-            m->pred_narrow = m->desc.residual_predictor == 6 && wp_coded && !ctx->tune.pred_wide && !waves.empty();
+            // (the 32-bit kernel is the self-correcting predictor only: every unit has to use it)
+            m->pred_narrow = any_wp && all_wp && wp_coded && !ctx->tune.pred_wide && !waves.empty();
             std::vector<PredSrc> srcs(tiles.size());
             for (size_t i = 0; i < tiles.size(); ++i) srcs[i].src = tile_src[tiles[i].base];
             if (int rc = malloc_dev(ctx, f, &m->pred_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(PredTile))) return rc;
@@ -2320,8 +2346,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
         }
         if (m->n_pred_tiles) {
             PredArgs pa;
-            pa.tiles = m->pred_tiles; pa.sink = m->pred_sink; pa.predictor = m->desc.residual_predictor;
-            pa.mul = m->desc.residual_multiplier; pa.off = m->desc.residual_offset;
+            pa.tiles = m->pred_tiles; pa.sink = m->pred_sink;
             for (int k = 0; k < 11; ++k) pa.wp[k] = m->desc.wp_params[k];
             if (m->n_pred_wide) {
                 pa.err_w = m->pred_err_w;
@@ -2612,7 +2637,10 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "residual_predictor is neither 0xFFFFFFFF nor a Predictor (0..13)");
     if (d->xyb_encoded)
         if (const char* why = color_params_unsupported(d->color)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, why);
-    if (d->residual_predictor <= 13 && d->group_dim > kPredLaneMaxW) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tiles wider than 1024");
+    if ((d->residual_predictor <= 13 || d->num_unit_leaves) && d->group_dim > kPredLaneMaxW) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tiles wider than 1024");
+    if (d->num_unit_leaves && !d->unit_leaves) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null unit_leaves");
+    for (uint32_t i = 0; i < d->num_unit_leaves; ++i)
+        if (d->unit_leaves[i].predictor > 13) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "a unit leaf's predictor is not a Predictor (0..13)");
     if (d->num_transforms && !d->transforms) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null transform list");
     if (d->num_meta_channels && !d->meta_channels) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null meta channel list");
     for (uint32_t c = 0; c < d->num_meta_channels; ++c)
@@ -2651,6 +2679,8 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
         ~Guard() { if (armed) jxlgpu_frame_free(c, f); }
     } guard{ctx, f};
     m->desc = *d;
+    if (d->num_unit_leaves) m->unit_leaves.assign(d->unit_leaves, d->unit_leaves + d->num_unit_leaves);
+    m->desc.unit_leaves = nullptr;   // (the caller's array may be gone after this call)
     m->esz = d->sample_type == JXLGPU_SAMPLE_I16 ? 2 : 4;
     for (uint32_t c = 0; c < d->num_channels; ++c) {
         const JxlGpuModularChannel& ch = d->channels[c];
@@ -2678,7 +2708,7 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
         m->meta.push_back(p);
         m->mw.push_back(ch.width);
         m->mh.push_back(ch.height);
-        if (d->residual_predictor <= 13) {  // the predictor pass rewrites the palette table: it needs a copy of its own
+        if (d->residual_predictor <= 13 || d->num_unit_leaves) {  // the predictor pass rewrites the palette table: it needs a copy of its own
             if ((rc = malloc_dev(ctx, f, &p, bytes))) return rc;
             m->meta_work.push_back(p);
         }

@@ -224,6 +224,53 @@ def residuals_in_place(bufs, metas, grids, nb_meta, group_dim, predictor, offset
             view[y0:y0 + h, x0:x0 + w] = tile_residuals(src[y0:y0 + h, x0:x0 + w].astype(np.int64), predictor, offset, wp)
 
 
+def channel_units(grids, nb_meta, group_dim):
+    """The decode units of every transformed channel in the order JxlGpuModularDesc::unit_leaves lists them: like
+    channel_tiles, but a grouped channel contributes all ncols x nrows subgrids of its fixed-count grid in raster order —
+    None for the ones that fall outside the (smaller) transformed channel — and a channel with a zero dimension nothing."""
+    out = []
+    grouped = False
+    for i, g in enumerate(grids):
+        if not (g.w and g.h):
+            out.append([])
+            continue
+        if not grouped and (i < nb_meta or (g.w <= group_dim and g.h <= group_dim)):
+            out.append([(0, 0, g.w, g.h)])
+            continue
+        grouped = True
+        dim = group_dim if min(g.hshift, g.vshift) < 3 else group_dim * 8
+        tw, th = dim >> g.hshift, dim >> g.vshift
+        ncols, nrows = -(-g.orig_w // dim), -(-g.orig_h // dim)
+        units = []
+        for gy in range(nrows):
+            for gx in range(ncols):
+                x0, y0 = gx * tw, gy * th
+                units.append((x0, y0, min(tw, g.w - x0), min(th, g.h - y0)) if x0 < g.w and y0 < g.h else None)
+        out.append(units)
+    return out
+
+
+def residuals_in_place_leaves(bufs, metas, grids, nb_meta, group_dim, rng, wp=None, predictors=None):
+    """Like residuals_in_place, with a leaf of its own for every decode unit — what a tree that splits on the static
+    properties channel / stream index gives (make_flat_tree, ma.rs:38-41): predictor drawn per unit, multiplier 1 (the chain
+    stays lossless), a small offset.  Returns the leaves [(predictor, multiplier, offset)] in unit_leaves order."""
+    predictors = list(range(14)) if predictors is None else predictors
+    leaves = []
+    for g, units in zip(grids, channel_units(grids, nb_meta, group_dim)):
+        arr = bufs[g.buf] if g.buf >= 0 else metas[~g.buf]
+        view = arr[g.y0:g.y0 + g.h, g.x0:g.x0 + g.w]
+        src = view.copy()
+        for u in units:
+            pred = int(predictors[int(rng.integers(0, len(predictors)))])
+            off = int(rng.integers(-3, 4))
+            leaves.append((pred, 1, off))
+            if u is None:
+                continue
+            x0, y0, w, h = u
+            view[y0:y0 + h, x0:x0 + w] = tile_residuals(src[y0:y0 + h, x0:x0 + w].astype(np.int64), pred, off, wp)
+    return leaves
+
+
 def gradient_residuals(img, group_dim):
     """Residuals such that decode_simple_grad's arithmetic (image.rs:821-872) rebuilds `img`,
     independently per group_dim x group_dim tile."""
@@ -432,7 +479,7 @@ class ModularWorkload:
 
     def __init__(self, width, height, kind="squeeze", seed=0, i16=True, lossy=True, rct_type=None,
                  xyb=True, epf_iters=0, gabor=False, bit_depth=8, predictor=5, pred_offset=0, residual=None,
-                 group_dim=256):
+                 group_dim=256, leaves=None):
         """`residual` (kinds 'squeeze', 'palette'): a Predictor id — the buffers then hold the RESIDUALS of
         that predictor (single-leaf MA tree) for every transformed channel, computed decode unit by decode
         unit (channel_tiles) from the transformed samples; None: they hold the samples themselves."""
@@ -452,17 +499,27 @@ class ModularWorkload:
         self.residual_predictor = 0xFFFFFFFF
         self.residual_multiplier, self.residual_offset = 1, 0
         self.expected = None  # exact integer result when the chain is lossless
+        # `leaves` = "mixed" (kinds 'predictor', 'squeeze', 'palette'): every decode unit gets a leaf of its own
+        # (JxlGpuModularDesc::unit_leaves); a list of predictor ids restricts the draw
+        self.unit_leaves = None
+        leaf_rng = np.random.default_rng(SEED_BASE + 0x777 + seed)
+        leaf_preds = None if leaves in (None, "mixed") else list(leaves)
 
         if kind == "predictor":
             # single-leaf tree with an arbitrary predictor on plain RGB8 (no transforms)
             rgb = [np.clip(p, 0, 255) for p in base]
             self.expected = [p.astype(self.dtype) for p in rgb]
-            if predictor == 6:
+            if leaves is not None:
+                chans = [p.copy() for p in rgb]
+                self.unit_leaves = residuals_in_place_leaves(chans, [], [_Grid(i, 0, 0, W, H) for i in range(3)], 0, group_dim,
+                                                             leaf_rng, predictors=leaf_preds)
+            elif predictor == 6:
                 chans = [weighted_residuals(p, group_dim) for p in rgb]
             else:
                 chans = [predictor_residuals(p, group_dim, predictor, pred_offset) for p in rgb]
-            self.residual_predictor = predictor
-            self.residual_offset = pred_offset
+            if leaves is None:
+                self.residual_predictor = predictor
+                self.residual_offset = pred_offset
             self.buffers = [p.astype(self.dtype) for p in chans]
 
         elif kind == "lossless_rgb8":
@@ -502,7 +559,9 @@ class ModularWorkload:
                 return _trunc_div(res, q) * 1  # quantised residuals (dequantised form is what is coded)
             forward_squeeze(bufs, grids, steps, quant)
             self.transforms.append(("squeeze", None))
-            if residual is not None:
+            if leaves is not None:
+                self.unit_leaves = residuals_in_place_leaves(bufs, [], grids, 0, group_dim, leaf_rng, predictors=leaf_preds)
+            elif residual is not None:
                 residuals_in_place(bufs, [], grids, 0, group_dim, residual, pred_offset)
                 self.residual_predictor, self.residual_offset = residual, pred_offset
             self.buffers = [b.astype(self.dtype) for b in bufs]
@@ -512,12 +571,15 @@ class ModularWorkload:
             idx = rng.integers(0, ncol, size=(H, W)).astype(np.int64)
             self.expected = [pal[c][idx].astype(self.dtype) for c in range(3)]
             self.transforms.append(("palette", 0, 3, ncol))
-            if residual is not None:
+            if residual is not None or leaves is not None:
                 # transformed channel list: [palette table (meta, unshiftable), index channel]
                 grids = [_Grid(~0, 0, 0, ncol, 3, -1, -1), _Grid(0, 0, 0, W, H)]
                 bufs, metas = [idx], [pal]
-                residuals_in_place(bufs, metas, grids, 1, group_dim, residual, pred_offset)
-                self.residual_predictor, self.residual_offset = residual, pred_offset
+                if leaves is not None:
+                    self.unit_leaves = residuals_in_place_leaves(bufs, metas, grids, 1, group_dim, leaf_rng, predictors=leaf_preds)
+                else:
+                    residuals_in_place(bufs, metas, grids, 1, group_dim, residual, pred_offset)
+                    self.residual_predictor, self.residual_offset = residual, pred_offset
             self.meta.append(pal.astype(self.dtype))
             self.buffers = [idx.astype(self.dtype), np.zeros((H, W), self.dtype), np.zeros((H, W), self.dtype)]
         elif kind == "palette_delta":
@@ -551,7 +613,9 @@ class ModularWorkload:
             grids = [_Grid(0, 0, 0, W, H)]
             forward_squeeze(bufs, grids, default_squeeze_params(grids), lambda level, res: res)
             self.transforms.append(("squeeze", None))
-            if residual is not None:
+            if leaves is not None:
+                self.unit_leaves = residuals_in_place_leaves(bufs, [], grids, 0, group_dim, leaf_rng, predictors=leaf_preds)
+            elif residual is not None:
                 residuals_in_place(bufs, [], grids, 0, group_dim, residual, pred_offset)
                 self.residual_predictor, self.residual_offset = residual, pred_offset
             self.buffers = [b.astype(self.dtype) for b in bufs]
@@ -645,4 +709,11 @@ class ModularWorkload:
             d.color.ycbcr = 1
         d.noise = getattr(self, "noise", abi.NoiseParams())
         self._keep = [chans, metas, trs]
+        if self.unit_leaves is not None:
+            lv = (abi.MaLeaf * max(1, len(self.unit_leaves)))()
+            for i, (pred, mul, off) in enumerate(self.unit_leaves):
+                lv[i].predictor, lv[i].multiplier, lv[i].offset = pred, mul, off
+            d.unit_leaves = C.cast(lv, C.POINTER(abi.MaLeaf))
+            d.num_unit_leaves = len(self.unit_leaves)
+            self._keep.append(lv)
         return d

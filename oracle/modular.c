@@ -361,10 +361,14 @@ int jxl_oracle_modular_inverse(const JxlGpuModularDesc* d, void* const* out) {
      * LF-group tiles (group_dim >> (shift - 3)) (:286-306); the tile count comes from original_width /
      * original_height.  decode_single_node's dispatch (image.rs:733-777): Gradient with offset 0 and
      * multiplier 1 takes decode_simple_grad, everything else decode_one (predict.c).                    */
-    if (d->residual_predictor <= 13 && rc == 0) {
+    /* Per-unit leaves (JxlGpuModularDesc::unit_leaves): make_flat_tree(channel, stream_index, ..) resolves the decisions on the
+     * static properties 0 and 1 (ma.rs:38-41, image.rs:477-490), so every decode unit may come with its own single node
+     * (decode_single_node per unit, image.rs:553-562).  One entry per unit: channels in list order, ncols x nrows subgrids each
+     * (raster order, the ones outside the transformed channel included), 1 for a channel decoded whole.                    */
+    if ((d->residual_predictor <= 13 || d->num_unit_leaves) && rc == 0) {
         const uint32_t gd = d->group_dim ? d->group_dim : 256;
-        const int simple_grad = d->residual_predictor == 5 && d->residual_offset == 0 && d->residual_multiplier == 1;
         int global_phase = 1;
+        size_t unit_base = 0;
         for (int i = 0; i < l.n && rc == 0; ++i) {
             const Grid* g = &l.g[i];
             if (g->w == 0 || g->h == 0) continue;
@@ -386,6 +390,10 @@ int jxl_oracle_modular_inverse(const JxlGpuModularDesc* d, void* const* out) {
             size_t stride;
             char* base = (char*)grid_ptr(&w, g, &stride, esz);
             const uint32_t W = g->w, H = g->h;
+            if (d->num_unit_leaves && unit_base + (size_t)ncols * nrows > d->num_unit_leaves) { rc = JXLGPU_ERR_INVALID_ARG; break; }
+            const JxlGpuMaLeaf* leaves = d->num_unit_leaves ? d->unit_leaves + unit_base : NULL;
+            unit_base += (size_t)ncols * nrows;
+            int bad_leaf = 0;
 #pragma omp parallel for schedule(dynamic)
             for (long t = 0; t < (long)ncols * nrows; ++t) {
                 uint32_t x0 = (uint32_t)(t % ncols) * tw, y0 = (uint32_t)(t / ncols) * th;
@@ -394,13 +402,18 @@ int jxl_oracle_modular_inverse(const JxlGpuModularDesc* d, void* const* out) {
                 const uint32_t gw = W - x0 < tw ? W - x0 : tw, gh = H - y0 < th ? H - y0 : th;
                 if (gw == 0 || gh == 0) continue;
                 char* p = base + ((size_t)y0 * stride + x0) * esz;
-                if (!simple_grad)
-                    orc_predict_apply(p, stride, gw, gh, (int)esz, d->residual_predictor, d->residual_multiplier,
-                                      d->residual_offset, d->wp_params);
+                const uint32_t predictor = leaves ? leaves[t].predictor : d->residual_predictor;
+                const int32_t multiplier = leaves ? leaves[t].multiplier : d->residual_multiplier;
+                const int32_t offset = leaves ? leaves[t].offset : d->residual_offset;
+                if (predictor > 13) { bad_leaf = 1; continue; }
+                const int simple_grad = predictor == 5 && offset == 0 && multiplier == 1;   /* image.rs:762 */
+                if (!simple_grad) orc_predict_apply(p, stride, gw, gh, (int)esz, predictor, multiplier, offset, d->wp_params);
                 else if (esz == 2) gradient_apply_i16((int16_t*)p, stride, gw, gh);
                 else gradient_apply_i32((int32_t*)p, stride, gw, gh);
             }
+            if (bad_leaf) rc = JXLGPU_ERR_INVALID_ARG;
         }
+        if (rc == 0 && d->num_unit_leaves && unit_base != d->num_unit_leaves) rc = JXLGPU_ERR_INVALID_ARG;
     }
 
     /* inverse, last transform first */

@@ -64,7 +64,7 @@ def test_field_offsets_match_the_compiler():
              ("JxlGpuVardctDesc", abi.VardctDesc),
              ("JxlGpuOut", abi.Out), ("JxlGpuRegion", abi.Region), ("JxlGpuBlendRect", abi.BlendRect), ("JxlGpuSqueezeStep", abi.SqueezeStep),
              ("JxlGpuTransform", abi.Transform), ("JxlGpuModularChannel", abi.ModularChannel),
-             ("JxlGpuModularDesc", abi.ModularDesc)]
+             ("JxlGpuModularDesc", abi.ModularDesc), ("JxlGpuMaLeaf", abi.MaLeaf)]
     lines, want = [], []
     for cname, mirror in pairs:
         lines.append(f'printf("%zu\\n", sizeof({cname}));')

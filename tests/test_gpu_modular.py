@@ -278,6 +278,43 @@ def test_post_stage_reads_the_integer_planes(oracle, monkeypatch, size, gabor, i
     assert np.array_equal(got["int"].view(np.uint32), exp.view(np.uint32)), "post stage differs from the oracle"
 
 
+@pytest.mark.parametrize("case", [
+    dict(width=300, height=270, kind="predictor", i16=False, seed=1),
+    dict(width=300, height=270, kind="predictor", i16=True, seed=6),
+    dict(width=600, height=333, kind="squeeze", lossy=False, xyb=False, seed=2),
+    dict(width=300, height=200, kind="palette", seed=3, i16=False),
+    dict(width=1100, height=600, kind="squeeze", lossy=False, xyb=False, seed=4, group_dim=128, i16=False),
+    dict(width=520, height=300, kind="squeeze", lossy=False, xyb=False, seed=5, leaves=[6]),
+    dict(width=1100, height=700, kind="squeeze", lossy=False, xyb=False, seed=7, group_dim=1024, leaves=[6, 5, 13]),
+])
+def test_per_unit_leaves(gpu_ctx, oracle, case):
+    """JxlGpuModularDesc::unit_leaves: every decode unit with the single node make_flat_tree leaves it (a tree that splits on
+    the static properties channel / stream index: ma.rs:38-41, image.rs:477-490, 553-562) — its own predictor, offset and
+    multiplier.  The host forms the predictor waves by predictor, multiplier and offset travel with the subgrid.  Device
+    against oracle, and against the original image (the residuals come from the independent numpy forward, unit by unit);
+    then the same buffers with multipliers other than 1 (no ground truth: device against oracle only); a wrong count is
+    refused at the first inverse."""
+    from jxl_oxide_amd.runtime import JxlGpuError
+    kw = dict(case)
+    kw.setdefault("leaves", "mixed")
+    wl = ModularWorkload(**kw)
+    got = _inverse_both(gpu_ctx, oracle, wl)
+    for c in range(3):
+        assert np.array_equal(got[c], wl.expected[c]), f"channel {c} differs from the original image"
+    rng = np.random.default_rng(kw["seed"])
+    wl.unit_leaves = [(p, int(rng.integers(-3, 4)), o) for p, _, o in wl.unit_leaves]
+    wl.expected = None
+    _inverse_both(gpu_ctx, oracle, wl)
+    d = wl.desc()
+    d.num_unit_leaves -= 1
+    f = gpu_ctx.modular_upload(d)
+    try:
+        with pytest.raises(JxlGpuError):
+            gpu_ctx.modular_inverse(f, wl.shapes(), wl.dtype)
+    finally:
+        f.free()
+
+
 @pytest.mark.parametrize("kind", ["squeeze", "lossless_rgb8"])
 def test_render_with_noise(gpu_ctx, oracle, kind):
     """Noise on Modular frames: base correlations (0, 1) (noise.rs:35), on XYB and on plain RGB."""

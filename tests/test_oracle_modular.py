@@ -237,3 +237,36 @@ def test_subsampled_ycbcr_modular_equals_preupsampled_444(oracle, kind):
     yy = y + 128.0 / 255.0
     exp = np.stack([yy + 1.402 * cru, yy - 0.114 * 1.772 / 0.587 * cbu - 0.299 * 1.402 / 0.587 * cru, yy + 1.772 * cbu])
     assert np.abs(got - exp).max() < 2e-6
+
+
+@pytest.mark.parametrize("case", [
+    dict(width=300, height=270, kind="predictor", i16=False, seed=1),                                  # 2 x 2 groups per channel: 12 units
+    dict(width=600, height=333, kind="squeeze", lossy=False, xyb=False, seed=2),                        # Squeeze sub-channels, whole and grouped
+    dict(width=300, height=200, kind="palette", seed=3, i16=False),                                     # the palette table is a unit too
+    dict(width=1100, height=600, kind="squeeze", lossy=False, xyb=False, seed=4, group_dim=128, i16=False),   # 719 units, LF-group units among them
+    dict(width=520, height=300, kind="squeeze", lossy=False, xyb=False, seed=5, leaves=[6]),            # every unit the self-correcting predictor, own offsets
+])
+def test_per_unit_leaves_roundtrip(oracle, case):
+    """JxlGpuModularDesc::unit_leaves — a tree that splits on the static properties channel / stream index is a single node for
+    every decode unit, each with its own predictor and offset (make_flat_tree, ma.rs:38-41; decode_single_node per unit,
+    image.rs:553-562).  Residuals computed unit by unit by the independent numpy forward with that unit's leaf; the oracle
+    must rebuild the original image.  Pins the enumeration order of the units as well: a shifted list cannot round-trip."""
+    kw = dict(case)
+    kw.setdefault("leaves", "mixed")
+    wl = ModularWorkload(**kw)
+    assert wl.unit_leaves and len({p for p, _, _ in wl.unit_leaves}) >= (1 if kw["leaves"] != "mixed" else 2)
+    d = wl.desc()
+    assert d.residual_predictor == 0xFFFFFFFF     # the per-unit list alone says that residuals are present
+    got = oracle.modular_inverse(d, wl.shapes(), wl.dtype)
+    for c in range(3):
+        assert np.array_equal(got[c], wl.expected[c]), f"channel {c}"
+    # one leaf too few / too many: refused
+    for n in (len(wl.unit_leaves) - 1, len(wl.unit_leaves) + 1):
+        d.num_unit_leaves = n
+        with pytest.raises(Exception):
+            oracle.modular_inverse(d, wl.shapes(), wl.dtype)
+    # rotating the list by one breaks the round trip (the order matters)
+    if kw["leaves"] == "mixed":
+        wl.unit_leaves = wl.unit_leaves[1:] + wl.unit_leaves[:1]
+        got = oracle.modular_inverse(wl.desc(), wl.shapes(), wl.dtype)
+        assert not all(np.array_equal(got[c], wl.expected[c]) for c in range(3))

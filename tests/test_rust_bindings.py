@@ -32,7 +32,7 @@ def test_struct_sizes_equal_the_c_layout():
         "JxlGpuNoiseParams": abi.NoiseParams, "JxlGpuUpsampling": abi.Upsampling, "JxlGpuLfGroup": abi.LfGroup,
         "JxlGpuHfGroup": abi.HfGroup, "JxlGpuVardctDesc": abi.VardctDesc, "JxlGpuRegion": abi.Region, "JxlGpuOut": abi.Out,
         "JxlGpuFormatDesc": abi.FormatDesc, "JxlGpuExtraChannel": abi.ExtraChannel, "JxlGpuSqueezeStep": abi.SqueezeStep, "JxlGpuTransform": abi.Transform,
-        "JxlGpuModularChannel": abi.ModularChannel, "JxlGpuModularDesc": abi.ModularDesc,
+        "JxlGpuModularChannel": abi.ModularChannel, "JxlGpuModularDesc": abi.ModularDesc, "JxlGpuMaLeaf": abi.MaLeaf,
     }
     assert set(mirror) == set(sizes), set(mirror) ^ set(sizes)
     for name, cls in mirror.items():
