@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 22u
+#define JXLGPU_ABI_VERSION 23u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -45,7 +45,7 @@ extern "C" {
 #define JXLGPU_ERR_OOM (-2)         /* device or pinned allocation failed (jxl_grid::OutOfMemory)     */
 #define JXLGPU_ERR_DEVICE (-3)      /* HIP runtime error; jxlgpu_last_error() has the text             */
 #define JXLGPU_ERR_UNSUPPORTED (-4) /* valid JPEG XL, but outside this library's scope (caller falls   */
-                                    /* back to the CPU path): HLG, group_dim != 256 VarDCT frames, ...  */
+                                    /* back to the CPU path): group_dim != 256 VarDCT frames, ...       */
 #define JXLGPU_ERR_ABI (-5)         /* desc->abi != JXLGPU_ABI_VERSION                                  */
 
 typedef struct jxlgpu_ctx jxlgpu_ctx;     /* device + stream + scratch arena          */
@@ -85,7 +85,8 @@ typedef struct {
 #define JXLGPU_TF_PQ 2u
 #define JXLGPU_TF_BT709 3u
 #define JXLGPU_TF_GAMMA 4u
-#define JXLGPU_TF_HLG 5u   /* rejected with JXLGPU_ERR_UNSUPPORTED: tf.rs:101-160 uses libm powf/ln   */
+#define JXLGPU_TF_HLG 5u   /* linear_to_hlg (tf.rs:148-160): sqrt / libm logf, the latter as glibc computes  */
+                           /* it (csrc/libm_f32.h); see hlg_ootf_intensity_target for the inverse OOTF       */
 /* JxlGpuColorParams.gamut_map: what sits between the two Matrix ops (convert.rs:398-414) */
 #define JXLGPU_GAMUT_NONE 0u
 #define JXLGPU_GAMUT_MAP 1u  /* ColorTransformOp::GamutMap (perceptual intent)                     */
@@ -105,7 +106,7 @@ typedef struct {
     uint32_t transfer_function;/* JXLGPU_TF_*                                                    */
     float gamma;               /* for JXLGPU_TF_GAMMA: the exponent apply_gamma receives         */
                                /* (convert.rs:979-1020: 1e7/g, g/1e7, or 1/2.6 for DCI)          */
-    float hlg_luminances[3];   /* for JXLGPU_TF_HLG inverse OOTF (unsupported, see above)         */
+    float hlg_luminances[3];   /* HdrParams.luminances of the HLG inverse OOTF (see the last field) */
     /* ToneMapRec2408 { hdr_params, target_display_luminance, detect_peak: false } and the
      * GamutMap that follows it for perceptual intent (convert.rs:478-500), between matrix2 and the
      * transfer function.  detect_peak = true (a whole-image reduction) is not offered.            */
@@ -119,6 +120,22 @@ typedef struct {
      * `jxl_color::ycbcr_to_rgb` (jxl-color/src/ycbcr.rs:40-56, jxl-render/src/lib.rs:950-954) runs
      * instead of the XYB op list (`enabled` is ignored).                                          */
     uint32_t ycbcr;
+    /* HLG targets (ABI 23).  0: no inverse OOTF.  Otherwise `tf::hlg_inverse_oo(rgb, hlg_luminances, this)`
+     * (tf.rs:118-143; a no-op for 295..=305 as there) runs after the tone map and before the tone map's GamutMap —
+     * the one place the reference's op lists put it:
+     *   XYB image, HLG target (convert.rs:1021-1032): TransferFunction{Hlg} = inverse OOTF with the image's
+     *     intensity_target, then linear_to_hlg           -> this = intensity_target, no tone map;
+     *   PQ image, HLG target (`from_pq`, convert.rs:501-536): ToneMapRec2408{target 1000, detect_peak: false},
+     *     HlgInverseOotf{intensity_target: 1000}, GamutMap{0.1} for perceptual intent, then the transfer function
+     *     with intensity_target 300 (its own OOTF skipped)
+     *                                                    -> tone_map = 1, tm_target_display_luminance = 1000,
+     *                                                       this = 1000, tm_gamut_map / tm_gamut_saturation_factor 0.1;
+     *   the same with 999 <= intensity_target <= 1001: only the GamutMap and the transfer function
+     *                                                    -> tone_map = 0, this = 0, tm_gamut_map = 1 (since ABI 23
+     *                                                       tm_gamut_map is honoured without tone_map, with tm_luminances).
+     * The system gamma `1.2 * 1.111.powf(log2(it / 1000))` is evaluated once per frame on the host with the platform libm,
+     * as the reference does; the per-sample `mixed.powf(exp)` and `ln` on the device as glibc's powf / logf compute them. */
+    float hlg_ootf_intensity_target;
 } JxlGpuColorParams;
 
 /* ---- non-separable upsampling (jxl-render/src/features/upsampling.rs) ---- */
@@ -310,6 +327,11 @@ int jxlgpu_memory_usage(const jxlgpu_ctx* ctx, uint64_t* live_bytes, uint64_t* p
  * ms[0] work-list / side-plane build (worker threads), ms[1] reserved (0), ms[2] device allocations + enqueueing
  * the copies, ms[3] the whole call, ms[4] the arena's H2D copy on the device (HIP events; waits for it).      */
 int jxlgpu_upload_split(jxlgpu_ctx* ctx, double ms[5]);
+/* Diagnostic (ABI 23): evaluates on the device, for `n` host floats, the restatements of the platform libm that the HLG
+ * colour ops use (csrc/libm_f32.h; the reference calls libm there: jxl-color/src/tf.rs:118-160) — which = 0: logf(x[i]),
+ * which = 1: powf(x[i], y) with a finite y — and copies the results to `out`.  Synchronous.  A caller (or a test) compares
+ * them with its own libm: equal bits on glibc >= 2.28 / x86_64, which is what makes HLG frames bit-identical there.     */
+int jxlgpu_selftest_libm(jxlgpu_ctx* ctx, int which, const float* x, size_t n, float y, float* out);
 
 /* Measurement hook (no reference counterpart: the reference only has wall-clock MP/s in its CLI,
  * jxl-oxide-cli/src/decode.rs:164-209).  Brackets every launch group of the selected kind with

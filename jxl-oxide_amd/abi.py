@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -96,6 +96,7 @@ class ColorParams(C.Structure):
         ("tm_gamut_map", C.c_uint32),
         ("tm_gamut_saturation_factor", C.c_float),
         ("ycbcr", C.c_uint32),
+        ("hlg_ootf_intensity_target", C.c_float),
     ]
 
 
@@ -307,6 +308,7 @@ _SYMBOLS = [
     ("jxlgpu_host_alloc", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("jxlgpu_host_free", None, [C.c_void_p, C.c_void_p]),
     ("jxlgpu_upload_split", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    ("jxlgpu_selftest_libm", C.c_int, [C.c_void_p, C.c_int, f32p, C.c_size_t, C.c_float, f32p]),
     ("jxlgpu_set_memory_limit", C.c_int, [C.c_void_p, C.c_uint64]),
     ("jxlgpu_memory_usage", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("jxlgpu_profile_select", C.c_int, [C.c_void_p, C.c_int]),

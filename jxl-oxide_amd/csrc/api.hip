@@ -424,10 +424,21 @@ void fill_color_args(const JxlGpuColorParams& cp, ColorArgs* c) {
         c->tm_ks = 1.5f * c->tm_max_luminance - 0.5f;
         c->tm_one_sub_ks = 1.0f - c->tm_ks;
         c->tm_scale = it / cp.tm_target_display_luminance;
-        for (int i = 0; i < 3; ++i) c->tm_lum[i] = cp.tm_luminances[i];
-        c->tm_gamut_map = cp.tm_gamut_map;
-        c->tm_gamut_sat = cp.tm_gamut_saturation_factor;
     }
+    // the GamutMap behind the tone map; on its own in the PQ -> HLG list of a 1000-nit image (convert.rs:521-528)
+    for (int i = 0; i < 3; ++i) c->tm_lum[i] = cp.tm_luminances[i];
+    c->tm_gamut_map = cp.tm_gamut_map;
+    c->tm_gamut_sat = cp.tm_gamut_saturation_factor;
+    // HlgInverseOotf / the inverse OOTF of TransferFunction{Hlg}: tf.rs:118-143.  The system gamma is a frame constant; the
+    // reference evaluates it with the platform libm (f32::log2 / powf), and so does this line — the same two libm calls.
+    const float hit = cp.hlg_ootf_intensity_target;
+    if (hit != 0.0f && !(hit >= 295.0f && hit <= 305.0f)) {
+        const float gamma = 1.2f * ::powf(1.111f, ::log2f(hit / 1e3f));
+        c->hlg_ootf = 1;
+        c->hlg_exp = (1.0f - gamma) / gamma;
+        for (int i = 0; i < 3; ++i) c->hlg_lum[i] = cp.hlg_luminances[i];
+    }
+    c->staged_only = (c->hlg_ootf || c->tf == JXLGPU_TF_HLG || (c->tm_gamut_map && !c->tone_map)) && !c->ycbcr;
 }
 
 // upsample_inner's weights_quarter (features/upsampling.rs:77-93)
@@ -455,9 +466,9 @@ std::vector<float> expand_up_weights_public(const float* weights, int k) { retur
 // nullptr if the colour op list can run on the device, else why not
 const char* color_params_unsupported(const JxlGpuColorParams& cp) {
     if (!cp.enabled || cp.ycbcr) return nullptr;
-    if (cp.transfer_function == JXLGPU_TF_HLG)
-        return "HLG transfer function (libm powf/ln in the reference, not bit-reproducible) stays on the CPU path";
     if (cp.transfer_function > JXLGPU_TF_HLG) return "unknown transfer function";
+    if (!(cp.hlg_ootf_intensity_target >= 0.0f) || std::isinf(cp.hlg_ootf_intensity_target))
+        return "hlg_ootf_intensity_target is 0 (no inverse OOTF) or a finite positive intensity target";
     if (cp.gamut_map > JXLGPU_GAMUT_CLIP) return "unknown gamut_map mode";
     return nullptr;
 }
@@ -1435,7 +1446,8 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
     const bool do_up = (stages & JXLGPU_STAGE_UPSAMPLE) && up_factor > 1;
     const bool do_color = (stages & JXLGPU_STAGE_COLOR) && (f->desc.color.enabled || f->desc.color.ycbcr);
     const bool do_noise = (stages & JXLGPU_STAGE_NOISE) && f->desc.noise.enabled;
-    const bool fuse_color = do_color && !do_up && !do_noise;  // noise sits between upsampling and colour
+    // noise sits between upsampling and colour; HLG op lists are evaluated by the staged colour kernel only
+    const bool fuse_color = do_color && !do_up && !do_noise && !f->color.staged_only;
     if (region && do_noise)
         return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "noise synthesis with a region (the generator is seeded per absolute group)");
     // the rectangle of coded samples the output region needs: its own, or with 2x / 4x / 8x upsampling the
@@ -1498,7 +1510,7 @@ int run_post_stages(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages, const Jxl
         const float* kern = f->up_weights[k == 2 ? 0 : k == 4 ? 1 : 2];
         // 2x (BASELINE config 5): one streaming pass for the three planes, colour transform fused
         // when nothing (noise) sits between the two
-        const bool fuse = do_color && !do_noise;
+        const bool fuse = do_color && !do_noise && !f->color.staged_only;
         // output window: the region; for the 2x streaming kernel, the input samples under it
         PixRect win2{0, 0, (int)W, (int)H};
         if (region) win2 = PixRect{std::max(region->x0, 0) / 2, std::max(region->y0, 0) / 2,

@@ -130,8 +130,16 @@ struct ColorArgs {
     uint32_t tone_map;
     float tm_lum[3];
     float tm_lum0_pq, tm_source_pq_diff, tm_min_luminance, tm_max_luminance, tm_ks, tm_one_sub_ks, tm_scale;
-    uint32_t tm_gamut_map;
+    uint32_t tm_gamut_map;     // honoured with or without tone_map (PQ image, HLG target, intensity_target ~ 1000)
     float tm_gamut_sat;
+    // HLG targets: inverse OOTF (tf.rs:118-143) between the tone map and its GamutMap; hlg_exp = (1 - gamma) / gamma with the
+    // system gamma evaluated once per frame on the host (platform libm, as the reference does)
+    uint32_t hlg_ootf;
+    float hlg_exp;
+    float hlg_lum[3];
+    // the op list has something only the staged colour kernel evaluates (color_pixel_t<true>): the fused post / upsampling
+    // kernels run without their colour epilogue and launch_color follows (run_post_stages)
+    uint32_t staged_only;
 };
 
 // Fused post stage (fused_kernels.hip): Gabor -> EPF -> colour in one pass.

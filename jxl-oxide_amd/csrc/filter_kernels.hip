@@ -1,6 +1,8 @@
 // Stage-at-a-time restoration / colour / upsampling kernels (one launch per stage, planes in
 // HBM).  These are the simple forms used for stage-level parity tests and for configurations the
 // fused tile kernel (fused_kernels.hip) does not cover; the fused kernel is the fast path.
+#include <cmath>
+
 #include "common.h"
 #include "pixel_device.h"
 
@@ -55,6 +57,8 @@ void launch_epf(hipStream_t s, int step, const FilterArgs& a) {
 }
 
 // ---------------------------------------------------------------- C1-C4 colour, in place
+// FULL: with the HLG ops (color_pixel_t<true>; ColorArgs::staged_only frames), the only kernel built with them
+template <bool FULL>
 __global__ __launch_bounds__(256) void color_kernel(ColorArgs cp, float* p0, float* p1, float* p2,
                                                     uint32_t stride, uint32_t width, uint32_t height) {
     uint32_t x = blockIdx.x * 256 + threadIdx.x;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void color_kernel(ColorArgs cp, float* p0, flo
     if (x >= width) return;
     size_t i = (size_t)y * stride + x;
     float v[3] = {p0[i], p1[i], p2[i]};
-    color_pixel(cp, v);
+    color_pixel_t<FULL>(cp, v);
     p0[i] = v[0];
     p1[i] = v[1];
     p2[i] = v[2];
@@ -71,7 +75,42 @@ __global__ __launch_bounds__(256) void color_kernel(ColorArgs cp, float* p0, flo
 void launch_color(hipStream_t s, const ColorArgs& c, float* const planes[3], uint32_t stride,
                   uint32_t width, uint32_t height) {
     dim3 grid(ceil_div(width, 256), height);
-    color_kernel<<<grid, 256, 0, s>>>(c, planes[0], planes[1], planes[2], stride, width, height);
+    if (c.staged_only) color_kernel<true><<<grid, 256, 0, s>>>(c, planes[0], planes[1], planes[2], stride, width, height);
+    else color_kernel<false><<<grid, 256, 0, s>>>(c, planes[0], planes[1], planes[2], stride, width, height);
+}
+
+// ---------------------------------------------------------------- device self-test of libm_f32.h
+namespace {
+__global__ __launch_bounds__(256) void libm_selftest_kernel(int which, const float* __restrict__ x, size_t n, float y,
+                                                            float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = which == 0 ? libm_f32::logf(x[i]) : libm_f32::powf(x[i], y);
+}
+}  // namespace
+
+extern "C" int jxlgpu_selftest_libm(jxlgpu_ctx* ctx, int which, const float* x, size_t n, float y, float* out) {
+    if (!ctx) return JXLGPU_ERR_INVALID_ARG;
+    if ((which != 0 && which != 1) || (n && (!x || !out)) || !std::isfinite(y) || n > ((size_t)1 << 30)) {
+        ctx->last_error = "jxlgpu_selftest_libm: which is 0 (logf) or 1 (powf), y finite, n <= 2^30";
+        return JXLGPU_ERR_INVALID_ARG;
+    }
+    if (n == 0) return JXLGPU_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *dx = nullptr, *dout = nullptr;   // a diagnostic: plain allocations, outside the pool and the memory budget
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dx), n * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dout), n * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(dx, x, n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        libm_selftest_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, ctx->stream>>>(which, dx, n, y, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (dx) (void)hipFree(dx);
+    if (dout) (void)hipFree(dout);
+    HIP_TRY(ctx, e);
+    return JXLGPU_OK;
 }
 
 // ---------------------------------------------------------------- F3 non-separable upsampling

@@ -728,7 +728,7 @@ hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in
     }
     // plain XYB -> sRGB (no gamut map / second matrix) gets a branch-free colour epilogue
     *plain_srgb = a.color.tf == JXLGPU_TF_SRGB && !a.color.gamut_map && !a.color.has_matrix2 &&
-                  !a.color.tone_map && !a.color.ycbcr;
+                  !a.color.tone_map && !a.color.ycbcr && !a.color.staged_only;
     return hipSuccess;
 }
 

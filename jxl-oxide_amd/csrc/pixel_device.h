@@ -4,6 +4,7 @@
 #pragma once
 
 #include "common.h"
+#include "libm_f32.h"
 
 // jxl-render/src/util.rs:376-386
 __device__ __forceinline__ int mirror_idx(int offset, int len) {
@@ -298,9 +299,31 @@ __device__ __forceinline__ void matmul3vec_dev(const float (&a)[9], float (&v)[3
     v[2] = a[6] * b0 + a[7] * b1 + a[8] * b2;
 }
 
-// XybToMixedLms -> Matrix -> [GamutMap -> Matrix] -> TransferFunction for one pixel
+// hlg_inverse_oo (tf.rs:118-143) for one pixel; `mixed.powf(exp)` as glibc's powf computes it (libm_f32.h).  A negative
+// or zero luminance mix gives what it gives in the reference: NaN (x86's default NaN pattern) or +inf times the sample.
+__device__ __forceinline__ void hlg_inverse_oo_dev(const ColorArgs& cp, float (&v)[3]) {
+    const float mixed = __builtin_fmaf(v[0], cp.hlg_lum[0], __builtin_fmaf(v[1], cp.hlg_lum[1], v[2] * cp.hlg_lum[2]));
+    const float mult = libm_f32::powf(mixed, cp.hlg_exp);
+    v[0] *= mult;
+    v[1] *= mult;
+    v[2] *= mult;
+}
+
+// linear_to_hlg (tf.rs:145-160); `ln` as glibc's logf computes it
+__device__ __forceinline__ float linear_to_hlg_dev(float s) {
+    const float a = fabsf(s);
+    const float v = a <= 1.0f / 12.0f ? sqrtf(3.0f * a)
+                                      : 0.17883277f * libm_f32::logf(__builtin_fmaf(a, 12.0f, -0.28466892f)) + 0.5599107f;
+    return copysignf(v, s);
+}
+
+// XybToMixedLms -> Matrix -> [GamutMap -> Matrix] -> [ToneMap] -> [HlgInverseOotf] -> [GamutMap] -> TransferFunction for one pixel
 // (op list built at jxl-color/src/convert.rs:208-549; xyb.rs:44-58 for the first op).
-__device__ __forceinline__ void color_pixel(const ColorArgs& cp, float (&v)[3]) {
+// FULL = false: the op lists the fused kernels evaluate (everything but the HLG ones); FULL = true adds the HLG inverse OOTF, the
+// GamutMap without a tone map in front of it and linear_to_hlg — the double-precision libm restatements cost registers, so only
+// the staged colour kernel (color_kernel, filter_kernels.hip) is built with them and ColorArgs::staged_only sends such frames there.
+template <bool FULL>
+__device__ __forceinline__ void color_pixel_t(const ColorArgs& cp, float (&v)[3]) {
     if (cp.ycbcr) {
         // ycbcr_to_rgb run_generic, jxl-color/src/ycbcr.rs:40-56 (planes are Cb, Y, Cr)
         const float cb = v[0], yy = v[1] + 128.0f / 255.0f, cr = v[2];
@@ -325,7 +348,11 @@ __device__ __forceinline__ void color_pixel(const ColorArgs& cp, float (&v)[3]) 
         for (int c = 0; c < 3; ++c) v[c] = clamp01_dev(v[c]);
     }
     if (cp.has_matrix2) matmul3vec_dev(cp.matrix2, v);
-    if (cp.tone_map) {
+    if constexpr (FULL) {
+        if (cp.tone_map) tone_map_dev(cp, v);
+        if (cp.hlg_ootf) hlg_inverse_oo_dev(cp, v);    // convert.rs:501-536 / :1021-1032
+        if (cp.tm_gamut_map) map_gamut_dev(v, cp.tm_lum, cp.tm_gamut_sat);
+    } else if (cp.tone_map) {
         tone_map_dev(cp, v);
         if (cp.tm_gamut_map) map_gamut_dev(v, cp.tm_lum, cp.tm_gamut_sat);
     }
@@ -341,8 +368,13 @@ __device__ __forceinline__ void color_pixel(const ColorArgs& cp, float (&v)[3]) 
     } else if (cp.tf == JXLGPU_TF_PQ) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = linear_to_pq_dev(v[c], cp.intensity_target);
+    } else if (FULL && cp.tf == JXLGPU_TF_HLG) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = linear_to_hlg_dev(v[c]);
     }
 }
+
+__device__ __forceinline__ void color_pixel(const ColorArgs& cp, float (&v)[3]) { color_pixel_t<false>(cp, v); }
 
 // Same, specialised for the common chain XybToMixedLms -> Matrix -> sRGB (no branches).
 __device__ __forceinline__ void color_pixel_srgb(const ColorArgs& cp, float (&v)[3]) {

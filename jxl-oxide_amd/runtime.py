@@ -318,6 +318,14 @@ class Context:
         self._check(self.lib.jxlgpu_upload_split(self.handle, ms))
         return list(ms)
 
+    def selftest_libm(self, which, x, y=1.0):
+        """The device's logf (which = 0) / powf(x, y) (which = 1) restatements (csrc/libm_f32.h) on the f32 array `x`."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        self._check(self.lib.jxlgpu_selftest_libm(self.handle, which, x.ctypes.data_as(abi.f32p), x.size, y,
+                                                  out.ctypes.data_as(abi.f32p)))
+        return out
+
     def download_lf(self, frame, w8, h8):
         lf = np.zeros((3, h8, w8), dtype=np.float32)
         arr = (abi.f32p * 3)(*[lf[c].ctypes.data_as(abi.f32p) for c in range(3)])

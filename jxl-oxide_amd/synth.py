@@ -196,6 +196,32 @@ def configure_color(cp, mode):
     elif mode == "gamma22":
         cp.transfer_function = abi.TF_GAMMA
         cp.gamma = float(np.float32(1e7) / np.float32(22000000))  # Gamma{g: 22000000, inverted: false}
+    elif mode == "hlg":
+        # XYB image shown on an HLG target: TransferFunction{Hlg} = inverse OOTF with the image's intensity target, then
+        # linear_to_hlg (convert.rs:1021-1032; HLG is an HDR encoding, so no tone map: :478)
+        cp.transfer_function = abi.TF_HLG
+        cp.hlg_luminances[:] = SRGB_LUMINANCES
+        cp.hlg_ootf_intensity_target = cp.intensity_target
+    elif mode == "pq_to_hlg":
+        # PQ image, HLG target, perceptual intent (`from_pq`, convert.rs:501-536): ToneMapRec2408{target 1000} ->
+        # HlgInverseOotf{1000} -> GamutMap{0.1} -> linear_to_hlg (the transfer function's own OOTF skipped: 300)
+        assert not 999.0 <= cp.intensity_target <= 1001.0
+        cp.tone_map = 1
+        cp.tm_luminances[:] = SRGB_LUMINANCES
+        cp.tm_min_nits = 0.0
+        cp.tm_target_display_luminance = 1000.0
+        cp.hlg_luminances[:] = SRGB_LUMINANCES
+        cp.hlg_ootf_intensity_target = 1000.0
+        cp.tm_gamut_map = 1
+        cp.tm_gamut_saturation_factor = 0.1
+        cp.transfer_function = abi.TF_HLG
+    elif mode == "pq_to_hlg_1000":
+        # the same for a 1000-nit image: no tone map, no inverse OOTF, only GamutMap{0.1} and linear_to_hlg
+        assert 999.0 <= cp.intensity_target <= 1001.0
+        cp.tm_luminances[:] = SRGB_LUMINANCES
+        cp.tm_gamut_map = 1
+        cp.tm_gamut_saturation_factor = 0.1
+        cp.transfer_function = abi.TF_HLG
     else:
         raise ValueError(mode)
 

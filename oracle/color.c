@@ -17,8 +17,13 @@
  *   linear_to_bt709 (scalar)    jxl-color/src/tf/bt709.rs:60-68
  *   apply_gamma (scalar)        jxl-color/src/tf.rs:60-68
  *   Clip                        jxl-color/src/convert.rs:948-955
- * Not restated: HLG (tf.rs:101-160 goes through libm powf/ln/log2, which is not reproducible
- * bit-for-bit across platforms) and peak detection (a whole-image reduction ahead of the per-sample
+ *   hlg_inverse_oo              jxl-color/src/tf.rs:118-143   (op HlgInverseOotf, convert.rs:906-916; TransferFunction
+ *   linear_to_hlg               jxl-color/src/tf.rs:145-160    {Hlg}, convert.rs:1021-1032)
+ *     Both go through the platform libm (f32::powf / ln / log2 -> powf / logf / log2f): the calls below are the
+ *     SAME libm calls, so on this box the oracle computes what the reference computes on this box.  (The product
+ *     restates glibc's powf / logf for the device, csrc/libm_f32.h; tests/test_libm_f32.py compares that
+ *     restatement with the installed libm on every float.)
+ * Not restated: peak detection (a whole-image reduction ahead of the per-sample
  * pass; ColorTransformBuilder's default is detect_peak = false, convert.rs:141).
  * Op order of the pipeline: jxl-color/src/convert.rs:208-549.
  */
@@ -246,6 +251,36 @@ static void map_gamut(float rgb[3], const float lum[3], float saturation_factor)
     for (int i = 0; i < 3; ++i) rgb[i] = mixed[i] / max_color_val;
 }
 
+/* libm through pointers the compiler cannot see through: no constant folding (GCC folds with MPFR, correctly
+ * rounded, which is not always what the library returns), no builtin expansion */
+static float (*volatile libm_powf)(float, float) = powf;
+static float (*volatile libm_logf)(float) = logf;
+static float (*volatile libm_log2f)(float) = log2f;
+
+/* tf.rs:118-143: hlg_inverse_oo.  Returns without touching the samples for 295 <= intensity_target <= 305. */
+static void hlg_inverse_oo(float rgb[3], const float lum[3], float intensity_target) {
+    if (intensity_target >= 295.0f && intensity_target <= 305.0f) return;
+    float gamma = 1.2f * libm_powf(1.111f, libm_log2f(intensity_target / 1e3f));
+    float exp = (1.0f - gamma) / gamma;
+    float mixed = fmaf(rgb[0], lum[0], fmaf(rgb[1], lum[1], rgb[2] * lum[2]));
+    float mult = libm_powf(mixed, exp);
+    rgb[0] *= mult;
+    rgb[1] *= mult;
+    rgb[2] *= mult;
+}
+
+/* tf.rs:145-160: linear_to_hlg */
+static float linear_to_hlg(float s) {
+    const float HLG_A = 0.17883277f, HLG_B = 0.28466892f, HLG_C = 0.5599107f;
+    float a = fabsf(s);
+    float v = a <= 1.0f / 12.0f ? sqrtf(3.0f * a) : HLG_A * libm_logf(fmaf(a, 12.0f, -HLG_B)) + HLG_C;
+    return copysignf(v, s);
+}
+
+/* hooks for tests/test_oracle_color.py */
+float orc_test_linear_to_hlg(float s) { return linear_to_hlg(s); }
+void orc_test_hlg_inverse_oo(float rgb[3], const float lum[3], float intensity_target) { hlg_inverse_oo(rgb, lum, intensity_target); }
+
 static void matmul3vec(const float a[9], float v[3]) {
     float b0 = v[0], b1 = v[1], b2 = v[2];
     v[0] = a[0] * b0 + a[1] * b1 + a[2] * b2;
@@ -281,16 +316,19 @@ void orc_color_transform(float* const ch[3], size_t n, const JxlGpuColorParams* 
         if (cp->gamut_map == JXLGPU_GAMUT_MAP) map_gamut(v, cp->gamut_luminances, cp->gamut_saturation_factor);
         else if (cp->gamut_map == JXLGPU_GAMUT_CLIP) for (int c = 0; c < 3; ++c) v[c] = clamp01(v[c]);
         if (cp->has_matrix2) matmul3vec(cp->matrix2, v);
-        if (cp->tone_map) {
+        if (cp->tone_map)
             tone_map(v, cp->tm_luminances, cp->intensity_target, cp->tm_min_nits, cp->tm_target_display_luminance);
-            if (cp->tm_gamut_map) map_gamut(v, cp->tm_luminances, cp->tm_gamut_saturation_factor);
-        }
+        /* convert.rs:501-536 (PQ image, HLG target): ToneMapRec2408 -> HlgInverseOotf -> GamutMap; :1021-1032 (the
+         * transfer function's own inverse OOTF): nothing sits between it and linear_to_hlg, so one position serves both */
+        if (cp->hlg_ootf_intensity_target != 0.0f) hlg_inverse_oo(v, cp->hlg_luminances, cp->hlg_ootf_intensity_target);
+        if (cp->tm_gamut_map) map_gamut(v, cp->tm_luminances, cp->tm_gamut_saturation_factor);
         for (int c = 0; c < 3; ++c) {
             switch (cp->transfer_function) {
                 case JXLGPU_TF_SRGB: v[c] = linear_to_srgb(v[c]); break;
                 case JXLGPU_TF_PQ: v[c] = linear_to_pq(v[c], cp->intensity_target); break;
                 case JXLGPU_TF_BT709: v[c] = linear_to_bt709(v[c]); break;
                 case JXLGPU_TF_GAMMA: v[c] = apply_gamma(v[c], cp->gamma); break;
+                case JXLGPU_TF_HLG: v[c] = linear_to_hlg(v[c]); break;
                 default: break;
             }
         }

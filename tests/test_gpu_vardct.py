@@ -231,14 +231,6 @@ def test_noise_where_the_reference_panics_is_refused(gpu_ctx):
         frame.free()
 
 
-def test_hlg_is_refused(gpu_ctx):
-    wl = VardctWorkload(64, 64, seed=5)
-    wl.color.transfer_function = abi.TF_HLG
-    with pytest.raises(Exception) as e:
-        gpu_ctx.vardct_upload(wl.desc())
-    assert e.value.code == abi.ERR_UNSUPPORTED
-
-
 @pytest.mark.parametrize("factor", [2, 4, 8])
 def test_upsampling(gpu_ctx, oracle, factor):
     wl = VardctWorkload(72, 56, seed=20 + factor, upsampling=factor, epf_iters=1)
