@@ -2829,7 +2829,6 @@ static int modular_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages
     }
     if (subsampled && (m->desc.xyb_encoded || !m->desc.color.ycbcr))
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "subsampled colour channels need a YCbCr frame (color.ycbcr, not XYB)");
-    if (subsampled && region_in) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "region render of a chroma-subsampled Modular frame");
     if (gray) stages &= ~(uint32_t)JXLGPU_STAGE_NOISE;  // render.rs:208-221: "Cannot render noise on grayscale buffer; skipping"
     if (!(stages & JXLGPU_STAGE_MODULAR_TO_FLOAT)) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "render needs JXLGPU_STAGE_MODULAR_TO_FLOAT");
     ctx->prof_begin(PROF_MODULAR);
@@ -2875,7 +2874,9 @@ static int modular_render_impl(jxlgpu_ctx* ctx, jxlgpu_frame* f, uint32_t stages
         if (!clip_region(region_in, fw, fh, &region)) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "the region does not intersect the frame");
         const bool any_filter = ((stages & JXLGPU_STAGE_GABOR) && f->desc.filter.gab_enabled) || ((stages & JXLGPU_STAGE_EPF) && f->desc.filter.epf_iters);
         const bool noisy = (stages & JXLGPU_STAGE_NOISE) && f->desc.noise.enabled;  // seeded per absolute group: whole frame, then crop
-        cut = !noisy && (!any_filter || fused_post_supported(ctx, f, true, 2));  // the staged filters run on whole planes: crop afterwards
+        // the staged filters run on whole planes: crop afterwards; so does a chroma-subsampled frame (its planes are
+        // upsampled whole above, as the VarDCT JPEG-transcode path does: whole frame, the region cropped from it)
+        cut = !noisy && !subsampled && (!any_filter || fused_post_supported(ctx, f, true, 2));
     }
     rc = run_post_stages(ctx, f, stages, f->desc.filter, f->desc.upsampling.factor ? f->desc.upsampling.factor : 1,
                          cur, &stride, &ow, &oh, false, cut ? &region : nullptr);

@@ -137,6 +137,23 @@ def test_modular_region(gpu_ctx):
             frame.free()
 
 
+@pytest.mark.parametrize("kind", ["ycbcr420", "ycbcr422", "ycbcr440"])
+def test_subsampled_modular_region_is_cropped_from_the_whole_frame(gpu_ctx, kind):
+    """do_ycbcr Modular frames with jpeg_upsampling: the planes are upsampled whole, the region is cropped from the result."""
+    stages = S_ALL | abi.STAGE_MODULAR_TO_FLOAT
+    for kw, size in ((dict(), (301, 271)), (dict(gabor=True, epf_iters=2), (520, 300))):
+        wl = ModularWorkload(*size, kind=kind, i16=True, seed=6, xyb=False, **kw)
+        frame = gpu_ctx.modular_upload(wl.desc())
+        try:
+            full = gpu_ctx.modular_render(frame, stages)
+            rng = np.random.default_rng(3)
+            w, h = size
+            _check(gpu_ctx, frame, full, _random_regions(rng, w, h, 3) + [(0, 0, w, h), (w - 9, h - 7, 9, 7), (1, 1, 2, 2)], stages,
+                   gpu_ctx.modular_render_region)
+        finally:
+            frame.free()
+
+
 def test_jpeg_transcode_region_is_cropped_from_the_whole_frame(gpu_ctx):
     from jxl_oxide_amd.synth import JpegWorkload
     wl = JpegWorkload(328, 264, mode="420", seed=2)
