@@ -45,7 +45,7 @@ extern "C" {
 #define JXLGPU_ERR_OOM (-2)         /* device or pinned allocation failed (jxl_grid::OutOfMemory)     */
 #define JXLGPU_ERR_DEVICE (-3)      /* HIP runtime error; jxlgpu_last_error() has the text             */
 #define JXLGPU_ERR_UNSUPPORTED (-4) /* valid JPEG XL, but outside this library's scope (caller falls   */
-                                    /* back to the CPU path): group_dim != 256 VarDCT frames, ...       */
+                                    /* back to the CPU path): frames above the size limits, ...         */
 #define JXLGPU_ERR_ABI (-5)         /* desc->abi != JXLGPU_ABI_VERSION                                  */
 
 typedef struct jxlgpu_ctx jxlgpu_ctx;     /* device + stream + scratch arena          */
