@@ -51,6 +51,18 @@ POST_VALU_PER_ROW, POST_STRIP = (354, 56) if os.environ.get("JXLGPU_NO_PK") else
 POST_HALO_ROWS = 8
 
 
+def _owner_link_bound(gathered_gb, world, mp_per_step, gb_per_s_per_link=76.8):
+    """Upper bound of a rooted (stitched on rank 0) job from the owner's inbound xGMI links: None at N = 1 or without a gather."""
+    try:
+        if not gathered_gb or world < 2:
+            return None
+        ms = gathered_gb / ((world - 1) * gb_per_s_per_link) * 1e3
+        return {"GB_per_step": gathered_gb, "links": world - 1, "GB_per_s_per_link_inbound": gb_per_s_per_link,
+                "ms_per_step": round(ms, 4), "value_bound": round(mp_per_step / (ms * 1e-3), 1), "unit": "MP/s"}
+    except Exception:   # never let a reporting extra take the line down
+        return None
+
+
 def post_rows_per_seg(ih, iw, num_cus):
     """Rows per wave segment of the batched streaming post launch, as fused_prepare() (csrc/fused_kernels.hip) picks them:
     JXLGPU_BATCH_STREAM_ROWS if set, otherwise ONE resident round of waves (two per SIMD) per launch of 16 frames."""
@@ -377,6 +389,8 @@ def main():
             others = None
             if not args.no_extras and args.config == 2 and world == 1:
                 others = other_configs()
+            gathered_gb = None if gather is None else round(
+                (gather.slot_bytes * gather.slots * (world - 1) if gather_mode == "p2p" else gather.bytes_to_dst / max(gstep[0], 1)) * passes / 1e9, 3)
             out = {
                 "metric": job["metric"],
                 "value": round(value, 1),
@@ -394,8 +408,11 @@ def main():
                 "value_render_only": None if value_render_only is None else round(value_render_only, 1),
                 "gather_error": gather_error,
                 "gather_mode": gather_mode,
-                "gathered_GB_per_step": None if gather is None else round(
-                    (gather.slot_bytes * gather.slots * (world - 1) if gather_mode == "p2p" else gather.bytes_to_dst / max(gstep[0], 1)) * passes / 1e9, 3),
+                "gathered_GB_per_step": gathered_gb,
+                # what the owner's xGMI links allow at most for a ROOTED output: every other rank's bytes enter rank 0
+                # over that rank's own link (p2p) — (world - 1) links x 76.8 GB/s inbound; `value` can approach, never pass, `value_bound`;
+                # `value_render_only` (the output left sharded) is not subject to it.  Arithmetic only, nothing measured.
+                "owner_link_bound": _owner_link_bound(gathered_gb, world, n_total * passes * mp_per_frame),
                 "vs_baseline": None,
                 "dtype": job["dtype"],
                 "data": "synthetic",
