@@ -9,10 +9,10 @@
 // the end.  libm is a dependency that is not under /root/reference, so this file restates the PUBLISHED algorithm
 // (tables and polynomials are the published constants; tools/libm_tables.py re-reads them from the installed
 // libm.so.6 and checks this file) — and tests/test_libm_f32.py compiles this very header with g++ and compares it
-// with the installed libm: logf on EVERY positive normal float, powf on every positive float for the exponents the
-// HLG system gamma can take, plus the special cases.  The arithmetic is IEEE double add / mul / fma and exact
-// integer steps only, every fused multiply-add written out (-ffp-contract=off on both compilers), so the device
-// evaluates bit for bit what the host test evaluates.
+// with the installed libm: logf on EVERY float (all 2^32 bit patterns), powf on every float as the base for the
+// exponents the HLG system gamma takes (188 more exponents x 2^32 bases were run once: no mismatch).  The arithmetic
+// is IEEE double add / mul / fma and exact integer steps only, every fused multiply-add written out
+// (-ffp-contract=off on both compilers), so the device evaluates bit for bit what the host test evaluates.
 //
 // Scope: what the HLG path can hand in.  logf: any float (the caller hands 12a - b with a > 1/12, NaN or inf).
 // powf: any x, FINITE y (the exponent is a frame constant the host derives from intensity_target).

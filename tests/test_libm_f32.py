@@ -67,3 +67,15 @@ def test_powf_every_float_for_the_hlg_exponents(checker):
     ys = [repr(hlg_exponent(it)) for it in (1000.0, 4000.0, 400.0)]
     r = subprocess.run([checker, "powf", *ys], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.count("mismatches: 0") == len(ys), (r.stdout, r.stderr)
+
+
+@pytest.mark.skipif(not os.environ.get("JXL_LIBM_CAMPAIGN"), reason="opt-in: JXL_LIBM_CAMPAIGN=<number of random exponents> (8 s each on 8 cores)")
+def test_powf_campaign(checker):
+    """The long form of the test above: random exponents in [-1, 2.5] (the HLG exponent (1 - gamma) / gamma lies in (-1, inf)),
+    every float as the base.  188 exponents were run once in round 5: no mismatch."""
+    import numpy as np
+    rng = np.random.default_rng(int(os.environ.get("JXL_LIBM_SEED", "1")))
+    ys = [repr(float(np.float32(y))) for y in rng.uniform(-1.0, 2.5, int(os.environ["JXL_LIBM_CAMPAIGN"]))]
+    r = subprocess.run([checker, "powf", *ys], capture_output=True, text=True, timeout=36000)
+    assert r.returncode == 0 and r.stdout.count("mismatches: 0") == len(ys), (r.stdout[-2000:], r.stderr[-2000:])
+
