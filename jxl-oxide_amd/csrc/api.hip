@@ -549,6 +549,8 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     if (const char* v = getenv("JXLGPU_RING_MODE")) ctx->tune.ring_mode = std::min(2, std::max(0, atoi(v)));
     ctx->tune.int_post = getenv("JXLGPU_INT_POST") != nullptr && atoi(getenv("JXLGPU_INT_POST")) != 0;
     if (const char* v = getenv("JXLGPU_BATCH_TR_MULT")) ctx->tune.batch_tr_mult = std::min(4, std::max(1, atoi(v)));
+    ctx->tune.batch_lf_ahead = getenv("JXLGPU_BATCH_LF_AHEAD") != nullptr && atoi(getenv("JXLGPU_BATCH_LF_AHEAD")) != 0;
+    if (const char* v = getenv("JXLGPU_POST_LDS_PAD")) ctx->tune.post_lds_pad = std::min(150 * 1024, std::max(0, atoi(v)));
     if (const char* v = getenv("JXLGPU_BATCH_HEAVY")) ctx->tune.batch_heavy = (uint32_t)strtoul(v, nullptr, 0) & 31u;
     if (const char* v = getenv("JXLGPU_GUARD")) {
         const int m = atoi(v);
@@ -2117,7 +2119,27 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
             }
         }
         ctx->prof_begin(PROF_LF, st);
-        HIP_TRY(ctx, launch_lf_batch(st, b, m, max_w8, max_h8, any_smooth));
+        if (!(overlap && ctx->tune.batch_lf_ahead)) {
+            HIP_TRY(ctx, launch_lf_batch(st, b, m, max_w8, max_h8, any_smooth));
+        } else {
+            // experiment: V1-V3 one chunk AHEAD — this chunk's LF launches were queued in front of the previous chunk's
+            // transform launches (the first chunk's here), the next chunk's go in front of this chunk's
+            for (uint32_t k0 = (i0 == 0 ? 0u : i0 + tchunk); k0 < n && k0 <= i0 + tchunk; k0 += tchunk) {
+                const uint32_t mk = std::min<uint32_t>(tchunk, n - k0);
+                FrameBatch bl;
+                memset(&bl, 0, sizeof(bl));
+                uint32_t lw8 = 0, lh8 = 0;
+                bool sm = false;
+                for (uint32_t i = 0; i < mk; ++i) {
+                    jxlgpu_frame* f = frames[k0 + i];
+                    bl.f[i] = f->dev_args;
+                    lw8 = std::max(lw8, f->w8); lh8 = std::max(lh8, f->h8);
+                    sm |= !f->desc.skip_adaptive_lf_smoothing;
+                    if (k0 != i0 && f->ev_last && f->ev_last_set) HIP_TRY(ctx, hipStreamWaitEvent(st, f->ev_last, 0));
+                }
+                HIP_TRY(ctx, launch_lf_batch(st, bl, mk, lw8, lh8, sm));
+            }
+        }
         ctx->prof_end(PROF_LF, st);
         ctx->prof_begin(PROF_TRANSFORM, st);
         const uint32_t heavy = overlap ? ctx->tune.batch_heavy : 0u;
@@ -2201,13 +2223,13 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
             if (overlap && ctx->tune.ring_mode != 0) {
                 // the border rings on the render stream itself, at full occupancy, in front of / behind the streaming kernel
                 if (ctx->tune.ring_mode == 1) HIP_TRY(ctx, launch_post_batch(sp, nullptr, bp, mp, 0, p_ring, !ctx->tune.no_pk));
-                HIP_TRY(ctx, launch_post_batch(sp, nullptr, bp, mp, p_stream, 0, !ctx->tune.no_pk, ctx->tune.post_fast));
+                HIP_TRY(ctx, launch_post_batch(sp, nullptr, bp, mp, p_stream, 0, !ctx->tune.no_pk, ctx->tune.post_fast, ctx->tune.post_lds_pad));
                 if (ctx->tune.ring_mode == 2) HIP_TRY(ctx, launch_post_batch(sp, nullptr, bp, mp, 0, p_ring, !ctx->tune.no_pk));
             } else {
                 // one fork / join per launch: the border rings run beside the streaming kernel
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, sp));
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-                HIP_TRY(ctx, launch_post_batch(sp, ctx->stream2, bp, mp, p_stream, p_ring, !ctx->tune.no_pk, ctx->tune.post_fast));
+                HIP_TRY(ctx, launch_post_batch(sp, ctx->stream2, bp, mp, p_stream, p_ring, !ctx->tune.no_pk, ctx->tune.post_fast, ctx->tune.post_lds_pad));
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
                 HIP_TRY(ctx, hipStreamWaitEvent(sp, ctx->ev_join, 0));
             }

@@ -227,6 +227,12 @@ struct Tuning {
     int batch_chunk = 0;         // JXLGPU_BATCH_CHUNK: > 0: frames per launch of a batch (default: JXLGPU_MAX_BATCH)
     bool int_post = false;       // JXLGPU_INT_POST=1: the post stage of Modular XYB frames reads the integer planes (no float copy by to_float_kernel);
                                  // measured on config 3: 14.7 vs 15.2-15.4 GP/s (the VALU-bound post kernel pays more for the conversion than the copy costs): off
+    bool batch_lf_ahead = false; // JXLGPU_BATCH_LF_AHEAD=1 (experiment, round 6): the LF launches (V1-V3) of EVERY chunk of a batched render in front of
+                                 // the first transform launch, instead of each chunk's in front of its own (the LF smoothing launch of chunk k+1 was
+                                 // seen waiting 0.35 ms behind the border-ring launch of chunk k for registers)
+    int post_lds_pad = 0;        // JXLGPU_POST_LDS_PAD=bytes (experiment, round 6): dynamic LDS reserved per workgroup of the batched packed post
+                                 // launch — 81920 leaves ONE workgroup = one post wave per SIMD on a CU: what a one-pass kernel that keeps a
+                                 // 64-row window of the transform output in LDS would have to live with
     int batch_tr_mult = 1;       // JXLGPU_BATCH_TR_MULT: chunks per LF / transform launch of a batched render (post launches: one chunk)
     int tr_side_max = 16;        // JXLGPU_TR_SIDE_MAX: launches of <= this many frames run the big-shape transforms on the side stream
                                  // (short launches: their tails overlap; +2.7 % at 8 frames per launch, nothing at 32)
@@ -482,7 +488,7 @@ hipError_t launch_lf_batch(hipStream_t s, const FrameBatch& b, uint32_t n, uint3
 hipError_t launch_transform_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, const uint32_t max_wgs[4],
                                   uint32_t max_special, uint32_t mask = 31u);
 hipError_t launch_post_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, uint32_t max_stream_wgs,
-                             uint32_t max_ring, bool pk, bool fast = false);
+                             uint32_t max_ring, bool pk, bool fast = false, int lds_pad = 0);
 hipError_t launch_transform_items(hipStream_t s, int family, const TransformArgs& a, const uint4* entries,
                                   const uint32_t class_first[CLS_COUNT], const uint32_t list_count[CLS_COUNT],
                                   uint32_t num_cus, int wgs_per_cu);

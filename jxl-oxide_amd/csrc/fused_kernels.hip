@@ -873,11 +873,17 @@ hipError_t launch_fused_post(hipStream_t s, jxlgpu_frame* f, const float* const 
 // Default pipeline of n frames: streaming kernel on `s`, border rings beside it on `side` (may be
 // null: same stream).  The caller forks / joins the two streams once per batch.
 hipError_t launch_post_batch(hipStream_t s, hipStream_t side, const FrameBatch& b, uint32_t n, uint32_t max_stream_wgs,
-                             uint32_t max_ring, bool pk, bool fast) {
+                             uint32_t max_ring, bool pk, bool fast, int lds_pad) {
     constexpr size_t lds_bytes = 2 * 3 * PostCfg<true, 2, kRingL, kRingT>::PLANE * sizeof(float);  // 23 KB
     if (max_ring) post_ring_batch_kernel<<<dim3(max_ring, n), 256, lds_bytes, side ? side : s>>>(b);
+    if (lds_pad > 0) {   // JXLGPU_POST_LDS_PAD (experiment): reserved, never touched
+        static std::once_flag once;
+        std::call_once(once, [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&post_pk_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        });
+    }
     if (max_stream_wgs && pk && fast) post_pk_fast_batch_kernel<<<dim3(max_stream_wgs, n), 256, 0, s>>>(b);
-    else if (max_stream_wgs && pk) post_pk_batch_kernel<<<dim3(max_stream_wgs, n), 256, 0, s>>>(b);
+    else if (max_stream_wgs && pk) post_pk_batch_kernel<<<dim3(max_stream_wgs, n), 256, (size_t)std::max(0, lds_pad), s>>>(b);
     else if (max_stream_wgs) post_stream_batch_kernel<<<dim3(max_stream_wgs, n), 256, 0, s>>>(b);
     return hipGetLastError();
 }

@@ -2157,6 +2157,11 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     if (g.w == 0 || g.h == 0 || g.buf < 0) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "cannot squeeze this channel");
                     Grid r = g;
                     r.fwd_step = (int)(&st - sp.data());
+                    // a rectangle that is squeezed AGAIN (explicit steps over earlier residuals, a second Squeeze transform)
+                    // is no longer "the residual of step k": its inverse reads the average half as soon as the later step is
+                    // undone, long before step k is — its predictor waves must not run late (ev_late is only waited for by
+                    // the step that reads a late rectangle as its residual input, or as its average: below)
+                    g.fwd_step = -1;
                     if (g.hshift > 30 || g.vshift > 30) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "channel squeezed too much");
                     if (st.horizontal) {
                         uint32_t len = g.w; g.w = (len + 1) / 2; r.w = len / 2; r.x0 = g.x0 + g.w;
@@ -2478,6 +2483,8 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 if (late_pending) {
                     bool reads_late = false;
                     for (const Grid& r : res) reads_late |= r.fwd_step >= 0 && r.fwd_step < ctx->tune.pred_late_steps;
+                    for (int k = 0; k < count; ++k)   // the average halves as well (never late after the forward bookkeeping above)
+                        reads_late |= l[begin + k].fwd_step >= 0 && l[begin + k].fwd_step < ctx->tune.pred_late_steps;
                     if (reads_late) {
                         // (the chain of small levels queued so far is flushed first: it does not depend on the late residuals)
                         if (i16) flush_chain<int16_t>(s, plan); else flush_chain<int32_t>(s, plan);

@@ -479,10 +479,13 @@ class ModularWorkload:
 
     def __init__(self, width, height, kind="squeeze", seed=0, i16=True, lossy=True, rct_type=None,
                  xyb=True, epf_iters=0, gabor=False, bit_depth=8, predictor=5, pred_offset=0, residual=None,
-                 group_dim=256, leaves=None):
+                 group_dim=256, leaves=None, squeeze_plan=None):
         """`residual` (kinds 'squeeze', 'palette'): a Predictor id — the buffers then hold the RESIDUALS of
         that predictor (single-leaf MA tree) for every transformed channel, computed decode unit by decode
-        unit (channel_tiles) from the transformed samples; None: they hold the samples themselves."""
+        unit (channel_tiles) from the transformed samples; None: they hold the samples themselves.
+        `squeeze_plan` (kind 'squeeze'): one entry per Squeeze transform, applied in order — None = default parameters
+        (set_default_params on the channel list as it stands then), or explicit steps [(horizontal, in_place, begin_c,
+        num_c)]: steps may squeeze the residual channels of earlier steps again."""
         rng = np.random.default_rng(SEED_BASE + 0x100 + seed)
         self.width, self.height, self.kind = width, height, kind
         self.group_dim = group_dim
@@ -549,16 +552,17 @@ class ModularWorkload:
                 self.expected = [p.astype(self.dtype) for p in orig]
             bufs = [p.copy() for p in planes]
             grids = [_Grid(i, 0, 0, W, H) for i in range(3)]
-            steps = default_squeeze_params(grids)
-            nsteps = len(steps)
+            for plan in ([None] if squeeze_plan is None else squeeze_plan):
+                steps = default_squeeze_params(grids) if plan is None else [tuple(st) for st in plan]
+                nsteps = len(steps)
 
-            def quant(level, res):
-                if not lossy:
-                    return res
-                q = 1 << max(0, (nsteps - level) // 5)  # coarser for the finest levels
-                return _trunc_div(res, q) * 1  # quantised residuals (dequantised form is what is coded)
-            forward_squeeze(bufs, grids, steps, quant)
-            self.transforms.append(("squeeze", None))
+                def quant(level, res):
+                    if not lossy:
+                        return res
+                    q = 1 << max(0, (nsteps - level) // 5)  # coarser for the finest levels
+                    return _trunc_div(res, q) * 1  # quantised residuals (dequantised form is what is coded)
+                forward_squeeze(bufs, grids, steps, quant)
+                self.transforms.append(("squeeze", None if plan is None else steps))
             if leaves is not None:
                 self.unit_leaves = residuals_in_place_leaves(bufs, [], grids, 0, group_dim, leaf_rng, predictors=leaf_preds)
             elif residual is not None:
@@ -680,6 +684,7 @@ class ModularWorkload:
         d.num_meta_channels = len(self.meta)
         d.meta_channels = C.cast(metas, C.POINTER(abi.ModularChannel))
         trs = (abi.Transform * len(self.transforms))()
+        sq_keep = []
         for i, t in enumerate(self.transforms):
             if t[0] == "rct":
                 trs[i].kind = abi.TR_RCT
@@ -687,6 +692,13 @@ class ModularWorkload:
             elif t[0] == "squeeze":
                 trs[i].kind = abi.TR_SQUEEZE
                 trs[i].num_sq = 0
+                if t[1]:
+                    sq = (abi.SqueezeStep * len(t[1]))()
+                    for j, (hor, inp, beg, num) in enumerate(t[1]):
+                        sq[j].horizontal, sq[j].in_place, sq[j].begin_c, sq[j].num_c = hor, inp, beg, num
+                    trs[i].num_sq = len(t[1])
+                    trs[i].sq = C.cast(sq, C.POINTER(abi.SqueezeStep))
+                    sq_keep.append(sq)
             else:
                 trs[i].kind = abi.TR_PALETTE
                 trs[i].begin_c, trs[i].num_c, trs[i].nb_colours = t[1], t[2], t[3]
@@ -708,7 +720,7 @@ class ModularWorkload:
         if getattr(self, "ycbcr", False):
             d.color.ycbcr = 1
         d.noise = getattr(self, "noise", abi.NoiseParams())
-        self._keep = [chans, metas, trs]
+        self._keep = [chans, metas, trs, sq_keep]
         if self.unit_leaves is not None:
             lv = (abi.MaLeaf * max(1, len(self.unit_leaves)))()
             for i, (pred, mul, off) in enumerate(self.unit_leaves):

@@ -518,3 +518,19 @@ def test_predictor_squeeze_render_tail(gpu_ctx, oracle):
     finally:
         f.free()
     assert_ulp(got, exp, 1, "lossy Squeeze + WP residuals render")
+
+
+@pytest.mark.parametrize("plan", ["explicit_steps_over_residuals", "two_squeeze_transforms", "appended_then_squeezed"])
+@pytest.mark.parametrize("residual", [None, 6, 5])
+def test_resqueezed_residuals(gpu_ctx, oracle, plan, residual):
+    """A residual rectangle of an early Squeeze step that a later step (or a second Squeeze transform) squeezes again: the
+    inverse of the LATER step reads it as its average input, first.  With the self-correcting predictor the waves of the first
+    steps' residuals run on a side stream (ModularState::ev_late): such a rectangle must not be among them (ADVICE r5)."""
+    from test_oracle_modular import RESQUEEZE_PLANS
+    for size, seed in (((1100, 720), 31), ((600, 333), 32)):
+        wl = ModularWorkload(size[0], size[1], kind="squeeze", lossy=False, xyb=False, seed=seed, residual=residual,
+                             squeeze_plan=RESQUEEZE_PLANS[plan])
+        for _ in range(2):
+            got = _inverse_both(gpu_ctx, oracle, wl)
+            for c in range(3):
+                assert np.array_equal(got[c], wl.expected[c])

@@ -270,3 +270,24 @@ def test_per_unit_leaves_roundtrip(oracle, case):
         wl.unit_leaves = wl.unit_leaves[1:] + wl.unit_leaves[:1]
         got = oracle.modular_inverse(wl.desc(), wl.shapes(), wl.dtype)
         assert not all(np.array_equal(got[c], wl.expected[c]) for c in range(3))
+
+
+# Squeeze plans in which a residual rectangle of an early step is squeezed AGAIN (the device ran the predictor
+# waves of such rectangles late and never waited for them): explicit steps over earlier residuals, and a second Squeeze
+# transform with default parameters behind a partial explicit one (its range covers every channel, residuals included:
+# set_default_params, transform.rs:285-341).  (horizontal, in_place, begin_c, num_c)
+RESQUEEZE_PLANS = {
+    "explicit_steps_over_residuals": [[(1, 1, 0, 3), (0, 1, 0, 3), (1, 1, 0, 3), (0, 1, 9, 3), (1, 1, 9, 3), (0, 1, 0, 3)]],
+    "two_squeeze_transforms": [[(1, 1, 0, 3), (0, 1, 0, 3)], None],
+    "appended_then_squeezed": [[(1, 0, 1, 2), (0, 0, 1, 2), (1, 1, 0, 7), (0, 1, 0, 7), (1, 1, 3, 4)]],
+}
+
+
+@pytest.mark.parametrize("plan", sorted(RESQUEEZE_PLANS))
+@pytest.mark.parametrize("residual", [None, 6])
+def test_resqueezed_residuals_roundtrip(oracle, plan, residual):
+    wl = ModularWorkload(600, 333, kind="squeeze", lossy=False, xyb=False, seed=21, residual=residual,
+                         squeeze_plan=RESQUEEZE_PLANS[plan])
+    got = oracle.modular_inverse(wl.desc(), wl.shapes(), wl.dtype)
+    for c in range(3):
+        assert np.array_equal(got[c], wl.expected[c]), f"channel {c}"
