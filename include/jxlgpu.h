@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define JXLGPU_ABI_VERSION 23u
+#define JXLGPU_ABI_VERSION 24u
 
 /* ---- error codes (map to jxl_render::Error in the Rust shim) ---- */
 #define JXLGPU_OK 0
@@ -541,9 +541,21 @@ typedef struct {
 /* The MA-tree leaf of ONE decode unit (a (group, channel) subgrid), without its entropy-coding cluster:
  * MaTreeLeafClustered { predictor, offset, multiplier } (jxl-modular/src/ma.rs).                     */
 typedef struct {
-    uint32_t predictor;          /* Predictor id 0..13 (jxl-modular/src/predictor.rs:26-41)          */
+    uint32_t predictor;          /* Predictor id 0..13 (jxl-modular/src/predictor.rs:26-41); in `unit_leaves` also
+                                  * JXLGPU_LEAF_BY_ROW / JXLGPU_LEAF_BY_COLUMN (below)                 */
     int32_t multiplier, offset;
 } JxlGpuMaLeaf;
+/* A unit whose (flattened) tree still splits on property 2 (y) or on property 3 (x) — the static properties of
+ * `Properties::get`, predictor.rs:458-478: nothing in them depends on decoded samples, so the host can still read
+ * every token (decode_slow, image.rs:1169-1228, with `get_leaf` a function of the row / the column alone).  Its entry
+ * in `unit_leaves` carries one of these two values as `predictor`, and `multiplier` = the index of its first entry
+ * in `axis_leaves`: one leaf per ROW of the unit's subgrid (BY_ROW: gh entries) or per COLUMN (BY_COLUMN: gw
+ * entries), each a plain leaf (predictor 0..13).  The unit keeps ONE PredictorState; the self-correcting predictor's
+ * state is kept for every sample of the unit as soon as one of its leaves uses it (FlatMaTree::need_self_correcting,
+ * ma.rs:275-285).  A tree that splits on y AND x inside one unit is not served (JXLGPU_ERR_UNSUPPORTED is the
+ * caller's to raise: there is no encoding for it here).  `offset` of such an entry must be 0.          */
+#define JXLGPU_LEAF_BY_ROW 14u
+#define JXLGPU_LEAF_BY_COLUMN 15u
 
 typedef struct {
     uint32_t abi;
@@ -605,6 +617,10 @@ typedef struct {
      * wrong count is JXLGPU_ERR_INVALID_ARG at the first inverse.  The array is copied by jxlgpu_modular_upload.       */
     const JxlGpuMaLeaf* unit_leaves;
     uint32_t num_unit_leaves;
+    /* ABI 24: the per-row / per-column leaves of the units marked JXLGPU_LEAF_BY_ROW / _BY_COLUMN in unit_leaves
+     * (null / 0 when there are none).  Copied by jxlgpu_modular_upload.                                        */
+    const JxlGpuMaLeaf* axis_leaves;
+    uint32_t num_axis_leaves;
 } JxlGpuModularDesc;
 
 #define JXLGPU_STAGE_MODULAR_INVERSE 0x02u /* same bit as TRANSFORM: inverse Squeeze/RCT/Palette    */

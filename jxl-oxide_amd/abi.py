@@ -6,7 +6,7 @@ the HIP library is missing — there is no CPU fallback in this package.
 import ctypes as C
 import os
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 NUM_TRANSFORMS = 27
 
 OK = 0
@@ -43,6 +43,7 @@ MEM_DEVICE = 1
 MEM_HOST_PINNED = 2
 
 TR_RCT, TR_PALETTE, TR_SQUEEZE = 0, 1, 2
+LEAF_BY_ROW, LEAF_BY_COLUMN = 14, 15   # JxlGpuMaLeaf.predictor in unit_leaves: the unit's leaves come per row / column from axis_leaves
 
 # TransformType (jxl-vardct/src/dct_select.rs:4-32) -> (bw, bh) in 8x8 cells (:52-76)
 DCT_SELECT_SIZE = [
@@ -293,6 +294,8 @@ class ModularDesc(C.Structure):
         ("color", ColorParams),
         ("unit_leaves", C.POINTER(MaLeaf)),
         ("num_unit_leaves", C.c_uint32),
+        ("axis_leaves", C.POINTER(MaLeaf)),
+        ("num_axis_leaves", C.c_uint32),
     ]
 
 

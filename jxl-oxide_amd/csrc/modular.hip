@@ -905,12 +905,17 @@ struct PredTile {
     uint32_t packed;         // 1: handled by the lane-packed kernel (P lanes of a wave), 0: a workgroup of its own
     // the unit's MA-tree leaf (MaTreeLeafClustered without its cluster): the frame's one leaf, or the unit's own
     // (JxlGpuModularDesc::unit_leaves: trees that split on the static properties channel / stream index, make_flat_tree)
+    // ... or, predictor == JXLGPU_LEAF_BY_ROW / _BY_COLUMN: a tree that still splits on y / x inside the unit (decode_slow,
+    // image.rs:1169-1228, with get_leaf a function of the row / column alone): the leaf of a sample is PredArgs::axis[mul + row]
+    // resp. [mul + column]; `sc` = one of those leaves is the self-correcting predictor, whose state is then kept for every
+    // sample of the unit (FlatMaTree::need_self_correcting, ma.rs:275-285).  Kernels compiled with MAPPED serve these.
     uint32_t predictor;
     int32_t mul, off;
-    uint32_t pad;
+    uint32_t sc;
 };
 struct PredArgs {
     const PredTile* tiles;
+    const JxlGpuMaLeaf* axis;  // JxlGpuModularDesc::axis_leaves on the device (MAPPED kernels)
     void* sink;              // 64 samples nobody reads: where off-grid lanes of the one-wave kernels store
     uint32_t err_w;          // columns of the error rows in dynamic LDS (>= the widest subgrid; 1 when unused)
     int32_t wp[11];
@@ -918,7 +923,7 @@ struct PredArgs {
 
 __device__ __forceinline__ uint32_t div_lookup_dev(uint32_t i) { return i == 0 ? 0u : (1u << 24) / i; }  // predictor.rs:150-160
 
-template <typename S>
+template <typename S, bool MAPPED = false>
 __global__ __launch_bounds__(256) void predict_tiles_kernel(PredArgs a) {
     // the self-correcting predictor's error rows: 5 x err_w words of dynamic LDS (err_w = widest subgrid of the launch)
     extern __shared__ int32_t s_err[];
@@ -936,8 +941,8 @@ __global__ __launch_bounds__(256) void predict_tiles_kernel(PredArgs a) {
     const uint32_t r = threadIdx.x;
     S* row = (S*)t.base + (size_t)r * t.stride;
     const bool have_row = r < gh;
-    const uint32_t predictor = t.predictor;   // one subgrid per workgroup: uniform
-    const bool sc_on = predictor == 6;
+    const uint32_t tile_pred = t.predictor;   // one subgrid per workgroup: uniform
+    const bool sc_on = tile_pred == 6 || (MAPPED && tile_pred >= JXLGPU_LEAF_BY_ROW && t.sc);
     for (uint32_t i = r; i < 5 * a.err_w; i += 256) s_err[i] = 0;
     __syncthreads();
     const int32_t* prev = s_out[r > 0 ? r - 1 : 0];
@@ -1031,6 +1036,14 @@ __global__ __launch_bounds__(256) void predict_tiles_kernel(PredArgs a) {
                     }
 
                     // Predictor::predict, predictor.rs:79-125
+                    uint32_t predictor = tile_pred;
+                    int32_t lmul = t.mul, loff = t.off;
+                    if constexpr (MAPPED) {
+                        if (tile_pred >= JXLGPU_LEAF_BY_ROW) {   // the sample's own leaf: by row (property 2) or by column (property 3)
+                            const JxlGpuMaLeaf lf = a.axis[(uint32_t)t.mul + (tile_pred == JXLGPU_LEAF_BY_ROW ? r : (uint32_t)x)];
+                            predictor = lf.predictor; lmul = lf.multiplier; loff = lf.offset;
+                        }
+                    }
                     int32_t pred;
                     {
                         const int64_t N = n, W = w, NW = nw;
@@ -1063,7 +1076,7 @@ __global__ __launch_bounds__(256) void predict_tiles_kernel(PredArgs a) {
                     }
                     // decode_one: diff = residual.wrapping_muladd_i32(multiplier, offset); diff.add(prediction)
                     const S res = (S)s_in[r][x & (kRing - 1)];
-                    const S diff = Wrap<S>::add(Wrap<S>::mul(res, (S)t.mul), (S)t.off);
+                    const S diff = Wrap<S>::add(Wrap<S>::mul(res, (S)lmul), (S)loff);
                     const S value = Wrap<S>::add(diff, (S)pred);
                     row[x] = value;
                     const int32_t sample = (int32_t)value;
@@ -1166,7 +1179,7 @@ struct PredSrc {
 // `srcs` / `wave_flags` non-null: the redo pass behind predict_lanes_narrow_kernel — only flagged waves run, and
 // they read the residuals from `srcs` (the narrow pass has written over `base`).
 // VEC: four-sample global accesses, as in predict_lanes_narrow_kernel below.
-template <typename S, bool VEC, int RO>
+template <typename S, bool VEC, int RO, bool MAPPED = false>
 __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const PredWave* waves, const PredSrc* srcs,
                                                            const uint32_t* wave_flags) {
     if (wave_flags && wave_flags[blockIdx.x] == 0) return;
@@ -1193,8 +1206,10 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
     if (lane == 0) s_div[64] = div_lookup_dev(64);
     __syncthreads();
     // the subgrids of a wave share their predictor (the host forms waves by it); multiplier and offset are the subgrid's own
-    const uint32_t predictor = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tiles[wv.first].predictor);
-    const bool sc_on = predictor == 6;
+    // (MAPPED: a wave's subgrids share the marker BY_ROW / BY_COLUMN; the leaf is the sample's own, fetched per step — a
+    //  load inside the step loop, which is why this is a separate instantiation: see the note on counted accesses below)
+    const uint32_t wave_pred = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tiles[wv.first].predictor);
+    const bool sc_on = wave_pred == 6 || (MAPPED && wave_pred >= JXLGPU_LEAF_BY_ROW && t.sc);
     // rows r - 1 and r - 2 live in the rings of lanes k - 1 and k - 2 (mod P), one round back where the index wrapped
     const uint32_t lane0 = lane & ~(P - 1);
     uint32_t wrap1 = 0, wrap2 = 0;
@@ -1316,6 +1331,14 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
                     sc_prediction = prediction;
                 }
 
+                uint32_t predictor = wave_pred;
+                int32_t lmul = t.mul, loff = t.off;
+                if constexpr (MAPPED) {
+                    if (wave_pred >= JXLGPU_LEAF_BY_ROW) {
+                        const JxlGpuMaLeaf lf = a.axis[(uint32_t)t.mul + (wave_pred == JXLGPU_LEAF_BY_ROW ? r : ux)];
+                        predictor = lf.predictor; lmul = lf.multiplier; loff = lf.offset;
+                    }
+                }
                 int32_t pred;
                 {
                     const int64_t N = n, W = w, NW = nw;
@@ -1347,7 +1370,7 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
                     }
                 }
                 const S res = (S)s_in[lane][u & (kRing - 1)];
-                const S diff = Wrap<S>::add(Wrap<S>::mul(res, (S)t.mul), (S)t.off);
+                const S diff = Wrap<S>::add(Wrap<S>::mul(res, (S)lmul), (S)loff);
                 const S value = Wrap<S>::add(diff, (S)pred);
                 st_value = value;
                 st_ptr = as_global((S*)t.base + (size_t)r * t.stride + ux);
@@ -1962,6 +1985,8 @@ struct ModularState {
     ~ModularState() { if (ev_late) (void)hipEventDestroy(ev_late); }
     bool pred_narrow = false;
     std::vector<JxlGpuMaLeaf> unit_leaves;   // copy of JxlGpuModularDesc::unit_leaves (empty: the frame's one leaf)
+    std::vector<JxlGpuMaLeaf> axis_leaves;   // copy of JxlGpuModularDesc::axis_leaves (per-row / per-column leaves of the units marked BY_ROW / BY_COLUMN)
+    JxlGpuMaLeaf* d_axis_leaves = nullptr;   // ... on the device
     bool pred_big_ring = false;   // a subgrid wider than 512 columns: rows trail by D = 16, the lane kernels with the 64-column sample ring
     float* fpix[3] = {};
 };
@@ -2237,7 +2262,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             const JxlGpuMaLeaf* leaves = m->unit_leaves.empty() ? nullptr : m->unit_leaves.data() + unit_base;
             unit_base += (size_t)ncols * nrows;
             bool chan_wp = !leaves && one_leaf.predictor == 6;
-            for (size_t u = 0; leaves && u < (size_t)ncols * nrows; ++u) chan_wp |= leaves[u].predictor == 6;
+            for (size_t u = 0; leaves && u < (size_t)ncols * nrows; ++u) chan_wp |= leaves[u].predictor == 6 || leaves[u].predictor >= JXLGPU_LEAF_BY_ROW;
             if (!lanes_ok && (th > 256 || (chan_wp && tw > kPredMaxTileW)))
                 return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tile wider than 1024 columns with more than 256 rows (or wider than 1024 with the self-correcting predictor)");
             uint32_t stride = 0;
@@ -2252,9 +2277,19 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     const uint32_t gw = std::min(tw, g.w - x0), gh = std::min(th, g.h - y0);
                     if (gw == 0 || gh == 0) continue;
                     const JxlGpuMaLeaf& lf = leaves ? leaves[(size_t)gy * ncols + gx] : one_leaf;
-                    any_wp |= lf.predictor == 6; all_wp &= lf.predictor == 6;
+                    uint32_t tile_sc = 0;
+                    if (lf.predictor >= JXLGPU_LEAF_BY_ROW) {
+                        // a tree that splits on y / x inside the unit: its per-row / per-column leaves
+                        const size_t need = lf.predictor == JXLGPU_LEAF_BY_ROW ? gh : gw;
+                        if (lf.multiplier < 0 || lf.offset != 0 || (size_t)lf.multiplier + need > m->axis_leaves.size())
+                            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "a per-row / per-column unit leaf points outside axis_leaves");
+                        for (size_t q = 0; q < need; ++q) tile_sc |= m->axis_leaves[(size_t)lf.multiplier + q].predictor == 6 ? 1u : 0u;
+                        any_wp |= tile_sc != 0; all_wp = false;
+                    } else {
+                        any_wp |= lf.predictor == 6; all_wp &= lf.predictor == 6;
+                    }
                     tiles.push_back(PredTile{base + ((size_t)y0 * stride + x0) * esz, stride, gw, gh, lanes_ok ? 1u : 0u,
-                                             lf.predictor, lf.multiplier, lf.offset, 0u});
+                                             lf.predictor, lf.multiplier, lf.offset, tile_sc});
                     tile_src[tiles.back().base] = src_base + ((size_t)y0 * stride + x0) * esz;
                     tile_late[tiles.back().base] = (lanes_ok && g.fwd_step >= 0 && g.fwd_step < late_steps) ? 1 : 0;
                     if (!lanes_ok) max_w = std::max(max_w, gw);
@@ -2272,7 +2307,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             // four-sample accesses: both copies of the subgrid aligned to four samples, rows too, width a multiple of four
             auto vec_of = [&](const PredTile& t) {
                 const uintptr_t al = 4 * esz;
-                return (uintptr_t)t.base % al == 0 && (uintptr_t)tile_src[t.base] % al == 0 && t.stride % 4 == 0 && t.gw % 4 == 0;
+                return t.predictor < JXLGPU_LEAF_BY_ROW && (uintptr_t)t.base % al == 0 && (uintptr_t)tile_src[t.base] % al == 0 && t.stride % 4 == 0 && t.gw % 4 == 0;
             };
             // wide subgrids first (own launch), then the lane-packed ones by (vec, P, DP), longest chains first inside a class
             std::stable_sort(tiles.begin(), tiles.end(), [&](const PredTile& x, const PredTile& y) {
@@ -2333,6 +2368,10 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             if (int rc = malloc_dev(ctx, f, &m->pred_srcs, std::max<size_t>(srcs.size(), 1) * sizeof(PredSrc))) return rc;
             if (int rc = malloc_dev(ctx, f, &m->pred_flags, std::max<size_t>(waves.size(), 1) * sizeof(uint32_t))) return rc;
             if (int rc = malloc_dev(ctx, f, &m->pred_sink, 1024)) return rc;
+            if (!m->axis_leaves.empty()) {
+                if (int rc = malloc_dev(ctx, f, &m->d_axis_leaves, m->axis_leaves.size() * sizeof(JxlGpuMaLeaf))) return rc;
+                HIP_TRY(ctx, hipMemcpy(m->d_axis_leaves, m->axis_leaves.data(), m->axis_leaves.size() * sizeof(JxlGpuMaLeaf), hipMemcpyHostToDevice));
+            }
             // blocking copies from the host vectors: the lists are built once per frame (the geometry never changes)
             if (!tiles.empty()) {
                 HIP_TRY(ctx, hipMemcpy(m->pred_tiles, tiles.data(), tiles.size() * sizeof(PredTile), hipMemcpyHostToDevice));
@@ -2351,12 +2390,17 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
         }
         if (m->n_pred_tiles) {
             PredArgs pa;
-            pa.tiles = m->pred_tiles; pa.sink = m->pred_sink;
+            pa.tiles = m->pred_tiles; pa.sink = m->pred_sink; pa.axis = m->d_axis_leaves;
             for (int k = 0; k < 11; ++k) pa.wp[k] = m->desc.wp_params[k];
+            // a frame with per-row / per-column leaves: the MAPPED instantiations (they serve plain units as well)
+            const bool mapped = m->d_axis_leaves != nullptr;
             if (m->n_pred_wide) {
                 pa.err_w = m->pred_err_w;
                 const size_t lds = (size_t)5 * m->pred_err_w * 4;
-                if (i16) predict_tiles_kernel<int16_t><<<m->n_pred_wide, 256, lds, s>>>(pa);
+                if (mapped) {
+                    if (i16) predict_tiles_kernel<int16_t, true><<<m->n_pred_wide, 256, lds, s>>>(pa);
+                    else predict_tiles_kernel<int32_t, true><<<m->n_pred_wide, 256, lds, s>>>(pa);
+                } else if (i16) predict_tiles_kernel<int16_t><<<m->n_pred_wide, 256, lds, s>>>(pa);
                 else predict_tiles_kernel<int32_t><<<m->n_pred_wide, 256, lds, s>>>(pa);
             }
             if (m->n_pred_waves) {
@@ -2365,6 +2409,15 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 auto lanes_launch = [&](hipStream_t st, uint32_t first, uint32_t count, bool vec, const PredSrc* srcs, const uint32_t* flags) {
                     auto go = [&](auto kern) { kern<<<count, 64, lds, st>>>(pa, m->pred_waves + first, srcs, flags); };
                     const int sel = (i16 ? 4 : 0) | (vec ? 2 : 0) | (m->pred_big_ring ? 1 : 0);
+                    if (mapped && !vec) {   // (the four-sample waves never hold a mapped unit: vec_of)
+                        switch (sel) {
+                            case 0: go(predict_lanes_kernel<int32_t, false, kRing, true>); break;
+                            case 1: go(predict_lanes_kernel<int32_t, false, kBigRing, true>); break;
+                            case 4: go(predict_lanes_kernel<int16_t, false, kRing, true>); break;
+                            default: go(predict_lanes_kernel<int16_t, false, kBigRing, true>); break;
+                        }
+                        return;
+                    }
                     switch (sel) {
                         case 0: go(predict_lanes_kernel<int32_t, false, kRing>); break;
                         case 1: go(predict_lanes_kernel<int32_t, false, kBigRing>); break;
@@ -2646,8 +2699,15 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
         if (const char* why = color_params_unsupported(d->color)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, why);
     if ((d->residual_predictor <= 13 || d->num_unit_leaves) && d->group_dim > kPredLaneMaxW) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tiles wider than 1024");
     if (d->num_unit_leaves && !d->unit_leaves) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null unit_leaves");
-    for (uint32_t i = 0; i < d->num_unit_leaves; ++i)
-        if (d->unit_leaves[i].predictor > 13) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "a unit leaf's predictor is not a Predictor (0..13)");
+    if (d->num_axis_leaves && !d->axis_leaves) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null axis_leaves");
+    for (uint32_t i = 0; i < d->num_axis_leaves; ++i)
+        if (d->axis_leaves[i].predictor > 13) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "a per-row / per-column leaf's predictor is not a Predictor (0..13)");
+    for (uint32_t i = 0; i < d->num_unit_leaves; ++i) {
+        const JxlGpuMaLeaf& lf = d->unit_leaves[i];
+        if (lf.predictor > JXLGPU_LEAF_BY_COLUMN) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "a unit leaf's predictor is neither a Predictor (0..13) nor JXLGPU_LEAF_BY_ROW / _BY_COLUMN");
+        if (lf.predictor >= JXLGPU_LEAF_BY_ROW && (lf.multiplier < 0 || lf.offset != 0 || (uint32_t)lf.multiplier >= d->num_axis_leaves))
+            return fail(ctx, JXLGPU_ERR_INVALID_ARG, "a per-row / per-column unit leaf: multiplier is the first index into axis_leaves, offset 0");
+    }
     if (d->num_transforms && !d->transforms) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null transform list");
     if (d->num_meta_channels && !d->meta_channels) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null meta channel list");
     for (uint32_t c = 0; c < d->num_meta_channels; ++c)
@@ -2688,6 +2748,8 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
     m->desc = *d;
     if (d->num_unit_leaves) m->unit_leaves.assign(d->unit_leaves, d->unit_leaves + d->num_unit_leaves);
     m->desc.unit_leaves = nullptr;   // (the caller's array may be gone after this call)
+    if (d->num_axis_leaves) m->axis_leaves.assign(d->axis_leaves, d->axis_leaves + d->num_axis_leaves);
+    m->desc.axis_leaves = nullptr;
     m->esz = d->sample_type == JXLGPU_SAMPLE_I16 ? 2 : 4;
     for (uint32_t c = 0; c < d->num_channels; ++c) {
         const JxlGpuModularChannel& ch = d->channels[c];

@@ -250,10 +250,16 @@ def channel_units(grids, nb_meta, group_dim):
     return out
 
 
-def residuals_in_place_leaves(bufs, metas, grids, nb_meta, group_dim, rng, wp=None, predictors=None):
+def residuals_in_place_leaves(bufs, metas, grids, nb_meta, group_dim, rng, wp=None, predictors=None, axis_leaves=None):
     """Like residuals_in_place, with a leaf of its own for every decode unit — what a tree that splits on the static
     properties channel / stream index gives (make_flat_tree, ma.rs:38-41): predictor drawn per unit, multiplier 1 (the chain
-    stays lossless), a small offset.  Returns the leaves [(predictor, multiplier, offset)] in unit_leaves order."""
+    stays lossless), a small offset.  Returns the leaves [(predictor, multiplier, offset)] in unit_leaves order.
+    `axis_leaves` (a list, appended to): about half of the units get a tree that splits on y (property 2) or on x (property 3)
+    instead — runs of rows / columns with a leaf each, as thresholds on one property give; their unit entry is
+    (LEAF_BY_ROW | LEAF_BY_COLUMN, first index into axis_leaves, 0) and axis_leaves receives one leaf per row / column.  The
+    residual of a sample is that of ITS leaf's predictor computed from the finished image: the predictor state (and the
+    self-correcting predictor's, whose residuals come from the independent forward of synth_wp.c run over the whole unit) does
+    not depend on which leaf coded the other samples."""
     predictors = list(range(14)) if predictors is None else predictors
     leaves = []
     for g, units in zip(grids, channel_units(grids, nb_meta, group_dim)):
@@ -263,11 +269,36 @@ def residuals_in_place_leaves(bufs, metas, grids, nb_meta, group_dim, rng, wp=No
         for u in units:
             pred = int(predictors[int(rng.integers(0, len(predictors)))])
             off = int(rng.integers(-3, 4))
-            leaves.append((pred, 1, off))
-            if u is None:
+            mapped = axis_leaves is not None and u is not None and rng.random() < 0.5
+            if not mapped:
+                leaves.append((pred, 1, off))
+                if u is None:
+                    continue
+                x0, y0, w, h = u
+                view[y0:y0 + h, x0:x0 + w] = tile_residuals(src[y0:y0 + h, x0:x0 + w].astype(np.int64), pred, off, wp)
                 continue
             x0, y0, w, h = u
-            view[y0:y0 + h, x0:x0 + w] = tile_residuals(src[y0:y0 + h, x0:x0 + w].astype(np.int64), pred, off, wp)
+            by_row = bool(rng.integers(0, 2))
+            n = h if by_row else w
+            # 1..5 runs along the axis (thresholds of a small tree), a leaf each
+            cuts = sorted(set(int(c) for c in rng.integers(1, max(n, 2), size=int(rng.integers(0, 5))) if c < n))
+            bounds = [0] + cuts + [n]
+            per = []
+            for a, b in zip(bounds[:-1], bounds[1:]):
+                lp = int(predictors[int(rng.integers(0, len(predictors)))])
+                lo = int(rng.integers(-3, 4))
+                per += [(lp, 1, lo)] * (b - a)
+            leaves.append((abi.LEAF_BY_ROW if by_row else abi.LEAF_BY_COLUMN, len(axis_leaves), 0))
+            axis_leaves += per
+            tile = src[y0:y0 + h, x0:x0 + w].astype(np.int64)
+            res_of = {p_: tile_residuals(tile, p_, 0, wp) for p_ in sorted({p_ for p_, _, _ in per})}
+            out = np.empty_like(tile)
+            for i, (lp, _, lo) in enumerate(per):
+                if by_row:
+                    out[i, :] = res_of[lp][i, :] - lo
+                else:
+                    out[:, i] = res_of[lp][:, i] - lo
+            view[y0:y0 + h, x0:x0 + w] = out
     return leaves
 
 
@@ -505,8 +536,10 @@ class ModularWorkload:
         # `leaves` = "mixed" (kinds 'predictor', 'squeeze', 'palette'): every decode unit gets a leaf of its own
         # (JxlGpuModularDesc::unit_leaves); a list of predictor ids restricts the draw
         self.unit_leaves = None
+        # `leaves` = "axis": as "mixed", and about half of the units carry a tree that splits on y or on x (JxlGpuModularDesc::axis_leaves)
+        self.axis_leaves = [] if leaves == "axis" else None
         leaf_rng = np.random.default_rng(SEED_BASE + 0x777 + seed)
-        leaf_preds = None if leaves in (None, "mixed") else list(leaves)
+        leaf_preds = None if leaves in (None, "mixed", "axis") else list(leaves)
 
         if kind == "predictor":
             # single-leaf tree with an arbitrary predictor on plain RGB8 (no transforms)
@@ -515,7 +548,7 @@ class ModularWorkload:
             if leaves is not None:
                 chans = [p.copy() for p in rgb]
                 self.unit_leaves = residuals_in_place_leaves(chans, [], [_Grid(i, 0, 0, W, H) for i in range(3)], 0, group_dim,
-                                                             leaf_rng, predictors=leaf_preds)
+                                                             leaf_rng, predictors=leaf_preds, axis_leaves=self.axis_leaves)
             elif predictor == 6:
                 chans = [weighted_residuals(p, group_dim) for p in rgb]
             else:
@@ -564,7 +597,7 @@ class ModularWorkload:
                 forward_squeeze(bufs, grids, steps, quant)
                 self.transforms.append(("squeeze", None if plan is None else steps))
             if leaves is not None:
-                self.unit_leaves = residuals_in_place_leaves(bufs, [], grids, 0, group_dim, leaf_rng, predictors=leaf_preds)
+                self.unit_leaves = residuals_in_place_leaves(bufs, [], grids, 0, group_dim, leaf_rng, predictors=leaf_preds, axis_leaves=self.axis_leaves)
             elif residual is not None:
                 residuals_in_place(bufs, [], grids, 0, group_dim, residual, pred_offset)
                 self.residual_predictor, self.residual_offset = residual, pred_offset
@@ -580,7 +613,7 @@ class ModularWorkload:
                 grids = [_Grid(~0, 0, 0, ncol, 3, -1, -1), _Grid(0, 0, 0, W, H)]
                 bufs, metas = [idx], [pal]
                 if leaves is not None:
-                    self.unit_leaves = residuals_in_place_leaves(bufs, metas, grids, 1, group_dim, leaf_rng, predictors=leaf_preds)
+                    self.unit_leaves = residuals_in_place_leaves(bufs, metas, grids, 1, group_dim, leaf_rng, predictors=leaf_preds, axis_leaves=self.axis_leaves)
                 else:
                     residuals_in_place(bufs, metas, grids, 1, group_dim, residual, pred_offset)
                     self.residual_predictor, self.residual_offset = residual, pred_offset
@@ -618,7 +651,7 @@ class ModularWorkload:
             forward_squeeze(bufs, grids, default_squeeze_params(grids), lambda level, res: res)
             self.transforms.append(("squeeze", None))
             if leaves is not None:
-                self.unit_leaves = residuals_in_place_leaves(bufs, [], grids, 0, group_dim, leaf_rng, predictors=leaf_preds)
+                self.unit_leaves = residuals_in_place_leaves(bufs, [], grids, 0, group_dim, leaf_rng, predictors=leaf_preds, axis_leaves=self.axis_leaves)
             elif residual is not None:
                 residuals_in_place(bufs, [], grids, 0, group_dim, residual, pred_offset)
                 self.residual_predictor, self.residual_offset = residual, pred_offset
@@ -728,4 +761,11 @@ class ModularWorkload:
             d.unit_leaves = C.cast(lv, C.POINTER(abi.MaLeaf))
             d.num_unit_leaves = len(self.unit_leaves)
             self._keep.append(lv)
+            if self.axis_leaves:
+                al = (abi.MaLeaf * len(self.axis_leaves))()
+                for i, (pred, mul, off) in enumerate(self.axis_leaves):
+                    al[i].predictor, al[i].multiplier, al[i].offset = pred, mul, off
+                d.axis_leaves = C.cast(al, C.POINTER(abi.MaLeaf))
+                d.num_axis_leaves = len(self.axis_leaves)
+                self._keep.append(al)
         return d

@@ -405,6 +405,17 @@ int jxl_oracle_modular_inverse(const JxlGpuModularDesc* d, void* const* out) {
                 const uint32_t predictor = leaves ? leaves[t].predictor : d->residual_predictor;
                 const int32_t multiplier = leaves ? leaves[t].multiplier : d->residual_multiplier;
                 const int32_t offset = leaves ? leaves[t].offset : d->residual_offset;
+                if (leaves && (predictor == JXLGPU_LEAF_BY_ROW || predictor == JXLGPU_LEAF_BY_COLUMN)) {
+                    /* a tree that splits on y / x inside the unit: one leaf per row / column from axis_leaves */
+                    const size_t need = predictor == JXLGPU_LEAF_BY_ROW ? gh : gw;
+                    if (multiplier < 0 || offset != 0 || !d->axis_leaves || (size_t)multiplier + need > d->num_axis_leaves) { bad_leaf = 1; continue; }
+                    const JxlGpuMaLeaf* al = d->axis_leaves + multiplier;
+                    int ok = 1;
+                    for (size_t k = 0; k < need; ++k) ok &= al[k].predictor <= 13;
+                    if (!ok) { bad_leaf = 1; continue; }
+                    orc_predict_apply_leaves(p, stride, gw, gh, (int)esz, predictor == JXLGPU_LEAF_BY_ROW ? 1 : 2, al, d->wp_params);
+                    continue;
+                }
                 if (predictor > 13) { bad_leaf = 1; continue; }
                 const int simple_grad = predictor == 5 && offset == 0 && multiplier == 1;   /* image.rs:762 */
                 if (!simple_grad) orc_predict_apply(p, stride, gw, gh, (int)esz, predictor, multiplier, offset, d->wp_params);

@@ -79,6 +79,8 @@ int orc_render_noise(float* const ch[3], size_t stride, size_t width, size_t hei
 void orc_noise_group(uint32_t width, uint32_t height, uint64_t seed0, uint64_t seed1, float* out, uint32_t* stride_out);
 
 /* predict.c: single-leaf predictor application on one tile (residuals -> samples, in place) */
+void orc_predict_apply_leaves(void* tile, size_t stride, size_t width, size_t height, int esz, int axis,
+                              const JxlGpuMaLeaf* leaves, const int32_t wp[11]);
 void orc_predict_apply(void* tile, size_t stride, size_t width, size_t height, int esz, uint32_t predictor,
                        int32_t multiplier, int32_t offset, const int32_t wp[11]);
 

@@ -195,9 +195,14 @@ static void ps_record(PState* p, int32_t sample) {
 }
 
 /* One tile (a Modular group channel): residuals -> samples in place.  `esz` 2 = i16, 4 = i32.
- * wp = {p1, p2, p3a..p3e, w0..w3} (WpHeader) for predictor 6. */
-void orc_predict_apply(void* tile, size_t stride, size_t width, size_t height, int esz, uint32_t predictor,
-                       int32_t multiplier, int32_t offset, const int32_t wp[11]) {
+ * wp = {p1, p2, p3a..p3e, w0..w3} (WpHeader) for predictor 6.
+ * `axis`: 0 = one leaf for the tile (leaves[0]); 1 = the leaf of a sample is leaves[y] (a tree that splits on property 2);
+ * 2 = leaves[x] (property 3) — decode_slow, image.rs:1169-1228, with get_leaf a function of the row / column alone.
+ * One PredictorState per tile either way; the self-correcting predictor's state is kept for EVERY sample as soon as one
+ * leaf uses it (PredictorState::reset with the WpHeader when FlatMaTree::need_self_correcting, ma.rs:275-285,
+ * image.rs:556-560; properties() then runs it per sample, predictor.rs:206-212). */
+void orc_predict_apply_leaves(void* tile, size_t stride, size_t width, size_t height, int esz, int axis,
+                              const JxlGpuMaLeaf* leaves, const int32_t wp[11]) {
     if (width == 0 || height == 0) return;
     PState ps;
     memset(&ps, 0, sizeof(ps));
@@ -206,7 +211,10 @@ void orc_predict_apply(void* tile, size_t stride, size_t width, size_t height, i
     ps.curr_row = (int32_t*)calloc(width, 4);
     ScPred sc;
     memset(&sc, 0, sizeof(sc));
-    if (predictor == 6) {
+    const size_t nleaves = axis == 0 ? 1 : (axis == 1 ? height : width);
+    int use_sc = 0;
+    for (size_t i = 0; i < nleaves; ++i) use_sc |= leaves[i].predictor == 6;
+    if (use_sc) {
         sc.width = (uint32_t)width;
         sc.true_err_row = (int32_t*)calloc(width, 4);
         sc.subpred_err_row = (uint32_t(*)[4])calloc(width, 16);
@@ -216,8 +224,12 @@ void orc_predict_apply(void* tile, size_t stride, size_t width, size_t height, i
     }
     for (size_t y = 0; y < height; ++y) {
         for (size_t x = 0; x < width; ++x) {
+            const JxlGpuMaLeaf* lf = &leaves[axis == 0 ? 0 : (axis == 1 ? y : x)];
+            const uint32_t predictor = lf->predictor;
+            const int32_t multiplier = lf->multiplier, offset = lf->offset;
             ScResult r;
-            if (predictor == 6) r = sc_predict(&sc, ps.n, ps.nw, ps_ne(&ps), ps.w, ps_nn(&ps));
+            memset(&r, 0, sizeof(r));
+            if (use_sc) r = sc_predict(&sc, ps.n, ps.nw, ps_ne(&ps), ps.w, ps_nn(&ps));
             int32_t pred = predict(&ps, predictor, &r);
             int32_t value;
             if (esz == 2) {
@@ -233,12 +245,18 @@ void orc_predict_apply(void* tile, size_t stride, size_t width, size_t height, i
                 *px = v;
                 value = v;
             }
-            if (predictor == 6) sc_record(&sc, &r, value);
+            if (use_sc) sc_record(&sc, &r, value);
             ps_record(&ps, value);
         }
     }
     free(ps.prev_row); free(ps.curr_row);
     free(sc.true_err_row); free(sc.subpred_err_row);
+}
+
+void orc_predict_apply(void* tile, size_t stride, size_t width, size_t height, int esz, uint32_t predictor,
+                       int32_t multiplier, int32_t offset, const int32_t wp[11]) {
+    const JxlGpuMaLeaf lf = {predictor, multiplier, offset};
+    orc_predict_apply_leaves(tile, stride, width, height, esz, 0, &lf, wp);
 }
 
 /* The predictor pass of Palette::inverse_inner's slow path (transform/palette.rs:112-142): one

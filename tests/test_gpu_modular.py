@@ -534,3 +534,52 @@ def test_resqueezed_residuals(gpu_ctx, oracle, plan, residual):
             got = _inverse_both(gpu_ctx, oracle, wl)
             for c in range(3):
                 assert np.array_equal(got[c], wl.expected[c])
+
+
+def _axis_cases():
+    from test_oracle_modular import AXIS_TREE_CASES
+    return AXIS_TREE_CASES + [dict(width=1100, height=720, kind="squeeze", lossy=False, xyb=False, seed=46, i16=False),
+                              dict(width=1100, height=1060, kind="predictor", seed=47, group_dim=1024)]
+
+
+@pytest.mark.parametrize("case", range(7))
+def test_row_column_property_trees(gpu_ctx, oracle, case):
+    """Trees that still split on property 2 (y) / 3 (x) inside a decode unit: JxlGpuModularDesc::axis_leaves (ABI 24), one leaf
+    per row or per column of the unit, one PredictorState per unit (decode_slow, image.rs:1169-1228).  Device = oracle = the
+    original image (the residuals come from the independent forward)."""
+    from test_oracle_modular import _axis_workload
+    wl = _axis_workload(_axis_cases()[case])
+    kinds = {p for p, _, _ in wl.unit_leaves}
+    assert abi.LEAF_BY_ROW in kinds and abi.LEAF_BY_COLUMN in kinds
+    got = _inverse_both(gpu_ctx, oracle, wl)
+    for c in range(3):
+        assert np.array_equal(got[c], wl.expected[c])
+
+
+def test_row_column_property_trees_workgroup_kernel(oracle, monkeypatch):
+    """The same through the workgroup-per-subgrid kernel (JXLGPU_PRED_WG), and what the upload refuses."""
+    from jxl_oxide_amd import runtime
+    from test_oracle_modular import _axis_workload
+    monkeypatch.setenv("JXLGPU_PRED_WG", "1")
+    ctx = runtime.Context(0)
+    try:
+        wl = _axis_workload(dict(width=300, height=270, kind="squeeze", lossy=False, xyb=False, seed=48, leaves_preds=[6, 5, 13, 2]))
+        got = _inverse_both(ctx, oracle, wl)
+        for c in range(3):
+            assert np.array_equal(got[c], wl.expected[c])
+        # a unit entry that points past the axis table / carries an offset / an axis leaf that is itself a table: refused at upload
+        d = wl.desc()
+        d.num_axis_leaves = 1
+        with pytest.raises(runtime.JxlGpuError):
+            f = ctx.modular_upload(d)
+            try:
+                ctx.modular_inverse(f, wl.shapes(), wl.dtype)
+            finally:
+                f.free()
+        bad = list(wl.axis_leaves)
+        bad[0] = (abi.LEAF_BY_ROW, 1, 0)
+        wl.axis_leaves = bad
+        with pytest.raises(runtime.JxlGpuError):
+            ctx.modular_upload(wl.desc())
+    finally:
+        ctx.close()

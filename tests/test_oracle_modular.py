@@ -4,6 +4,7 @@ come back bit-for-bit."""
 import numpy as np
 import pytest
 
+from jxl_oxide_amd import abi
 from jxl_oxide_amd.synth_modular import ModularWorkload
 
 
@@ -291,3 +292,53 @@ def test_resqueezed_residuals_roundtrip(oracle, plan, residual):
     got = oracle.modular_inverse(wl.desc(), wl.shapes(), wl.dtype)
     for c in range(3):
         assert np.array_equal(got[c], wl.expected[c]), f"channel {c}"
+
+
+AXIS_TREE_CASES = [
+    dict(width=300, height=200, kind="predictor", seed=41),                                            # whole-channel units
+    dict(width=600, height=333, kind="predictor", seed=42, i16=False),                                 # 256 x 256 units, ragged edge units
+    dict(width=600, height=333, kind="squeeze", lossy=False, xyb=False, seed=43),                      # Squeeze sub-channels
+    dict(width=520, height=300, kind="squeeze", lossy=False, xyb=False, seed=44, leaves_preds=[6, 5, 13]),   # the self-correcting predictor among the leaves
+    dict(width=300, height=200, kind="palette", seed=45, i16=False),
+]
+
+
+def _axis_workload(case):
+    kw = dict(case)
+    preds = kw.pop("leaves_preds", None)
+    wl = ModularWorkload(leaves="axis", **kw)
+    if preds is not None:   # redraw with a restricted predictor set: rebuild through the same path
+        import jxl_oxide_amd.synth_modular as sm
+        orig = sm.residuals_in_place_leaves
+
+        def restricted(*a, **k):
+            k["predictors"] = preds
+            return orig(*a, **k)
+        sm.residuals_in_place_leaves = restricted
+        try:
+            wl = ModularWorkload(leaves="axis", **kw)
+        finally:
+            sm.residuals_in_place_leaves = orig
+    return wl
+
+
+@pytest.mark.parametrize("case", AXIS_TREE_CASES)
+def test_row_column_property_trees_roundtrip(oracle, case):
+    """Trees that still split on property 2 (y) or 3 (x) inside a decode unit (decode_slow, image.rs:1169-1228, with get_leaf a
+    function of the row / column alone): JxlGpuModularDesc::axis_leaves, one leaf per row or per column of the unit.  Residuals
+    from the independent numpy / C forward, sample by sample with that sample's leaf; the oracle must rebuild the image."""
+    wl = _axis_workload(case)
+    kinds = {p for p, _, _ in wl.unit_leaves}
+    assert abi.LEAF_BY_ROW in kinds and abi.LEAF_BY_COLUMN in kinds and wl.axis_leaves
+    d = wl.desc()
+    got = oracle.modular_inverse(d, wl.shapes(), wl.dtype)
+    for c in range(3):
+        assert np.array_equal(got[c], wl.expected[c]), f"channel {c}"
+    # an axis table that is too short, a non-zero offset on the unit entry, a leaf that is itself a table: refused
+    d.num_axis_leaves = len(wl.axis_leaves) - 1
+    with pytest.raises(Exception):
+        oracle.modular_inverse(d, wl.shapes(), wl.dtype)
+    # shifting the per-row / per-column leaves by one breaks the round trip
+    wl.axis_leaves = wl.axis_leaves[1:] + wl.axis_leaves[:1]
+    got = oracle.modular_inverse(wl.desc(), wl.shapes(), wl.dtype)
+    assert not all(np.array_equal(got[c], wl.expected[c]) for c in range(3))
