@@ -44,7 +44,10 @@ sys.path.insert(0, ROOT)
 
 W4K, H4K = 3840, 2160
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_GINSTR = 614.4    # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 f32 instruction (profiles/r01_pk_probe.txt)
+VALU_PEAK_GINSTR = 614.4    # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction: what a packed / DPP / SGPR-operand instruction costs
+VALU_PEAK_GINSTR_2CYC = 1228.8  # ... / 2 cycles: the micro-architecture guide's figure, and what plain v_fma / v_add / v_mul / v_and on
+                            # VGPR operands reach with >= 4 waves per SIMD (profiles/r06_valu_cost_probe.txt: the post kernel's mix of
+                            # 204 packed + 47 DPP + ~50 other 4-cycle and ~130 2-cycle instructions per row step costs ~3.5 cycles each)
 # static VALU count of one row step of the streaming post kernel and its strip width (tools/isa_blocks.sh):
 # packed kernel (two columns per lane, the default) / scalar kernel (JXLGPU_NO_PK)
 POST_VALU_PER_ROW, POST_STRIP = (354, 56) if os.environ.get("JXLGPU_NO_PK") else (428, 120)
@@ -295,6 +298,15 @@ def main():
                                 "the CUs (separate streams): avg_launch_ms is the duration under that sharing; roofline_isolated has the "
                                 "kernel alone") if (job["batched"] and not os.environ.get("JXLGPU_NO_BATCH_OVERLAP")) else None,
             }
+            # What the job HAS to move with the resident input it actually reads: with the list transport the
+            # 12 B/px of coefficient planes that SURVEY 8(d)'s 24.33 B/px counts are never read — the compulsory bytes are the
+            # lists (4 B per non-zero coefficient + 6 B of counts per varblock), the side data and the 12 B/px written.
+            if job.get("compulsory_bytes"):
+                cb = job["compulsory_bytes"](wls[next(iter(wls))], f0)
+                roofline["compulsory_bytes_per_frame"] = int(cb)
+                roofline["pipeline_compulsory_frac"] = round(cb * n_total * passes * args.steps / elapsed / 1e9 / world / HBM_PEAK_GBS, 4)
+                roofline["compulsory_note"] = ("list transport: non-zero lists + counts + side data read, f32 planes written; "
+                                               "pipeline_algorithmic_frac credits SURVEY 8(d)'s 12 B/px of coefficient planes that this path never reads")
             # The timed region runs V1-V8 of chunk k+1 beside the post launch of chunk k (two streams): the bracket above is
             # the kernel's duration WHILE IT SHARES THE CUs.  The same kernel alone (a second context without the overlap,
             # 32 frames per launch as in rounds 2-3), bracketed the same way, for comparison with earlier rounds:
@@ -332,6 +344,10 @@ def main():
                 ach = winstr / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
                 roofline_valu = {"bound": "valu", "achieved": round(ach, 1), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
                                  "frac": round(ach / VALU_PEAK_GINSTR, 4),
+                                 "peak_2_cycles": VALU_PEAK_GINSTR_2CYC, "frac_at_2_cycles": round(ach / VALU_PEAK_GINSTR_2CYC, 4),
+                                 "peaks": "`peak` = one wave64 instruction per 4 SIMD cycles (packed f32, DPP, SGPR / 3-operand integer forms: what "
+                                          "profiles/r06_valu_cost_probe.txt measures for them); `peak_2_cycles` = the guide's v_fma_f32 figure, reached "
+                                          "only by plain VGPR-operand f32 / logic instructions at >= 4 waves per SIMD; this kernel's mix averages ~3.5",
                                  "note": "streaming post kernel, f32 in the reference's operation order (no FMA contraction, "
                                          "correctly rounded division); a packed v_pk_*_f32 instruction counts once; halo rows "
                                          "and columns are recomputed (%d/%d x %d/%d)" % (
@@ -464,8 +480,8 @@ def make_job(config, distinct, transport="grouped", nz=0.15):
 
     def pmc_traffic(pattern_names):
         def fn(dominant, frames_per_launch):
-            src = next((os.path.join("profiles", n) for n in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json")
-                        if os.path.exists(os.path.join(ROOT, "profiles", n))), os.path.join("profiles", "r05_pmc_hbm_traffic.json"))
+            src = next((os.path.join("profiles", n) for n in ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json")
+                        if os.path.exists(os.path.join(ROOT, "profiles", n))), os.path.join("profiles", "r06_pmc_hbm_traffic.json"))
             try:
                 pmc = json.load(open(os.path.join(ROOT, src)))
                 kb = 0.0
@@ -510,6 +526,12 @@ def make_job(config, distinct, transport="grouped", nz=0.15):
                                     "correctly rounded divisions, fma-contracted sums / polynomials); a measured option, never the default")
             return res
 
+        def compulsory_bytes(wl, f):
+            nnz = sum(int(np.count_nonzero(wl.coeff[c])) for c in range(3))
+            nvb = int((wl.kind <= 26).sum())
+            side = f.algorithmic_bytes(stages) - f.algorithmic_bytes(stages & ~abi.STAGE_TRANSFORM)   # = the coefficient planes 8(d) counts
+            return f.algorithmic_bytes(stages) - side + nnz * 4 + nvb * 6
+
         def alg_bytes(f, group):
             npx, ncell = W4K * H4K, (W4K // 8) * (H4K // 8)
             if group == 1:
@@ -535,6 +557,7 @@ def make_job(config, distinct, transport="grouped", nz=0.15):
             "group_names": {1: "transform: transform_items_batch_kernel<0..3> + transform_special_batch_kernel (V4-V8)",
                             2: "post: post_pk_batch_kernel (+ post_ring_batch_kernel beside it): Gabor + EPF steps 1,2 + XYB->sRGB"},
             "alg_bytes": alg_bytes, "verify": verify,
+            "compulsory_bytes": compulsory_bytes if transport == "grouped" else None,
             "traffic": pmc_traffic({1: ("transform_",), 2: ("post_pk", "post_stream", "post_ring")}),
         }
     if config == 5:
@@ -668,14 +691,73 @@ def end_to_end(ctx, wl, mp_per_frame):
     same = bool(np.array_equal(outs[(n - 1) % depth], ref))
     for o in outs:
         ctx.host_free(o)
+    # Two calling threads, a context each (the reference's own caller pattern: keyframes rendered from a rayon par_iter,
+    # jxl-oxide-cli/src/decode.rs:293-304; one jxlgpu_ctx per rendering thread): the host build of one thread's frame k + 1
+    # overlaps the other thread's calls — the 0.45 ms work-list build is what a single caller serialises on.
+    pipe2, same2 = None, None
+    try:
+        import threading
+        from jxl_oxide_amd import runtime
+        ncall = 2
+        ctxs = [runtime.Context(ctx.device if hasattr(ctx, "device") else 0) for _ in range(ncall)]
+        descs = [d] * ncall   # read-only for the library: both callers upload from the same decoded state
+        outs2 = [[c.host_alloc((wl.height, wl.width, 3), np.uint8) for _ in range(depth)] for c in ctxs]
+        errs = []
+
+        def caller(i, frames_each, bar):
+            try:
+                c, dd = ctxs[i], descs[i]
+                bar.wait(timeout=60)
+                inflight = []
+                for k in range(frames_each):
+                    f = c.vardct_upload(dd)
+                    c.vardct_render(f, abi.STAGE_ALL, to_host=False)
+                    c.format_output_async(f, abi.FMT_U8, outs2[i][k % depth])
+                    inflight.append(f)
+                    if len(inflight) == depth:
+                        g = inflight.pop(0); c.frame_wait(g); g.free()
+                for g in inflight:
+                    c.frame_wait(g); g.free()
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+
+        for rep in range(3):   # the first repetition warms the second contexts' pools and staging buffers
+            bar = threading.Barrier(ncall + 1)
+            ths = [threading.Thread(target=caller, args=(i, n // ncall, bar)) for i in range(ncall)]
+            for t in ths:
+                t.start()
+            bar.wait(timeout=60)
+            t0 = time.perf_counter()
+            for t in ths:
+                t.join(timeout=300)
+            dt = (time.perf_counter() - t0) / (n // ncall * ncall)
+            if rep and not errs:
+                pipe2 = dt if pipe2 is None else min(pipe2, dt)
+        same2 = bool(not errs and all(np.array_equal(outs2[i][(n // ncall - 1) % depth], ref) for i in range(ncall)))
+        for i, c in enumerate(ctxs):
+            for o in outs2[i]:
+                c.host_free(o)
+            c.close()
+        if errs:
+            print(f"end_to_end: two-caller leg: {errs[:2]}", file=sys.stderr)
+            pipe2 = None
+    except Exception as e:  # noqa: BLE001 - a reporting extra never takes the line down
+        print(f"end_to_end: two-caller leg failed: {e!r}", file=sys.stderr)
+        pipe2 = None
     nzw = int(sum(int(d.hf_groups[g].num_nz) for g in range(d.num_hf_groups)))
-    return {"ms_per_frame": round(pipe * 1e3, 3), "MP_per_s": round(mp_per_frame / pipe, 1),
+    best_pipe, callers = (pipe2, 2) if (pipe2 is not None and same2 and pipe2 < pipe) else (pipe, 1)
+    return {"ms_per_frame": round(best_pipe * 1e3, 3), "MP_per_s": round(mp_per_frame / best_pipe, 1), "callers": callers,
+            "ms_per_frame_one_caller": round(pipe * 1e3, 3),
+            "ms_per_frame_two_callers": None if pipe2 is None else round(pipe2 * 1e3, 3),
+            "two_caller_output_identical_to_serial": same2,
             "serial_ms_per_frame": round(best * 1e3, 3), "serial_MP_per_s": round(mp_per_frame / best, 1), "serial_split": split,
             "pipelined_output_identical_to_serial": same,
             "what": "per frame: jxlgpu_vardct_upload (grouped non-zero lists; work-list build on the ctx's host threads, one pinned arena, "
                     "one async H2D) + jxlgpu_vardct_render + jxlgpu_frame_format_output (u8 interleaved).  ms_per_frame: three frames in "
-                    "flight, output into pinned memory (upload k+1 / render k / download k-1 overlap); serial_*: one frame at a time, "
-                    "output into pageable memory, best of 5",
+                    "flight, output into pinned memory (upload k+1 / render k / download k-1 overlap) — from ONE calling thread "
+                    "(ms_per_frame_one_caller) and from TWO calling threads with a context each, the reference CLI's pattern "
+                    "(ms_per_frame_two_callers); ms_per_frame is the better of the two, `callers` says which; serial_*: one frame "
+                    "at a time, output into pageable memory, best of 5",
             "list_MB_per_frame": None if nzw is None else round(nzw * 4 / 1e6, 2)}
 
 

@@ -549,7 +549,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     if (const char* v = getenv("JXLGPU_RING_MODE")) ctx->tune.ring_mode = std::min(2, std::max(0, atoi(v)));
     ctx->tune.int_post = getenv("JXLGPU_INT_POST") != nullptr && atoi(getenv("JXLGPU_INT_POST")) != 0;
     if (const char* v = getenv("JXLGPU_BATCH_TR_MULT")) ctx->tune.batch_tr_mult = std::min(4, std::max(1, atoi(v)));
-    ctx->tune.batch_lf_ahead = getenv("JXLGPU_BATCH_LF_AHEAD") != nullptr && atoi(getenv("JXLGPU_BATCH_LF_AHEAD")) != 0;
+    if (const char* v = getenv("JXLGPU_BATCH_LF_MODE")) ctx->tune.batch_lf_mode = std::min(2, std::max(0, atoi(v)));
     if (const char* v = getenv("JXLGPU_POST_LDS_PAD")) ctx->tune.post_lds_pad = std::min(150 * 1024, std::max(0, atoi(v)));
     if (const char* v = getenv("JXLGPU_BATCH_HEAVY")) ctx->tune.batch_heavy = (uint32_t)strtoul(v, nullptr, 0) & 31u;
     if (const char* v = getenv("JXLGPU_GUARD")) {
@@ -2098,14 +2098,13 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
         FrameBatch b;
         memset(&b, 0, sizeof(b));
         uint32_t max_w8 = 0, max_h8 = 0, max_wgs[4] = {}, max_special = 0;
-        bool any_smooth = false, no_event = false;
+        bool no_event = false;
         for (uint32_t i = 0; i < m; ++i) {
             jxlgpu_frame* f = frames[i0 + i];
             b.f[i] = f->dev_args;
             max_w8 = std::max(max_w8, f->w8); max_h8 = std::max(max_h8, f->h8);
             for (int fam = 0; fam < 4; ++fam) max_wgs[fam] = std::max(max_wgs[fam], f->batch_wgs[fam]);
             max_special = std::max(max_special, f->list_count[CLS_SPECIAL8]);
-            any_smooth |= !f->desc.skip_adaptive_lf_smoothing;
             if (overlap && f->ev_last && f->ev_last_set) HIP_TRY(ctx, hipStreamWaitEvent(st, f->ev_last, 0));
             else if (overlap) no_event = true;   // (event creation / record failed earlier: order behind the render stream instead)
         }
@@ -2119,29 +2118,39 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
             }
         }
         ctx->prof_begin(PROF_LF, st);
-        if (!(overlap && ctx->tune.batch_lf_ahead)) {
-            HIP_TRY(ctx, launch_lf_batch(st, b, m, max_w8, max_h8, any_smooth));
-        } else {
-            // experiment: V1-V3 one chunk AHEAD — this chunk's LF launches were queued in front of the previous chunk's
-            // transform launches (the first chunk's here), the next chunk's go in front of this chunk's
-            for (uint32_t k0 = (i0 == 0 ? 0u : i0 + tchunk); k0 < n && k0 <= i0 + tchunk; k0 += tchunk) {
-                const uint32_t mk = std::min<uint32_t>(tchunk, n - k0);
-                FrameBatch bl;
-                memset(&bl, 0, sizeof(bl));
-                uint32_t lw8 = 0, lh8 = 0;
-                bool sm = false;
-                for (uint32_t i = 0; i < mk; ++i) {
-                    jxlgpu_frame* f = frames[k0 + i];
-                    bl.f[i] = f->dev_args;
-                    lw8 = std::max(lw8, f->w8); lh8 = std::max(lh8, f->h8);
-                    sm |= !f->desc.skip_adaptive_lf_smoothing;
-                    if (k0 != i0 && f->ev_last && f->ev_last_set) HIP_TRY(ctx, hipStreamWaitEvent(st, f->ev_last, 0));
-                }
-                HIP_TRY(ctx, launch_lf_batch(st, bl, mk, lw8, lh8, sm));
+        // V1-V3 of chunk `k0` (its frames' LF planes are their own); `wait`: behind the frames' last operations
+        auto launch_lf_of = [&](uint32_t k0, bool wait) -> int {
+            const uint32_t mk = std::min<uint32_t>(tchunk, n - k0);
+            FrameBatch bl;
+            memset(&bl, 0, sizeof(bl));
+            uint32_t lw8 = 0, lh8 = 0;
+            bool sm = false;
+            for (uint32_t i = 0; i < mk; ++i) {
+                jxlgpu_frame* f = frames[k0 + i];
+                bl.f[i] = f->dev_args;
+                lw8 = std::max(lw8, f->w8); lh8 = std::max(lh8, f->h8);
+                sm |= !f->desc.skip_adaptive_lf_smoothing;
+                if (wait && f->ev_last && f->ev_last_set) HIP_TRY(ctx, hipStreamWaitEvent(st, f->ev_last, 0));
             }
-        }
+            HIP_TRY(ctx, launch_lf_batch(st, bl, mk, lw8, lh8, sm));
+            return JXLGPU_OK;
+        };
+        // Where the LF launches of a chunk sit (JXLGPU_BATCH_LF_MODE, an experiment of round 6): 0 = in front of the chunk's own
+        // transform launches (the default); 1 = in front of the PREVIOUS chunk's; 2 = BEHIND the previous chunk's 8- / 16-px launches
+        // on the transform stream.  The kernel trace (profiles/r06_kernel_timeline.txt) shows the transform chain of chunk k + 1
+        // starting together with the post + border-ring launches of chunk k and its first two (tiny) launches sitting 0.35-0.5 ms
+        // behind the ring launch, on the chain that sets the period (1.7 ms against 1.13 ms of post).  Moving them does not help:
+        // the launches that follow then wait instead (104.3 / 106.0 / 109-114 us per frame for modes 0 / 1 / 2) — whichever group
+        // gets the registers first, the other one loses what it gains.
+        int lf_mode = overlap ? ctx->tune.batch_lf_mode : 0;
+        for (uint32_t i = 0; i < n && lf_mode; ++i)   // a frame without a usable "last operation" event is ordered by the no_event path above, chunk by chunk
+            if (!(frames[i]->ev_last && frames[i]->ev_last_set)) lf_mode = 0;
+        if (lf_mode == 0) TRY(launch_lf_of(i0, false));
+        else if (i0 == 0) TRY(launch_lf_of(0, false));
+        if (lf_mode == 1 && i0 + tchunk < n) TRY(launch_lf_of(i0 + tchunk, true));
         ctx->prof_end(PROF_LF, st);
         ctx->prof_begin(PROF_TRANSFORM, st);
+        bool lf_done_ahead = false;
         const uint32_t heavy = overlap ? ctx->tune.batch_heavy : 0u;
         if (heavy) {
             // the families of `heavy` on the render stream, behind post(k-1) and in front of post(k) (they need the LF
@@ -2181,6 +2190,7 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
             HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
             HIP_TRY(ctx, sparse_tr ? launch_transform_batch_sparse(st, side, b, m, max_wgs, max_special)
                                    : launch_transform_batch(st, side, b, m, max_wgs, max_special));
+            if (lf_mode == 2 && i0 + tchunk < n) { TRY(launch_lf_of(i0 + tchunk, true)); lf_done_ahead = true; }
             HIP_TRY(ctx, hipEventRecord(ctx->ev_join, side));
             HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
             }
@@ -2188,6 +2198,7 @@ int jxlgpu_vardct_render_batch(jxlgpu_ctx* ctx, jxlgpu_frame* const* frames, uin
             HIP_TRY(ctx, sparse_tr ? launch_transform_batch_sparse(st, nullptr, b, m, max_wgs, max_special)
                                    : launch_transform_batch(st, nullptr, b, m, max_wgs, max_special));
         }
+        if (lf_mode == 2 && !lf_done_ahead && i0 + tchunk < n) TRY(launch_lf_of(i0 + tchunk, true));   // (the other launch orders: behind the chunk's transforms)
         ctx->prof_end(PROF_TRANSFORM, st);
         if (overlap) {
             hipEvent_t& ev = ctx->ev_tr[ctx->ev_tr_next++ % 8];

@@ -227,9 +227,10 @@ struct Tuning {
     int batch_chunk = 0;         // JXLGPU_BATCH_CHUNK: > 0: frames per launch of a batch (default: JXLGPU_MAX_BATCH)
     bool int_post = false;       // JXLGPU_INT_POST=1: the post stage of Modular XYB frames reads the integer planes (no float copy by to_float_kernel);
                                  // measured on config 3: 14.7 vs 15.2-15.4 GP/s (the VALU-bound post kernel pays more for the conversion than the copy costs): off
-    bool batch_lf_ahead = false; // JXLGPU_BATCH_LF_AHEAD=1 (experiment, round 6): the LF launches (V1-V3) of EVERY chunk of a batched render in front of
-                                 // the first transform launch, instead of each chunk's in front of its own (the LF smoothing launch of chunk k+1 was
-                                 // seen waiting 0.35 ms behind the border-ring launch of chunk k for registers)
+    int batch_lf_mode = 0;       // JXLGPU_BATCH_LF_MODE (experiment, round 6): where the LF launches (V1-V3) of a chunk of a batched render sit: 0 = in front of
+                                 // its own transform launches (the default), 1 = in front of the previous chunk's, 2 = behind the previous chunk's
+                                 // 8- / 16-px launches.  Measured (64 frames, one box): 104.3-104.4 / 106.0 / 109.3-113.9 us per frame — moving the
+                                 // two tiny launches out from behind the border-ring launch only moves the wait to the launches that follow
     int post_lds_pad = 0;        // JXLGPU_POST_LDS_PAD=bytes (experiment, round 6): dynamic LDS reserved per workgroup of the batched packed post
                                  // launch — 81920 leaves ONE workgroup = one post wave per SIMD on a CU: what a one-pass kernel that keeps a
                                  // 64-row window of the transform output in LDS would have to live with

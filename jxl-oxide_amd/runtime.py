@@ -92,6 +92,7 @@ class Frame:
 class Context:
     def __init__(self, device=0):
         self.lib = abi.load_library()
+        self.device = device
         if self.lib.jxlgpu_abi_version() != abi.ABI_VERSION:
             raise RuntimeError("libjxlgpu.so ABI version does not match abi.py")
         h = C.c_void_p()

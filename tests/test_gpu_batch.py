@@ -35,10 +35,13 @@ def test_batch_matches_single_and_oracle(gpu_ctx, oracle):
             f.free()
 
 
-def test_batch_larger_than_one_launch(gpu_ctx):
+def test_batch_larger_than_one_launch(gpu_ctx, oracle):
     """More frames than one launch takes (JXLGPU_MAX_BATCH = 32): chunks."""
     wl = VardctWorkload(264, 200, seed=5)
     ref = _single(gpu_ctx, wl)
+    # the device-vs-device comparisons below stand on this one: the single-frame render equals the oracle
+    exp, _ = oracle.vardct_render(wl.desc(), abi.STAGE_ALL, wl.width, wl.height)
+    assert np.array_equal(ref.view(np.uint32), exp.view(np.uint32))
     frames = [gpu_ctx.vardct_upload(wl.desc()) for _ in range(35)]
     try:
         gpu_ctx.vardct_render_batch(frames, abi.STAGE_ALL)
@@ -50,11 +53,14 @@ def test_batch_larger_than_one_launch(gpu_ctx):
             f.free()
 
 
-def test_batch_with_frames_outside_the_default_pipeline(gpu_ctx):
+def test_batch_with_frames_outside_the_default_pipeline(gpu_ctx, oracle):
     """EPF iters 3 / no Gabor / a PQ target do not qualify: the call renders frame by frame."""
     wls = [VardctWorkload(264, 200, seed=6), VardctWorkload(264, 200, seed=7, epf_iters=3),
            VardctWorkload(200, 136, seed=8, gabor=False), VardctWorkload(200, 136, seed=9, intensity_target=4000.0, hdr_pq=True)]
     refs = [_single(gpu_ctx, w) for w in wls]
+    for w, r in zip(wls, refs):   # oracle-backed: the references of the comparisons below
+        exp, _ = oracle.vardct_render(w.desc(), abi.STAGE_ALL, w.width, w.height)
+        assert np.array_equal(r.view(np.uint32), exp.view(np.uint32)), (w.width, w.height)
     frames = [gpu_ctx.vardct_upload(w.desc()) for w in wls]
     try:
         gpu_ctx.vardct_render_batch(frames, abi.STAGE_ALL)

@@ -3,11 +3,15 @@
 //   hipcc -O2 --offload-arch=gfx950 tools/valu_cost_probe.hip -o /tmp/valu_cost_probe && /tmp/valu_cost_probe
 //
 // Every kernel is a loop of 64 instructions of ONE form on 8 independent accumulators (a dependent pair is 8
-// instructions apart), W waves per SIMD on every SIMD of the chip.  Printed: SIMD cycles per wave-instruction at the
-// clock the run reached (measured with a pure v_fma_f32 run beside it, which issues one wave64 instruction per 4
-// cycles), for W = 1, 2, 4, 8.  What it answers: which forms cost more than the 4 cycles bench.py's roofline_valu
-// assumes for every instruction — quarter-rate transcendentals, the wave-wide DPP shifts, instructions that write
-// or read SGPRs — i.e. where the post kernel's measured ~5.3 cycles per instruction come from.
+// instructions apart), W waves per SIMD on every SIMD of the chip.  Printed: SIMD cycles per wave-instruction RELATIVE to
+// a pure v_fma_f32 run in the same column (= 4.00), for W = 1, 2, 4, 8, and the absolute v_fma_f32 rate at the end.
+// What it found (profiles/r06_valu_cost_probe.txt): plain f32 / logic instructions on VGPR (or literal) operands —
+// v_fma / v_add / v_mul / v_and — issue at ~2.4 cycles with >= 4 waves per SIMD (the guide's "2 cycles"); packed f32,
+// every DPP form, an SGPR operand, v_cndmask, v_cmp, v_bfi, 3-operand integer forms and conversions cost ~4.1 cycles
+// (1.75 x); v_rcp / v_sqrt ~8; ONE wave per SIMD issues at most one instruction per ~5 cycles whatever the form.  So
+// a packed instruction buys nothing over two plain ones in issue cycles (it halves the instruction COUNT, which is what
+// a kernel of two waves per SIMD needs), and the 4-cycle peak bench.py's roofline_valu uses is the packed / DPP cost,
+// not a universal one.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -30,7 +34,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
                 asm volatile(ASM(a0) ASM(a1) ASM(a2) ASM(a3) ASM(a4) ASM(a5) ASM(a6) ASM(a7)        \
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
                              : "v"(b), "v"(c), "s"(s)                                               \
-                             : "vcc", "s20", "s21", "s22", "s23");                                  \
+                             : "vcc", "s20", "s21", "s22", "s23", "v200", "v201");                                  \
             }                                                                                       \
         }                                                                                           \
         out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                 \
@@ -75,6 +79,37 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define I_FMA_NOP(x) "v_fma_f32 " A_(x) ", " A_(x) ", %8, %9\ns_nop 1\n"
 #define I_ADD_DPP_AFTER(x) "v_add_f32_dpp " A_(x) ", " A_(x) ", " A_(x) " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
 
+#define I_ADD_U32(x) "v_add_u32 " A_(x) ", " A_(x) ", %8\n"
+#define I_SUB_U32(x) "v_sub_u32 " A_(x) ", " A_(x) ", %8\n"
+#define I_ADD3_U32(x) "v_add3_u32 " A_(x) ", " A_(x) ", %8, %9\n"
+#define I_LSHL(x) "v_lshlrev_b32 " A_(x) ", 3, " A_(x) "\n"
+#define I_LSHR(x) "v_lshrrev_b32 " A_(x) ", 3, " A_(x) "\n"
+#define I_ASHR(x) "v_ashrrev_i32 " A_(x) ", 3, " A_(x) "\n"
+#define I_LSHL_V(x) "v_lshlrev_b32 " A_(x) ", %8, " A_(x) "\n"
+#define I_OR(x) "v_or_b32 " A_(x) ", " A_(x) ", %8\n"
+#define I_XOR(x) "v_xor_b32 " A_(x) ", " A_(x) ", %8\n"
+#define I_MIN_I32(x) "v_min_i32 " A_(x) ", " A_(x) ", %8\n"
+#define I_MAX_U32(x) "v_max_u32 " A_(x) ", " A_(x) ", %8\n"
+#define I_MED3_I32(x) "v_med3_i32 " A_(x) ", " A_(x) ", %8, %9\n"
+#define I_MUL_U24(x) "v_mul_u32_u24 " A_(x) ", " A_(x) ", %8\n"
+#define I_MUL_I24(x) "v_mul_i32_i24 " A_(x) ", " A_(x) ", %8\n"
+#define I_MAD_I24(x) "v_mad_i32_i24 " A_(x) ", " A_(x) ", %8, %9\n"
+#define I_MUL_HI(x) "v_mul_hi_u32 " A_(x) ", " A_(x) ", %8\n"
+#define I_MOV(x) "v_mov_b32 " A_(x) ", %8\n"
+#define I_FFBH(x) "v_ffbh_u32 " A_(x) ", " A_(x) "\n"
+#define I_SUB_F32(x) "v_sub_f32 " A_(x) ", " A_(x) ", %8\n"
+#define I_MAX_F32(x) "v_max_f32 " A_(x) ", " A_(x) ", %8\n"
+#define I_MIN_F32(x) "v_min_f32 " A_(x) ", " A_(x) ", %8\n"
+#define I_MAX_F32_ABS(x) "v_max_f32 " A_(x) ", |" A_(x) "|, |%8|\n"
+#define I_FMAC(x) "v_fmac_f32 " A_(x) ", %8, %9\n"
+#define I_FMA_LIT(x) "v_fma_f32 " A_(x) ", " A_(x) ", %8, 0.5\n"
+#define I_MUL_LIT(x) "v_mul_f32 " A_(x) ", 0x3f9d70a4, " A_(x) "\n"
+#define I_RSQ(x) "v_rsq_f32 " A_(x) ", " A_(x) "\n"
+#define I_CVT_I32_F32(x) "v_cvt_i32_f32 " A_(x) ", " A_(x) "\n"
+#define I_BFE(x) "v_bfe_u32 " A_(x) ", " A_(x) ", 4, 8\n"
+#define I_AND_OR(x) "v_and_or_b32 " A_(x) ", " A_(x) ", %8, %9\n"
+#define I_MAD_U64(x) "v_mad_u64_u32 v[200:201], s[22:23], " A_(x) ", %8, v[200:201]\n"
+#define I_ADDC(x) "v_add_co_u32 " A_(x) ", vcc, " A_(x) ", %8\nv_addc_co_u32 " A_(x) ", vcc, " A_(x) ", %9, vcc\n"
 KERNEL_S(k_fma, I_FMA)
 KERNEL_S(k_add, I_ADD)
 KERNEL_S(k_mul, I_MUL)
@@ -103,6 +138,36 @@ KERNEL_S(k_div_scale, I_DIV_SCALE)
 KERNEL_S(k_div_fixup, I_DIV_FIXUP)
 KERNEL_S(k_fma_nop1, I_FMA_NOP)
 KERNEL_S(k_add_dpp_self, I_ADD_DPP_AFTER)
+KERNEL_S(k_add_u32, I_ADD_U32)
+KERNEL_S(k_sub_u32, I_SUB_U32)
+KERNEL_S(k_add3_u32, I_ADD3_U32)
+KERNEL_S(k_lshl, I_LSHL)
+KERNEL_S(k_lshr, I_LSHR)
+KERNEL_S(k_ashr, I_ASHR)
+KERNEL_S(k_lshl_v, I_LSHL_V)
+KERNEL_S(k_or, I_OR)
+KERNEL_S(k_xor, I_XOR)
+KERNEL_S(k_min_i32, I_MIN_I32)
+KERNEL_S(k_max_u32, I_MAX_U32)
+KERNEL_S(k_med3_i32, I_MED3_I32)
+KERNEL_S(k_mul_u24, I_MUL_U24)
+KERNEL_S(k_mul_i24, I_MUL_I24)
+KERNEL_S(k_mad_i24, I_MAD_I24)
+KERNEL_S(k_mul_hi, I_MUL_HI)
+KERNEL_S(k_mov, I_MOV)
+KERNEL_S(k_ffbh, I_FFBH)
+KERNEL_S(k_sub_f32, I_SUB_F32)
+KERNEL_S(k_max_f32, I_MAX_F32)
+KERNEL_S(k_min_f32, I_MIN_F32)
+KERNEL_S(k_max_f32_abs, I_MAX_F32_ABS)
+KERNEL_S(k_fmac, I_FMAC)
+KERNEL_S(k_fma_lit, I_FMA_LIT)
+KERNEL_S(k_mul_lit, I_MUL_LIT)
+KERNEL_S(k_rsq, I_RSQ)
+KERNEL_S(k_cvt_i32_f32, I_CVT_I32_F32)
+KERNEL_S(k_bfe, I_BFE)
+KERNEL_S(k_and_or, I_AND_OR)
+KERNEL_S(k_addc, I_ADDC)
 
 // packed forms: accumulators are VGPR pairs, b / c VGPR pairs, s an SGPR pair
 #define KERNEL_P(NAME, ASM)                                                                        \
@@ -219,6 +284,14 @@ int main() {
         {"v_cmp_lt_f32 -> vcc", k_cmp_vcc, 1}, {"v_cmp_lt_f32_e64 -> sgpr pair", k_cmp_sgpr, 1}, {"v_cmp + v_cndmask (per pair)", k_cmp_cnd, 2},
         {"v_readfirstlane_b32", k_readfirst, 1}, {"v_cvt_f32_i32", k_cvt, 1}, {"v_lshl_add_u32", k_lshl_add, 1},
         {"v_mad_u32_u24", k_mad_u24, 1}, {"v_mul_lo_u32", k_mul_lo, 1}, {"v_div_scale_f32", k_div_scale, 1}, {"v_div_fixup_f32", k_div_fixup, 1},
+        {"v_sub_f32", k_sub_f32, 1}, {"v_max_f32", k_max_f32, 1}, {"v_min_f32", k_min_f32, 1}, {"v_max_f32 |a|,|b| (e64)", k_max_f32_abs, 1},
+        {"v_fmac_f32", k_fmac, 1}, {"v_fma_f32 (inline const 0.5)", k_fma_lit, 1}, {"v_mul_f32 (32-bit literal)", k_mul_lit, 1},
+        {"v_rsq_f32", k_rsq, 1}, {"v_cvt_i32_f32", k_cvt_i32_f32, 1}, {"v_mov_b32", k_mov, 1},
+        {"v_add_u32", k_add_u32, 1}, {"v_sub_u32", k_sub_u32, 1}, {"v_add3_u32", k_add3_u32, 1}, {"v_add_co_u32 + v_addc_co_u32 (per pair)", k_addc, 2},
+        {"v_lshlrev_b32 (imm)", k_lshl, 1}, {"v_lshrrev_b32 (imm)", k_lshr, 1}, {"v_ashrrev_i32 (imm)", k_ashr, 1}, {"v_lshlrev_b32 (vgpr)", k_lshl_v, 1},
+        {"v_or_b32", k_or, 1}, {"v_xor_b32", k_xor, 1}, {"v_and_or_b32", k_and_or, 1}, {"v_bfe_u32", k_bfe, 1},
+        {"v_min_i32", k_min_i32, 1}, {"v_max_u32", k_max_u32, 1}, {"v_med3_i32", k_med3_i32, 1}, {"v_ffbh_u32", k_ffbh, 1},
+        {"v_mul_u32_u24", k_mul_u24, 1}, {"v_mul_i32_i24", k_mul_i24, 1}, {"v_mad_i32_i24", k_mad_i24, 1}, {"v_mul_hi_u32", k_mul_hi, 1},
         {"v_fma_f32 + s_nop 1 (per pair)", k_fma_nop1, 1},
         {"ds_read_b32 (8 in flight)", k_ds_read_b32, 1}, {"ds_read_b64 (8 in flight)", k_ds_read_b64, 1},
     };
@@ -236,7 +309,7 @@ int main() {
             printf(" %8.2f", 4.0 * per / base[col]);
             ++col;
         }
-        printf("   [%.3f ns per slot at 8 w/SIMD]\n", 0.0);
+        printf("\n");
     }
     // absolute: v_fma_f32 wave-instructions per ns per SIMD
     for (int i = 0, wps = 1; i < 4; ++i, wps *= 2)
