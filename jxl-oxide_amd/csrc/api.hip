@@ -492,16 +492,17 @@ extern "C" {
 
 uint32_t jxlgpu_abi_version(void) { return JXLGPU_ABI_VERSION; }
 
-// The transform stream of batched renders: lowest priority when JXLGPU_STREAM_PRIO is set (the post launches on the
-// render stream then get the wave slots first, the latency-bound transform launches fill what is left).
-static hipError_t create_tr_stream(jxlgpu_ctx* ctx) {
+// The transform streams of batched renders: JXLGPU_STREAM_PRIO > 0: lowest priority (the post launches on the render stream get
+// the wave slots first, the latency-bound transform launches fill what is left); < 0: highest (round 6: the transform chain is
+// the one that sets the period of a chunk — profiles/r06_kernel_timeline.txt).
+static hipError_t create_tr_stream(jxlgpu_ctx* ctx, hipStream_t* out) {
     const char* v = getenv("JXLGPU_STREAM_PRIO");
     if (v && atoi(v) != 0) {
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
-            return hipStreamCreateWithPriority(&ctx->stream_tr, hipStreamNonBlocking, atoi(v) > 0 ? lo : hi);
+            return hipStreamCreateWithPriority(out, hipStreamNonBlocking, atoi(v) > 0 ? lo : hi);
     }
-    return hipStreamCreateWithFlags(&ctx->stream_tr, hipStreamNonBlocking);
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
 }
 
 int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
@@ -579,8 +580,8 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
-        create_tr_stream(ctx) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream_tr2, hipStreamNonBlocking) != hipSuccess ||
+        create_tr_stream(ctx, &ctx->stream_tr) != hipSuccess ||
+        create_tr_stream(ctx, &ctx->stream_tr2) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_down, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||

@@ -1460,8 +1460,12 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
                                                                   uint32_t* wave_flags) {
     extern __shared__ int32_t s_err[];
     __shared__ uint32_t s_div[65];
-    __shared__ int32_t s_out[64][RO + 1];
-    __shared__ int32_t s_in[64][kRing + 1];
+    // the sample / residual rings hold values of the sample type: 16-bit rings for 16-bit buffers (BASELINE config 3) — the LDS
+    // footprint is what bounds the waves per CU of this kernel (14 -> 9.6 KB per wave with the 5 x 256-word error rows: 11 -> 16
+    // waves per CU), and a wave is one serial chain per subgrid
+    using R = typename std::conditional<sizeof(S) == 2, int16_t, int32_t>::type;
+    __shared__ R s_out[64][RO + 1];
+    __shared__ R s_in[64][kRing + 1];
     const PredWave wv = waves[blockIdx.x];
     const uint32_t lane = threadIdx.x;
     const uint32_t log2p = wv.log2p, log2dp = wv.log2dp, P = 1u << log2p, DPm1 = (1u << log2dp) - 1u;
@@ -1485,8 +1489,8 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
     int32_t q1 = (int32_t)k - 1, q2 = (int32_t)k - 2;
     while (q1 < 0) { q1 += (int32_t)P; ++wrap1; }
     while (q2 < 0) { q2 += (int32_t)P; ++wrap2; }
-    const int32_t* prev = s_out[lane0 + (uint32_t)q1];
-    const int32_t* prev2 = s_out[lane0 + (uint32_t)q2];
+    const R* prev = s_out[lane0 + (uint32_t)q1];
+    const R* prev2 = s_out[lane0 + (uint32_t)q2];
     const int32_t wp0 = a.wp[0], wp1 = a.wp[1], wp2 = a.wp[2], wp3 = a.wp[3], wp4 = a.wp[4], wp5 = a.wp[5], wp6 = a.wp[6];
     const uint32_t ww[4] = {(uint32_t)a.wp[7], (uint32_t)a.wp[8], (uint32_t)a.wp[9], (uint32_t)a.wp[10]};
 
@@ -1519,7 +1523,7 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
                     // park the four residuals requested 8 steps ago (positions u + 8 .. u + 11: one row, contiguous ring
                     // slots), request positions u + 16 .. u + 19; always issued (see the one-sample form below)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) s_in[lane][(u + 8 + i) & (kRing - 1)] = (int32_t)pfv[j >> 2].s[i];
+                    for (int i = 0; i < 4; ++i) s_in[lane][(u + 8 + i) & (kRing - 1)] = (R)pfv[j >> 2].s[i];
                     uint32_t rq, xq;
                     const bool ahead = where(u + 16, &rq, &xq);
                     pfv[j >> 2].v = *reinterpret_cast<GlobalPtr<const V4>>(src + (ahead ? (size_t)rq * t.stride + xq : (size_t)0));
@@ -1529,7 +1533,7 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
                 // slot nobody reads and stores to `sink`): with a load or store under a branch the compiler cannot count
                 // the accesses in flight and waits for ALL of them (s_waitcnt vmcnt(0)) before it parks a residual
                 uint32_t rq, xq;
-                s_in[lane][(u + 8) & (kRing - 1)] = pf[j];
+                s_in[lane][(u + 8) & (kRing - 1)] = (R)pf[j];
                 const bool ahead = where(u + 16, &rq, &xq);
                 pf[j] = (int32_t)src[ahead ? (size_t)rq * t.stride + xq : (size_t)0];
             }
@@ -1603,7 +1607,7 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
                 st_value = value;
                 st_ptr = as_global((S*)t.base + (size_t)r * t.stride + ux);
                 const int32_t sample = (int32_t)value;
-                s_out[lane][u & (RO - 1)] = sample;
+                s_out[lane][u & (RO - 1)] = (R)sample;
 
                 const int32_t s8 = sample * 8;
                 const int32_t true_err = prediction - s8;

@@ -15,6 +15,7 @@
 // no contraction), clamp to [min, max] of the 25 samples.
 #include "common.h"
 #include "pixel_device.h"
+#include "fast_math_device.h"
 
 namespace {
 
@@ -205,11 +206,28 @@ __device__ __forceinline__ void matmul3_pair(const cf2* m, cf2 (&v)[3]) {
 __device__ __forceinline__ void map_gamut_pair(const cf2* k, cf2 (&rgb)[3]) {
     const cf2 y = rgb[0] * k[HC_LUM] + rgb[1] * k[HC_LUM + 1] + rgb[2] * k[HC_LUM + 2];
     cf2 gray_saturation = {0.0f, 0.0f}, gray_luminance = {0.0f, 0.0f};
+    // 1 / (v - y) for the three channels: the residual-chain reciprocal of fast_math_device.h when every denominator of the wave
+    // lies in 2^-60 <= |d| <= 2^60 (an exact zero is replaced by 1, as in the reference), the ordinary divisions otherwise
+    cf2 dsub[3];
+    bool rcp_ok = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const cf2 t = rgb[i] - y;
+        dsub[i] = cf2{t.x == 0.0f ? 1.0f : t.x, t.y == 0.0f ? 1.0f : t.y};
+        rcp_ok = rcp_ok && fm_in_range_bits(fabsf(dsub[i].x), kFmBits2m60, kFmBits2p60) && fm_in_range_bits(fabsf(dsub[i].y), kFmBits2m60, kFmBits2p60);
+    }
+    const bool rcp_fast = __builtin_amdgcn_ballot_w64(!rcp_ok) == 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const cf2 v = rgb[i];
         const cf2 v_sub_y = v - y;
-        const cf2 inv = {1.0f / (v_sub_y.x == 0.0f ? 1.0f : v_sub_y.x), 1.0f / (v_sub_y.y == 0.0f ? 1.0f : v_sub_y.y)};
+        cf2 inv;
+        if (rcp_fast) {
+            inv = rcp_cr_pair(dsub[i]);
+        } else {
+            asm volatile("; ordinary reciprocals" ::: "memory");
+            inv = cf2{1.0f / dsub[i].x, 1.0f / dsub[i].y};
+        }
         const cf2 v_over = v * inv;
         const cf2 new_sat = sel2(v_sub_y.x >= 0.0f, v_sub_y.y >= 0.0f, gray_saturation,
                                  cf2{fmaxf(gray_saturation.x, v_over.x), fmaxf(gray_saturation.y, v_over.y)});
@@ -226,8 +244,26 @@ __device__ __forceinline__ void map_gamut_pair(const cf2* k, cf2 (&rgb)[3]) {
     cf2 max_color_val = {1.0f, 1.0f};
 #pragma unroll
     for (int i = 0; i < 3; ++i) max_color_val = cf2{fmaxf(rgb[i].x, max_color_val.x), fmaxf(rgb[i].y, max_color_val.y)};
+    // three quotients by one denominator >= 1 (gamut.rs:40-45).  Shared refined reciprocal + fma chains where that is provably the
+    // correctly rounded quotient (fast_math_device.h: 1 <= d <= 2^20, 2^-100 <= |n| <= 2^20 or n = +-0), tested wave by wave;
+    // the ordinary divisions otherwise (a tiny non-zero numerator, huge values, NaN)
+    {
+        bool ok = fm_in_range_bits(max_color_val.x, kFmBits1, kFmBits2p20) && fm_in_range_bits(max_color_val.y, kFmBits1, kFmBits2p20);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) rgb[i] = cf2{mixed[i].x / max_color_val.x, mixed[i].y / max_color_val.y};
+        for (int i = 0; i < 3; ++i) {
+            const float ax = fabsf(mixed[i].x), ay = fabsf(mixed[i].y);
+            ok = ok && (ax == 0.0f || fm_in_range_bits(ax, kFmBits2m100, kFmBits2p20)) && (ay == 0.0f || fm_in_range_bits(ay, kFmBits2m100, kFmBits2p20));
+        }
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+            const cf2 r = rcp_refined_pair(max_color_val);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rgb[i] = div_cr_pair_with(mixed[i], max_color_val, r);
+        } else {
+            asm volatile("; ordinary divisions" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rgb[i] = cf2{mixed[i].x / max_color_val.x, mixed[i].y / max_color_val.y};
+        }
+    }
 }
 
 // rational_poly5_dev's numerator / denominator on pairs (fastmath/rational_poly.rs:2-6)
@@ -239,10 +275,24 @@ __device__ __forceinline__ cf2 horner5_pair(cf2 x, const cf2* p) {
 }
 
 // linear_to_pq_dev on a pair (tf/pq.rs:127-142)
-__device__ __forceinline__ cf2 linear_to_pq_pair(cf2 s, const cf2* k) {
+// `y_mult_le_1` (uniform): intensity_target <= 10000, the range of PQ itself.  Then, for 2^-60 <= a_scaled <= 2^12 (tested wave by
+// wave), the fourth root is two correctly rounded square roots by the residual chain of fast_math_device.h (checked on the
+// device against sqrtf(sqrtf(x)) for EVERY float of that range), x = a_scaled^(1/4) lies in [2^-15, 8], and the selected
+// polynomials are inside the quotient chain's proven range: P(x) in [0.008, 2.8e5], Q(x) in [1.01, 1.7e5] on [0, 8]; the dark
+// pair is only selected for a < 1e-4, i.e. x <= 0.1, where PS(x) in (0, 42] and QS(x) in [33, 280].  Everything else — zeros
+// (a black image), denormals, huge or non-finite samples, larger intensity targets — keeps sqrtf and the ordinary division.
+__device__ __forceinline__ cf2 linear_to_pq_pair(cf2 s, const cf2* k, bool y_mult_le_1) {
     const cf2 a = {fabsf(s.x), fabsf(s.y)};
     const cf2 a_scaled = a * k[HC_YMULT];
-    const cf2 a_1_4 = {sqrtf(sqrtf(a_scaled.x)), sqrtf(sqrtf(a_scaled.y))};
+    const bool in_range = fm_in_range_bits(a_scaled.x, kFmBits2m60, kFmBits2p12) && fm_in_range_bits(a_scaled.y, kFmBits2m60, kFmBits2p12);
+    const bool fast = y_mult_le_1 && __builtin_amdgcn_ballot_w64(!in_range) == 0;
+    cf2 a_1_4;
+    if (fast) {
+        a_1_4 = sqrt_cr_pair(sqrt_cr_pair(a_scaled));
+    } else {
+        asm volatile("; ordinary square roots" ::: "memory");
+        a_1_4 = cf2{sqrtf(sqrtf(a_scaled.x)), sqrtf(sqrtf(a_scaled.y))};
+    }
     const bool sx = a.x < 1e-4f, sy = a.y < 1e-4f;
     cf2 yp = horner5_pair(a_1_4, k + HC_P), yq = horner5_pair(a_1_4, k + HC_Q);
     if (__builtin_amdgcn_ballot_w64(sx || sy) != 0) {   // dark samples: the other pair of polynomials (wave-uniform test)
@@ -250,7 +300,14 @@ __device__ __forceinline__ cf2 linear_to_pq_pair(cf2 s, const cf2* k) {
         yp = sel2(sx, sy, yps, yp);
         yq = sel2(sx, sy, yqs, yq);
     }
-    return cf2{copysignf(yp.x / yq.x, s.x), copysignf(yp.y / yq.y, s.y)};
+    cf2 q;
+    if (fast) {
+        q = div_cr_pair(yp, yq);
+    } else {
+        asm volatile("; ordinary division" ::: "memory");
+        q = cf2{yp.x / yq.x, yp.y / yq.y};
+    }
+    return cf2{copysignf(q.x, s.x), copysignf(q.y, s.y)};
 }
 
 __device__ __forceinline__ void color_pair_hdr(const cf2* k, cf2 (&v)[3]) {
@@ -268,10 +325,12 @@ __device__ __forceinline__ void color_pair_hdr(const cf2* k, cf2 (&v)[3]) {
     map_gamut_pair(k, v);
     asm volatile("" ::: "memory");
     matmul3_pair(k + HC_M2, v);
+    const bool y_mult_le_1 = __builtin_amdgcn_readfirstlane(__float_as_int(k[HC_YMULT].x)) <= __float_as_int(1.0f) &&
+                             __builtin_amdgcn_readfirstlane(__float_as_int(k[HC_YMULT].x)) >= 0;   // 0 <= y_mult <= 1 (bit patterns of non-negative floats order like the values)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         asm volatile("" ::: "memory");
-        v[c] = linear_to_pq_pair(v[c], k);
+        v[c] = linear_to_pq_pair(v[c], k, y_mult_le_1);
     }
 }
 
@@ -348,17 +407,18 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void upsample2_lds_kernel(UpSt
                 for (int ix = 0; ix < 5; ++ix) V[iy][ix] = row[ix];
                 sl = sl == 0 ? 4 : sl - 1;
             }
+            // minimum / maximum of the 25 window samples (upsampling.rs:100-113; exact operations: the order is free), three
+            // operands per instruction: 12 + 12 instead of 24 + 24 + a canonicalising v_max per sample read from LDS
             float mn, mx;
             {
                 float rmn[5], rmx[5];
 #pragma unroll
                 for (int iy = 0; iy < 5; ++iy) {
-                    rmn[iy] = fminf(fminf(fminf(V[iy][0], V[iy][1]), fminf(V[iy][2], V[iy][3])), V[iy][4]);
-                    rmx[iy] = fmaxf(fmaxf(fmaxf(V[iy][0], V[iy][1]), fmaxf(V[iy][2], V[iy][3])), V[iy][4]);
+                    rmn[iy] = fm_min3(fm_min3(V[iy][0], V[iy][1], V[iy][2]), V[iy][3], V[iy][4]);
+                    rmx[iy] = fm_max3(fm_max3(V[iy][0], V[iy][1], V[iy][2]), V[iy][3], V[iy][4]);
                 }
-                mn = rmn[0]; mx = rmx[0];
-#pragma unroll
-                for (int iy = 1; iy < 5; ++iy) { mn = fminf(mn, rmn[iy]); mx = fmaxf(mx, rmx[iy]); }
+                mn = fm_min3(fm_min3(rmn[0], rmn[1], rmn[2]), rmn[3], rmn[4]);
+                mx = fm_max3(fm_max3(rmx[0], rmx[1], rmx[2]), rmx[3], rmx[4]);
             }
             uf2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};   // output rows ym = 0, 1 (flip_v: kernel rows reversed)
 #pragma unroll
@@ -369,17 +429,27 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void upsample2_lds_kernel(UpSt
                     acc0 = acc0 + wp[iy][ix] * sv;
                     acc1 = acc1 + wp[4 - iy][ix] * sv;
                 }
-            const bool bad = !isfinite(mn);
-            const float nanv = __builtin_nanf("");
+            // clamp to [mn, mx].  With every window sample below 2^100 in magnitude (tested wave by wave: then no product or
+            // partial sum overflows, the sums are finite and mn <= mx are finite) the clamp is one v_med3_f32 per output; the
+            // general form — infinities, NaN, the non-finite-minimum rule — otherwise
+            const bool tame = fabsf(mn) < 0x1p100f && fabsf(mx) < 0x1p100f;
+            if (__builtin_amdgcn_ballot_w64(!tame) == 0) {
+                o[0][0][c] = fm_med3(acc0.x, mn, mx); o[0][1][c] = fm_med3(acc0.y, mn, mx);
+                o[1][0][c] = fm_med3(acc1.x, mn, mx); o[1][1][c] = fm_med3(acc1.y, mn, mx);
+            } else {
+                asm volatile("; general clamp" ::: "memory");
+                const bool bad = !isfinite(mn);
+                const float nanv = __builtin_nanf("");
 #pragma unroll
-            for (int ym = 0; ym < 2; ++ym)
+                for (int ym = 0; ym < 2; ++ym)
 #pragma unroll
-                for (int xm = 0; xm < 2; ++xm) {
-                    float v = ym ? (xm ? acc1.y : acc1.x) : (xm ? acc0.y : acc0.x);
-                    v = v < mn ? mn : v;
-                    v = v > mx ? mx : v;
-                    o[ym][xm][c] = bad ? nanv : v;
-                }
+                    for (int xm = 0; xm < 2; ++xm) {
+                        float v = ym ? (xm ? acc1.y : acc1.x) : (xm ? acc0.y : acc0.x);
+                        v = v < mn ? mn : v;
+                        v = v > mx ? mx : v;
+                        o[ym][xm][c] = bad ? nanv : v;
+                    }
+            }
         }
 #pragma unroll 1
         for (int ym = 0; ym < 2; ++ym) {
