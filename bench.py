@@ -336,7 +336,9 @@ def main():
             roofline_valu = None
             if args.config == 2 and dominant == 2:
                 # the streaming kernel's region and segmentation, as fused_prepare() lays them out
-                iw, ih = (W4K - 4) // 8 * 8 - 16, (H4K - 4) // 8 * 8 - 16
+                # (JXLGPU_PK_TB=1: the packed kernel takes the top / bottom image rows itself — every row of the frame)
+                tb = os.environ.get("JXLGPU_PK_TB", "0") not in ("", "0") and not os.environ.get("JXLGPU_NO_PK")
+                iw, ih = (W4K - 4) // 8 * 8 - 16, (H4K if tb else (H4K - 4) // 8 * 8 - 16)
                 rows = post_rows_per_seg(ih, iw, torch.cuda.get_device_properties(local_rank).multi_processor_count)
                 segs = -(-ih // rows)
                 strips = -(-iw // POST_STRIP)

@@ -87,6 +87,12 @@ typedef struct {
 #define JXLGPU_TF_GAMMA 4u
 #define JXLGPU_TF_HLG 5u   /* linear_to_hlg (tf.rs:148-160): sqrt / libm logf, the latter as glibc computes  */
                            /* it (csrc/libm_f32.h); see hlg_ootf_intensity_target for the inverse OOTF       */
+/* PLATFORM CONDITION of JXLGPU_TF_HLG (and of hlg_ootf_intensity_target below): the reference hands these samples to the
+ * platform libm (powf / ln); the device evaluates glibc's published algorithms.  Bit-identity with the caller's own CPU
+ * path therefore holds where that libm is glibc >= 2.28 on x86_64 with FMA (its `-mfma` variants); on musl, macOS,
+ * Windows or x86 without FMA the local CPU path itself computes other bits.  A caller that needs CPU / GPU agreement
+ * there runs jxlgpu_selftest_libm once against its own libm and keeps HLG op lists on the CPU when the results differ
+ * (the library does not refuse them: it cannot know the caller's libm).                                              */
 /* JxlGpuColorParams.gamut_map: what sits between the two Matrix ops (convert.rs:398-414) */
 #define JXLGPU_GAMUT_NONE 0u
 #define JXLGPU_GAMUT_MAP 1u  /* ColorTransformOp::GamutMap (perceptual intent)                     */

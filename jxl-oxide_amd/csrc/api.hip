@@ -470,6 +470,11 @@ const char* color_params_unsupported(const JxlGpuColorParams& cp) {
     if (!(cp.hlg_ootf_intensity_target >= 0.0f) || std::isinf(cp.hlg_ootf_intensity_target))
         return "hlg_ootf_intensity_target is 0 (no inverse OOTF) or a finite positive intensity target";
     if (cp.gamut_map > JXLGPU_GAMUT_CLIP) return "unknown gamut_map mode";
+    // a GamutMap behind the tone map WITHOUT a tone map exists in one op list of the reference only: PQ -> HLG of a 1000-nit image
+    // (convert.rs:521-528).  Anything else with tm_gamut_map set and tone_map clear is a stale field of the caller:
+    // refuse it instead of applying an extra GamutMap
+    if (cp.tm_gamut_map && !cp.tone_map && cp.transfer_function != JXLGPU_TF_HLG)
+        return "tm_gamut_map without tone_map is the PQ -> HLG op list only (transfer_function = JXLGPU_TF_HLG)";
     return nullptr;
 }
 
@@ -539,13 +544,16 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
         if (r >= 0 && r <= JXLGPU_MAX_BATCH) ctx->tune.batch_chunk = r;
     }
     ctx->tune.no_pk = getenv("JXLGPU_NO_PK") != nullptr;
+    ctx->tune.pk_tb = getenv("JXLGPU_PK_TB") != nullptr && atoi(getenv("JXLGPU_PK_TB")) != 0;
     if (const char* e = getenv("JXLGPU_TR_SIDE_MAX")) ctx->tune.tr_side_max = atoi(e);
     ctx->tune.no_stream = getenv("JXLGPU_NO_STREAM") != nullptr;
     ctx->tune.no_fused = getenv("JXLGPU_NO_FUSED") != nullptr;
     ctx->tune.no_sparse_tr = getenv("JXLGPU_NO_SPARSE_TR") != nullptr;
     ctx->tune.debug_sync = getenv("JXLGPU_DEBUG_SYNC") != nullptr;
     ctx->tune.no_batch_overlap = getenv("JXLGPU_NO_BATCH_OVERLAP") != nullptr;
+#ifdef JXL_ENABLE_POST_FAST   // the non-bit-exact post kernel exists in experiment builds only (tools/build_variant.sh ... -DJXL_ENABLE_POST_FAST)
     ctx->tune.post_fast = getenv("JXLGPU_POST_FAST") != nullptr && atoi(getenv("JXLGPU_POST_FAST")) != 0;
+#endif
     if (const char* v = getenv("JXLGPU_TR_STREAMS")) ctx->tune.tr_streams = std::min(5, std::max(2, atoi(v)));
     if (const char* v = getenv("JXLGPU_RING_MODE")) ctx->tune.ring_mode = std::min(2, std::max(0, atoi(v)));
     ctx->tune.int_post = getenv("JXLGPU_INT_POST") != nullptr && atoi(getenv("JXLGPU_INT_POST")) != 0;

@@ -159,6 +159,9 @@ struct FusedArgs {
     int sx0, sx1, sy0, sy1, rows_per_seg, strips, segs;
     uint32_t n_ring_h;       // ring tile list: the first n_ring_h tiles are 32 x 16, the rest 16 x 32
     uint32_t pk;             // the geometry is the packed kernel's (strips of 120 columns, two per lane)
+    uint32_t tb;             // packed kernel, round 6: it takes the TOP and BOTTOM image borders itself (sy0 = 0, sy1 = height:
+                             // every stage's mirrored rows are patched into the row rings, post_pk.inc); the tile list then holds
+                             // the left / right 16-px columns only
     // Modular XYB frames: in[] = the INTEGER planes of the inverse transforms in channel order (Y, X, B), in_stride in samples;
     // the loaders convert on the fly (convert_to_float_modular_xyb, jxl-render/src/image.rs:148-189) — no float copy of the
     // frame is made.  0: f32 input; 1: int16 planes; 2: int32 planes.  in_m = m_lf_unscaled (X, Y, B).
@@ -238,6 +241,11 @@ struct Tuning {
     int tr_side_max = 16;        // JXLGPU_TR_SIDE_MAX: launches of <= this many frames run the big-shape transforms on the side stream
                                  // (short launches: their tails overlap; +2.7 % at 8 frames per launch, nothing at 32)
     bool no_pk = false;          // JXLGPU_NO_PK: scalar streaming kernel (one column per lane)
+    bool pk_tb = false;          // JXLGPU_PK_TB=1 (round 6, measured, not the default): the packed streaming kernel takes the top / bottom image rows
+                                 // itself (mirrored rows patched into its row rings, post_pk.inc) and the ring-tile kernel only the left / right
+                                 // columns (-64 % of its tiles).  Bit-identical (tests/test_gpu_schedules.py runs both forms); 115.1-115.2 against
+                                 // 114.1-114.2 us per frame on one box, 112.5-112.9 against 111.5-112.0 on another: the 32 extra rows sit in the
+                                 // launch that sets the period, the ring tiles they replace ran beside it
     bool no_stream = false;      // JXLGPU_NO_STREAM: LDS tile kernel for the whole frame
     bool no_fused = false;       // JXLGPU_NO_FUSED: one kernel per post stage
     bool no_sparse_tr = false;   // JXLGPU_NO_SPARSE_TR: grouped lists are expanded to dense cells first (dense kernels)
@@ -449,6 +457,7 @@ struct jxlgpu_frame {
     uint32_t* ring_tiles = nullptr;      // border ring of the streaming post path: tile origins x0 | y0 << 16
     uint32_t n_ring_tiles = 0, n_ring_h = 0;  // the first n_ring_h are 32 x 16 (top / bottom), the rest 16 x 32
     std::vector<uint32_t> ring_host;     // the same list on the host (region renders launch the tiles they touch)
+    uint32_t ring_tb = 0;                // the list was built for a streaming kernel that takes the top / bottom borders itself (FusedArgs::tb)
     uint32_t* region_tiles[2] = {};      // region renders: tile lists of the launches in flight
     size_t region_tiles_cap[2] = {};
     float* up_weights[3] = {};  // expanded 5x5 kernels per phase for 2x/4x/8x

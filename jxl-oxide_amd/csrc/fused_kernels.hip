@@ -665,18 +665,33 @@ hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in
     // streaming kernel takes [sx0, sx1) x [sy0, sy1) — everything at least SH samples away from the
     // border, cut to whole 8x8 cells — and the tile kernel the ring of 16-px strips around it.
     const int W = (int)f->width, H = (int)f->height;
-    const int sx0 = kRingT, sy0 = kRingT, sx1 = (W - SH) / 8 * 8, sy1 = (H - SH) / 8 * 8;  // W - sx1 <= SH + 7 < kRingT
     const bool no_stream = ctx && ctx->tune.no_stream;
     bool stream = epf_iters == 2 && W >= 64 && H >= 64 && W < 65536 && H < 65536 && !no_stream;
-    if (stream && !f->ring_tiles) {
+    // Packed kernel (two columns per lane): 8-byte aligned input / output rows, and the sign conditions under which 1 + d * s <= 1 (clamp == max(., 0)).
+    bool pk = false;
+    {
+        const JxlGpuFilterParams& fp = a.fp;
+        pk = !(ctx && ctx->tune.no_pk) && (out_stride & 1) == 0 && (in_tiled_w8 || (in_stride & 1) == 0) &&
+             fp.epf_channel_scale[0] >= 0 && fp.epf_channel_scale[1] >= 0 && fp.epf_channel_scale[2] >= 0 &&
+             fp.epf_border_sad_mul >= 0 && fp.epf_pass2_sigma_scale >= 0;
+        for (int c = 0; c < 3; ++c)
+            pk = pk && (reinterpret_cast<uintptr_t>(out[c]) & 7) == 0 && (in_tiled_w8 || (reinterpret_cast<uintptr_t>(in[c]) & 7) == 0);
+    }
+    // JXLGPU_PK_TB=1: the packed kernel takes the image's top and bottom rows itself (round 6: measured, not the default — Tuning::pk_tb);
+    // the tile kernel then serves the left / right columns only
+    const bool tb = stream && pk && ctx && ctx->tune.pk_tb;
+    const int sx0 = kRingT, sx1 = (W - SH) / 8 * 8;  // W - sx1 <= SH + 7 < kRingT
+    const int sy0 = tb ? 0 : kRingT, sy1 = tb ? H : (H - SH) / 8 * 8;
+    if (stream && (!f->ring_tiles || f->ring_tb != (tb ? 1u : 0u))) {
         std::vector<uint32_t> ring;  // pixel origins x0 | y0 << 16
-        for (int x0 = 0; x0 < W; x0 += kRingL) {  // top, bottom: 32 x 16 tiles (corners included)
-            ring.push_back((uint32_t)x0);
-            ring.push_back((uint32_t)x0 | ((uint32_t)sy1 << 16));
-        }
+        if (!tb)
+            for (int x0 = 0; x0 < W; x0 += kRingL) {  // top, bottom: 32 x 16 tiles (corners included)
+                ring.push_back((uint32_t)x0);
+                ring.push_back((uint32_t)x0 | ((uint32_t)sy1 << 16));
+            }
         const uint32_t n_h = (uint32_t)ring.size();
-        for (int y0 = sy0; y0 < sy1; y0 += kRingL) {  // left, right: 16 x 32 tiles (the last pair may reach into
-            ring.push_back((uint32_t)y0 << 16);        // the bottom strip: the same samples, written twice)
+        for (int y0 = sy0; y0 < sy1; y0 += kRingL) {  // left, right: 16 x 32 tiles (the last pair may reach into the bottom
+            ring.push_back((uint32_t)y0 << 16);        // strip — or past the image: the tile kernel clips — the same samples, written twice)
             ring.push_back((uint32_t)sx1 | ((uint32_t)y0 << 16));
         }
         void* p = nullptr;
@@ -687,10 +702,11 @@ hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in
             f->allocs.push_back(p);
             hipError_t e = hipMemcpy(p, ring.data(), ring.size() * 4, hipMemcpyHostToDevice);
             if (e != hipSuccess) return e;
-            f->ring_tiles = static_cast<uint32_t*>(p);
+            f->ring_tiles = static_cast<uint32_t*>(p);   // (a list built for the other mode stays with the frame until it is freed: launches may still read it)
             f->n_ring_tiles = (uint32_t)ring.size();
             f->n_ring_h = n_h;
             f->ring_host = ring;
+            f->ring_tb = tb ? 1u : 0u;
         }
     }
     *stream_out = stream;
@@ -714,14 +730,8 @@ hipError_t fused_prepare(jxlgpu_ctx* ctx, jxlgpu_frame* f, const float* const in
             const int n = std::max(1, (total + a.rows_per_seg / 2) / a.rows_per_seg);
             a.rows_per_seg = ((total + n - 1) / n + 3) / 4 * 4;
         }
-        // Packed kernel (two columns per lane): 8-byte aligned input / output rows, and the sign conditions under which 1 + d * s <= 1 (clamp == max(., 0)).
-        const JxlGpuFilterParams& fp = a.fp;
-        bool pk = !(ctx && ctx->tune.no_pk) && (out_stride & 1) == 0 && (in_tiled_w8 || (in_stride & 1) == 0) &&
-                  fp.epf_channel_scale[0] >= 0 && fp.epf_channel_scale[1] >= 0 && fp.epf_channel_scale[2] >= 0 &&
-                  fp.epf_border_sad_mul >= 0 && fp.epf_pass2_sigma_scale >= 0;
-        for (int c = 0; c < 3; ++c)
-            pk = pk && (reinterpret_cast<uintptr_t>(out[c]) & 7) == 0 && (in_tiled_w8 || (reinterpret_cast<uintptr_t>(in[c]) & 7) == 0);
         a.pk = pk ? 1u : 0u;
+        a.tb = (tb && f->ring_tb) ? 1u : 0u;
         const int sw = pk ? PW : SW;
         a.strips = (a.sx1 - a.sx0 + sw - 1) / sw;
         a.segs = (a.sy1 - a.sy0 + a.rows_per_seg - 1) / a.rows_per_seg;
@@ -882,8 +892,12 @@ hipError_t launch_post_batch(hipStream_t s, hipStream_t side, const FrameBatch& 
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&post_pk_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         });
     }
-    if (max_stream_wgs && pk && fast) post_pk_fast_batch_kernel<<<dim3(max_stream_wgs, n), 256, 0, s>>>(b);
-    else if (max_stream_wgs && pk) post_pk_batch_kernel<<<dim3(max_stream_wgs, n), 256, (size_t)std::max(0, lds_pad), s>>>(b);
+#ifdef JXL_ENABLE_POST_FAST
+    if (max_stream_wgs && pk && fast) { post_pk_fast_batch_kernel<<<dim3(max_stream_wgs, n), 256, 0, s>>>(b); return hipGetLastError(); }
+#else
+    (void)fast;
+#endif
+    if (max_stream_wgs && pk) post_pk_batch_kernel<<<dim3(max_stream_wgs, n), 256, (size_t)std::max(0, lds_pad), s>>>(b);
     else if (max_stream_wgs) post_stream_batch_kernel<<<dim3(max_stream_wgs, n), 256, 0, s>>>(b);
     return hipGetLastError();
 }

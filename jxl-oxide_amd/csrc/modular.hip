@@ -2699,8 +2699,8 @@ int jxlgpu_modular_upload(jxlgpu_ctx* ctx, const JxlGpuModularDesc* d, jxlgpu_fr
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "fewer channels than colour channels");
     if (d->residual_predictor != 0xFFFFFFFFu && d->residual_predictor > 13)
         return fail(ctx, JXLGPU_ERR_INVALID_ARG, "residual_predictor is neither 0xFFFFFFFF nor a Predictor (0..13)");
-    if (d->xyb_encoded)
-        if (const char* why = color_params_unsupported(d->color)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, why);
+    // every frame that asks for the colour pass (color.enabled), XYB or not: the same checks as a VarDCT upload
+    if (const char* why = color_params_unsupported(d->color)) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, why);
     if ((d->residual_predictor <= 13 || d->num_unit_leaves) && d->group_dim > kPredLaneMaxW) return fail(ctx, JXLGPU_ERR_UNSUPPORTED, "predictor tiles wider than 1024");
     if (d->num_unit_leaves && !d->unit_leaves) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null unit_leaves");
     if (d->num_axis_leaves && !d->axis_leaves) return fail(ctx, JXLGPU_ERR_INVALID_ARG, "null axis_leaves");

@@ -1,7 +1,7 @@
 """The tuning switches of the batched render (csrc/common.h `Tuning`) change WHERE and WHEN launches run, never what they
 compute: under every one of them a batch must give the oracle's bits.  Also: the Modular predictor waves on the side stream
-(JXLGPU_PRED_LATE_STEPS), the guard allocator's 4-byte mode, and the one switch that is allowed to differ — JXLGPU_POST_FAST,
-a measured, non-bit-exact option, which must stay close and must stay off by default."""
+(JXLGPU_PRED_LATE_STEPS), the guard allocator's 4-byte mode, and the switch that used to be allowed to differ — JXLGPU_POST_FAST,
+since round 6 a compile-time option that the shipped library does not have."""
 import numpy as np
 import pytest
 
@@ -49,6 +49,12 @@ def expected(oracle):
     {"JXLGPU_BATCH_CHUNK": "4", "JXLGPU_BATCH_TR_MULT": "2"},                       # transform launches of two chunks, post launches of one
     {"JXLGPU_BATCH_CHUNK": "2", "JXLGPU_BATCH_TR_MULT": "4", "JXLGPU_TR_SIDE_MAX": "32"},
     {"JXLGPU_NO_BATCH_OVERLAP": "1"},
+    {"JXLGPU_PK_TB": "1"},                                # round 6: the top / bottom image rows inside the streaming kernel instead of through ring tiles
+    {"JXLGPU_PK_TB": "1", "JXLGPU_BATCH_CHUNK": "4"},
+    {"JXLGPU_PK_TB": "1", "JXLGPU_BATCH_STREAM_ROWS": "32"},
+    {"JXLGPU_BATCH_LF_MODE": "1", "JXLGPU_BATCH_CHUNK": "4"},   # LF launches one chunk ahead / behind the previous chunk's small families (round-6 experiments)
+    {"JXLGPU_BATCH_LF_MODE": "2", "JXLGPU_BATCH_CHUNK": "4"},
+    {"JXLGPU_STREAM_PRIO": "-1", "JXLGPU_BATCH_CHUNK": "4"},
 ], ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
 def test_every_schedule_gives_the_same_bits(expected, monkeypatch, env):
     wls, exp = expected
@@ -64,25 +70,19 @@ def test_every_schedule_gives_the_same_bits(expected, monkeypatch, env):
         assert np.array_equal(g.view(np.uint32), e.view(np.uint32)), (env, _WLS[i // 3])
 
 
-def test_post_fast_is_off_by_default_and_close_when_on(expected, monkeypatch):
-    """JXLGPU_POST_FAST=1 selects the non-bit-exact post kernel of the batched default pipeline (csrc/post_pk.inc): it has to
-    be asked for, and what it returns stays within 1e-4 of the oracle in display-referred sRGB (it differs by several ULP)."""
+def test_post_fast_cannot_be_switched_on_in_the_shipped_library(expected, monkeypatch):
+    """JXLGPU_POST_FAST selected a non-bit-exact post kernel in round 5 (a measured option: +6.6 %, 42 % of the samples beyond
+    1 ULP).  Since round 6 that kernel is compiled only with -DJXL_ENABLE_POST_FAST (tools/build_variant.sh): the library the
+    tests and the bench load ignores the variable — no environment can change the bits."""
     wls, exp = expected
-    monkeypatch.setenv("JXLGPU_POST_FAST", "1")
-    ctx = runtime.Context(0)
-    try:
-        got = _render_batch(ctx, wls[:1], copies=1)[0]
-    finally:
-        ctx.close()
-    assert not np.array_equal(got.view(np.uint32), exp[0].view(np.uint32)), "the fast kernel did not run (or became exact)"
-    assert np.nanmax(np.abs(got.astype(np.float64) - exp[0].astype(np.float64))) < 1e-4
-    monkeypatch.setenv("JXLGPU_POST_FAST", "0")
-    ctx = runtime.Context(0)
-    try:
-        got = _render_batch(ctx, wls[:1], copies=1)[0]
-    finally:
-        ctx.close()
-    assert np.array_equal(got.view(np.uint32), exp[0].view(np.uint32))
+    for v in ("1", "0"):
+        monkeypatch.setenv("JXLGPU_POST_FAST", v)
+        ctx = runtime.Context(0)
+        try:
+            got = _render_batch(ctx, wls[:1], copies=1)[0]
+        finally:
+            ctx.close()
+        assert np.array_equal(got.view(np.uint32), exp[0].view(np.uint32)), v
 
 
 @pytest.mark.parametrize("late", ["0", "1", "3", "9"])
