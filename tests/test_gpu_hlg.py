@@ -140,17 +140,24 @@ def test_hlg_modular_frame(gpu_ctx, oracle):
 
 
 def test_gamut_map_without_a_tone_map(gpu_ctx, oracle):
-    """tm_gamut_map is honoured without tone_map since ABI 23 (the PQ -> HLG list of a 1000-nit image); with another
-    transfer function too."""
+    """tm_gamut_map without tone_map is ONE op list of the reference: PQ -> HLG of a 1000-nit image (convert.rs:521-528; served,
+    MODES "pq_to_hlg_1000" above).  With any other transfer function it is a stale field of the caller: refused since round 6
+     instead of applying an extra GamutMap."""
     wl = VardctWorkload(264, 200, seed=90, intensity_target=1000.0)
-    wl.color.tm_luminances[:] = SRGB_LUMINANCES
-    wl.color.tm_gamut_map = 1
-    wl.color.tm_gamut_saturation_factor = 0.1
+    configure_color(wl.color, "pq_to_hlg_1000")
+    assert wl.color.tm_gamut_map == 1 and wl.color.tone_map == 0 and wl.color.transfer_function == abi.TF_HLG
     got, exp = _both(gpu_ctx, oracle, wl, S_ALL)
-    assert_same_bits_or_nan(got, exp, "GamutMap{0.1} -> sRGB", min_finite=1.0)
+    assert_same_bits_or_nan(got, exp, "GamutMap{0.1} -> HLG", min_finite=1.0)
     wl.color.tm_gamut_map = 0
     _, off = _both(gpu_ctx, oracle, wl, S_ALL)
-    assert np.abs(off - exp).max() > 1e-3
+    assert np.nanmax(np.abs(off - exp)) > 1e-3
+    stale = VardctWorkload(264, 200, seed=90, intensity_target=1000.0)   # plain sRGB target with the field left set
+    stale.color.tm_luminances[:] = SRGB_LUMINANCES
+    stale.color.tm_gamut_map = 1
+    stale.color.tm_gamut_saturation_factor = 0.1
+    with pytest.raises(Exception) as e:
+        gpu_ctx.vardct_upload(stale.desc())
+    assert e.value.code == abi.ERR_UNSUPPORTED
 
 
 def test_bad_hlg_parameters_are_refused(gpu_ctx):
