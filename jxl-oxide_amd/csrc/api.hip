@@ -579,6 +579,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     }
     if (const char* v = getenv("JXLGPU_SQZ_RUNIN")) ctx->tune.sqz_runin = (uint32_t)atoi(v);
     ctx->tune.pred_wg = getenv("JXLGPU_PRED_WG") != nullptr;
+    if (const char* v = getenv("JXLGPU_PRED_PRIO")) ctx->tune.pred_prio = atoi(v) != 0;
     ctx->tune.pred_wide = getenv("JXLGPU_PRED_WIDE") != nullptr;
     if (const char* v = getenv("JXLGPU_PRED_LATE_STEPS")) ctx->tune.pred_late_steps = std::max(0, atoi(v));
     ctx->tune.sqz_h_rows = getenv("JXLGPU_SQZ_H_ROWS") != nullptr;

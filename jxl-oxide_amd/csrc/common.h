@@ -270,6 +270,9 @@ struct Tuning {
     bool pred_wide = false;      // JXLGPU_PRED_WIDE: the self-correcting predictor in 64-bit arithmetic only
     int pred_late_steps = 3;     // JXLGPU_PRED_LATE_STEPS: residuals of the first so many (forward) Squeeze steps get their predictor waves on a
                                  // side stream, beside the deep Squeeze levels; the inverse step that reads them waits (0: everything in front)
+    bool pred_prio = false;      // JXLGPU_PRED_PRIO=1 (round 6, measured, not adopted): issue priority by chain length in the narrow predictor kernel
+                                 // (s_setprio 3 .. 0 for the longest quarter .. the short waves).  Config 3: 14.1-14.2 against 15.2-15.3 GP/s — the waves
+                                 // of the misaligned subgrids on the side stream (no priority of their own) take 0.48 instead of 0.30 ms
     bool pred_wg = false;        // JXLGPU_PRED_WG: predictor subgrids through the workgroup-per-subgrid kernel only
     int up2_variant = 0;         // JXLGPU_UP2_VARIANT: 1 = register-ring form of the 2x upsampling kernel, 2 = LDS ring with the
                                  // general colour code only (0: LDS ring, packed colour chain for the HDR PQ op list)

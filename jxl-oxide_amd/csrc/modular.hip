@@ -1467,6 +1467,16 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
     __shared__ R s_out[64][RO + 1];
     __shared__ R s_in[64][kRing + 1];
     const PredWave wv = waves[blockIdx.x];
+    // A wave is one serial chain; the launch lasts as long as its longest wave (1276 steps for a 256 x 256 subgrid), and a step's
+    // latency stretches with every other wave that shares the SIMD's issue slots.  The host ranks the waves by length
+    // (PredWave::pad[1]): the long ones issue ahead of the short ones, which have slack — JXLGPU_PRED_PRIO=1, an experiment of round 6 that
+    // LOST 7 % on config 3 (Tuning::pred_prio): off by default, pad[1] is 0.
+    switch (__builtin_amdgcn_readfirstlane((int)wv.pad[1])) {
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        default: break;
+    }
     const uint32_t lane = threadIdx.x;
     const uint32_t log2p = wv.log2p, log2dp = wv.log2dp, P = 1u << log2p, DPm1 = (1u << log2dp) - 1u;
     const int32_t D = (int32_t)(1u << (log2dp - log2p));
@@ -2350,6 +2360,13 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 if (x.vec != y.vec) return x.vec > y.vec;
                 return x.steps > y.steps;
             });
+            {   // issue priority by chain length (predict_lanes_narrow_kernel): the longest quarter 3, then 2, 1, 0
+                uint32_t max_steps = 1;
+                for (const PredWave& w : waves) max_steps = std::max(max_steps, w.steps);
+                const bool on = ctx->tune.pred_prio;
+                for (PredWave& w : waves)
+                    w.pad[1] = !on ? 0u : (w.steps * 4 >= max_steps * 3 ? 3u : (w.steps * 2 >= max_steps ? 2u : (w.steps * 4 >= max_steps ? 1u : 0u)));
+            }
             m->n_pred_vec_waves = m->n_pred_early = m->n_pred_late_vec = 0;
             for (const PredWave& w : waves) {
                 if (!w.pad[0]) { ++m->n_pred_early; m->n_pred_vec_waves += w.vec; }
