@@ -86,7 +86,7 @@ __device__ __forceinline__ void mirror_fill(float* buf, int lo, int ox, int oy, 
 
 template <int STEP, int LWX, int LWY, int K>
 __device__ __forceinline__ void epf_stage(const float* src, float* dst, int lo, int ox, int oy, int width,
-                                          int height, const FusedArgs& a, int t, bool last, float (&res)[K][3]) {
+                                          int height, const FusedArgs& a, int t, bool last, float (&res)[K][3], bool border = true) {
     constexpr int PLANE = LWX * LWY;
     const int nx = LWX - 2 * lo, ny = LWY - 2 * lo;
     const float step_multiplier = STEP == 0 ? a.fp.epf_pass0_sigma_scale
@@ -95,7 +95,7 @@ __device__ __forceinline__ void epf_stage(const float* src, float* dst, int lo, 
     for (int i = t; i < nx * ny; i += 256, ++k) {
         int ly = lo + i / nx, lx = lo + i % nx;
         int x = ox + lx, y = oy + ly;
-        if (x < 0 || x >= width || y < 0 || y >= height) continue;
+        if (border && (x < 0 || x >= width || y < 0 || y >= height)) continue;   // (workgroup-uniform `border`: false = the whole halo lies inside the image)
         const float* p = src + ly * LWX + lx;
         float o[3];
         float sigma_val = a.sigma[(size_t)(y >> 3) * a.sigma_stride + (x >> 3)];
@@ -136,12 +136,28 @@ __device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds, 
     const int W = a.width, H = a.height;
     const bool border = ox < 0 || oy < 0 || ox + LWX > W || oy + LWY > H;
 
-    // ---- load tile + halo (mirrored at the image border), 3 channels
-    for (int i = t; i < PLANE; i += 256) {
-        int ly = i / LWX, lx = i % LWX;
-        int x = mirror_idx(ox + lx, W), y = mirror_idx(oy + ly, H);
+    // ---- load tile + halo (mirrored at the image border), 3 channels.  A tile whose halo lies inside the image (workgroup-uniform:
+    //      nearly every tile of a frame) needs neither the mirror nor, below, the per-sample edge tests of the stages.
+    if (!border) {
+        for (int i = t; i < PLANE; i += 256) {
+            const int ly = i / LWX, lx = i % LWX;
+            const int x = ox + lx, y = oy + ly;
+            if constexpr (TILED) {
+                const size_t base = coeff_tiled_index((uint32_t)x, (uint32_t)y, 0u, a.in_w8);   // channels are 64 words apart inside a cell
 #pragma unroll
-        for (int c = 0; c < 3; ++c) bufA[c * PLANE + i] = load_in<TILED>(a, c, x, y);
+                for (int c = 0; c < 3; ++c) bufA[c * PLANE + i] = a.in[0][base + 64u * c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) bufA[c * PLANE + i] = load_in<TILED>(a, c, x, y);
+            }
+        }
+    } else {
+        for (int i = t; i < PLANE; i += 256) {
+            int ly = i / LWX, lx = i % LWX;
+            int x = mirror_idx(ox + lx, W), y = mirror_idx(oy + ly, H);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) bufA[c * PLANE + i] = load_in<TILED>(a, c, x, y);
+        }
     }
     __syncthreads();
 
@@ -158,12 +174,20 @@ __device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds, 
         for (int i = t; i < nx * ny; i += 256, ++k) {
             int ly = lo + i / nx, lx = lo + i % nx;
             int x = ox + lx, y = oy + ly;
-            if (x < 0 || x >= W || y < 0 || y >= H) continue;
+            if (border && (x < 0 || x >= W || y < 0 || y >= H)) continue;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float* p = src + c * PLANE + ly * LWX + lx;
                 auto at = [&](int dx, int dy) { return p[dy * LWX + dx]; };
-                float v = gabor_sample(at, x, y, W, H, a.fp.gab_weights[c][0], a.fp.gab_weights[c][1]);
+                float v;
+                if (border) {
+                    v = gabor_sample(at, x, y, W, H, a.fp.gab_weights[c][0], a.fp.gab_weights[c][1]);
+                } else {   // the interior expression of gabor_sample (run_gabor_row_generic, gabor.rs:135-147): no edge row / column in reach
+                    const float w0 = a.fp.gab_weights[c][0], w1 = a.fp.gab_weights[c][1];
+                    const float sum_side = at(0, -1) + at(-1, 0) + at(1, 0) + at(0, 1);
+                    const float sum_diag = at(-1, -1) + at(1, -1) + at(-1, 1) + at(1, 1);
+                    v = (at(0, 0) + sum_side * w0 + sum_diag * w1) * (1.0f / (1.0f + w0 * 4.0f + w1 * 4.0f));
+                }
                 if (last) res[k][c] = v;
                 else dst[c * PLANE + ly * LWX + lx] = v;
             }
@@ -180,7 +204,7 @@ __device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds, 
     if constexpr (Cfg::HAS_E0) {
         lo += 3;
         constexpr bool last = ITERS == 4;
-        epf_stage<0, LWX, LWY, K>(src, dst, lo, ox, oy, W, H, a, t, last, res);
+        epf_stage<0, LWX, LWY, K>(src, dst, lo, ox, oy, W, H, a, t, last, res, border);
         if (!last) {
             __syncthreads();
             if (border) {
@@ -193,7 +217,7 @@ __device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds, 
     if constexpr (Cfg::HAS_E1) {
         lo += 2;
         constexpr bool last = ITERS == 1;
-        epf_stage<1, LWX, LWY, K>(src, dst, lo, ox, oy, W, H, a, t, last, res);
+        epf_stage<1, LWX, LWY, K>(src, dst, lo, ox, oy, W, H, a, t, last, res, border);
         if (!last) {
             __syncthreads();
             if (border) {
@@ -205,7 +229,7 @@ __device__ __forceinline__ void fused_post_body(const FusedArgs& a, float* lds, 
     }
     if constexpr (Cfg::HAS_E2) {
         lo += 1;
-        epf_stage<2, LWX, LWY, K>(src, dst, lo, ox, oy, W, H, a, t, true, res);
+        epf_stage<2, LWX, LWY, K>(src, dst, lo, ox, oy, W, H, a, t, true, res, border);
     }
     if constexpr (!GAB && ITERS == 0) {
         // colour only: straight from the staged tile

@@ -349,6 +349,9 @@ static bool is_hdr_pq_list(const ColorArgs& c) {
 // five waves per SIMD.  The four phase sums of a sample run as two packed chains: phase xm = 1 uses the
 // horizontally flipped kernel, so (w[iy][ix], w[iy][4 - ix]) * (s, s) accumulates (xm = 0, xm = 1) with one
 // v_pk_mul_f32 + one v_pk_add_f32 per tap — the reference's mul-then-add, each rounded once, per half.
+#ifndef UP2_YM_UNROLL
+#define UP2_YM_UNROLL 1
+#endif
 typedef float uf2 __attribute__((ext_vector_type(2)));
 constexpr int RING_STRIDE = 68;  // floats per (slot, channel) row: 2 pad + 64 lanes + 2 pad
 
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void upsample2_lds_kernel(UpSt
                     }
             }
         }
-#pragma unroll 1
+#pragma unroll UP2_YM_UNROLL
         for (int ym = 0; ym < 2; ++ym) {
             float p0[3], p1[3];
 #pragma unroll

@@ -35,7 +35,7 @@ case "$1" in
      rm -rf $O/stats $O/sq/*/ 2>/dev/null
      find $O -name "*.csv" -size +8M -delete ;;
   B) for c in 3 5; do
-       timeout 300 python bench.py --config $c --cpu-seconds 2 > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err < /dev/null; echo "cfg$c rc=$?"; cut -c1-300 $O/bench_cfg$c.json
+       timeout 900 python bench.py --config $c --cpu-seconds 2 > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err < /dev/null; echo "cfg$c rc=$?"; cut -c1-300 $O/bench_cfg$c.json
        prof stats $O/stats_cfg$c python $R/bench.py --config $c --frames 2 --distinct 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-verify
        f=$(biggest $O/stats_cfg$c "*kernel_stats.csv"); [ -n "$f" ] && cp "$f" $O/cfg${c}_kernel_stats.csv && head -14 $O/cfg${c}_kernel_stats.csv | cut -c1-150
        rm -rf $O/stats_cfg$c
