@@ -75,6 +75,8 @@ __device__ __forceinline__ float rcp_cr(float d) {
 // operand when one is a NaN)
 __device__ __forceinline__ float fm_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float fm_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float fm_min3_abs(float a, float b, float c) { float r; asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float fm_max3_abs(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float fm_med3(float a, float b, float c) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float div_cr(float n, float d) {
     float r = __builtin_amdgcn_rcpf(d);

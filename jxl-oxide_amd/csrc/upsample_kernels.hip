@@ -248,11 +248,21 @@ __device__ __forceinline__ void map_gamut_pair(const cf2* k, cf2 (&rgb)[3]) {
     // correctly rounded quotient (fast_math_device.h: 1 <= d <= 2^20, 2^-100 <= |n| <= 2^20 or n = +-0), tested wave by wave;
     // the ordinary divisions otherwise (a tiny non-zero numerator, huge values, NaN)
     {
-        bool ok = fm_in_range_bits(max_color_val.x, kFmBits1, kFmBits2p20) && fm_in_range_bits(max_color_val.y, kFmBits1, kFmBits2p20);
+        // (max_color_val >= 1 by construction; the smallest and the largest magnitude of the six numerators with three-operand
+        //  min / max and |.| modifiers: four instructions; a wave that fails looks again with exact zeros allowed)
+        const float lo = fminf(fm_min3_abs(mixed[0].x, mixed[1].x, mixed[2].x), fm_min3_abs(mixed[0].y, mixed[1].y, mixed[2].y));
+        const float hi = fm_max3(fm_max3_abs(mixed[0].x, mixed[1].x, mixed[2].x), fm_max3_abs(mixed[0].y, mixed[1].y, mixed[2].y),
+                                 fmaxf(max_color_val.x, max_color_val.y));
+        const cf2 nsum = mixed[0] + mixed[1] + mixed[2];                      // (v_min3 / v_max3 skip a NaN operand: a NaN numerator shows here)
+        const bool no_nan = nsum.x == nsum.x && nsum.y == nsum.y;
+        bool ok = lo >= 0x1p-100f && hi <= 0x1p20f && no_nan;
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0) {
+            ok = hi <= 0x1p20f && no_nan;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float ax = fabsf(mixed[i].x), ay = fabsf(mixed[i].y);
-            ok = ok && (ax == 0.0f || fm_in_range_bits(ax, kFmBits2m100, kFmBits2p20)) && (ay == 0.0f || fm_in_range_bits(ay, kFmBits2m100, kFmBits2p20));
+            for (int i = 0; i < 3; ++i) {
+                const float ax = fabsf(mixed[i].x), ay = fabsf(mixed[i].y);
+                ok = ok && (ax == 0.0f || ax >= 0x1p-100f) && (ay == 0.0f || ay >= 0x1p-100f);
+            }
         }
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
             const cf2 r = rcp_refined_pair(max_color_val);
