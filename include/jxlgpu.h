@@ -346,6 +346,16 @@ int jxlgpu_selftest_libm(jxlgpu_ctx* ctx, int which, const float* x, size_t n, f
  * 1 = varblock transforms (V4-V8), 2 = restoration filters + upsampling + colour, 3 = Modular
  * inverse transforms; -1 = off.                                                                   */
 int jxlgpu_profile_select(jxlgpu_ctx* ctx, int group);
+
+/* Tracing hook (ABI 24): the reference wraps the work this library replaces in `tracing` spans ("Load LF groups",
+ * "Dequant and transform", "Edge-preserving filter", "Inverse Modular transform": jxl-render/src/vardct/mod.rs:164, :316,
+ * filter/epf.rs:21, modular.rs:134).  With a callback set, the library calls it on the CALLING thread when it starts
+ * (begin = 1) and when it has finished ENQUEUEING (begin = 0) the launch group that stands for such a span, with the
+ * reference's span name — what a Rust shim forwards to `tracing::trace_span!(..).entered()` / the guard's drop, so that a
+ * subscriber sees the same span tree with the device path as without it.  Device durations are not what the callback
+ * reports (the calls are asynchronous): jxlgpu_profile_select / rocprofv3 measure those.  callback = NULL switches it off. */
+typedef void (*jxlgpu_trace_fn)(void* user, const char* span, int begin);
+int jxlgpu_set_trace(jxlgpu_ctx* ctx, jxlgpu_trace_fn callback, void* user);
 int jxlgpu_profile_read(jxlgpu_ctx* ctx, double* total_ms, uint64_t* brackets);
 
 /* ---- VarDCT ---- */

@@ -239,6 +239,9 @@ class ExtraChannel(C.Structure):
     ]
 
 
+TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_int)   # jxlgpu_trace_fn
+
+
 class SqueezeStep(C.Structure):
     _fields_ = [("horizontal", C.c_uint32), ("in_place", C.c_uint32),
                 ("begin_c", C.c_uint32), ("num_c", C.c_uint32)]
@@ -314,6 +317,7 @@ _SYMBOLS = [
     ("jxlgpu_selftest_libm", C.c_int, [C.c_void_p, C.c_int, f32p, C.c_size_t, C.c_float, f32p]),
     ("jxlgpu_set_memory_limit", C.c_int, [C.c_void_p, C.c_uint64]),
     ("jxlgpu_memory_usage", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("jxlgpu_set_trace", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("jxlgpu_profile_select", C.c_int, [C.c_void_p, C.c_int]),
     ("jxlgpu_profile_read", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("jxlgpu_vardct_upload", C.c_int, [C.c_void_p, C.POINTER(VardctDesc), C.POINTER(C.c_void_p)]),

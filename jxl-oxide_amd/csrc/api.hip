@@ -724,6 +724,13 @@ int jxlgpu_upload_split(jxlgpu_ctx* ctx, double ms[5]) {
 
 void* jxlgpu_stream(jxlgpu_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+int jxlgpu_set_trace(jxlgpu_ctx* ctx, jxlgpu_trace_fn fn, void* user) {
+    if (!ctx) return JXLGPU_ERR_INVALID_ARG;
+    ctx->trace_fn = fn;
+    ctx->trace_user = user;
+    return JXLGPU_OK;
+}
+
 int jxlgpu_profile_select(jxlgpu_ctx* ctx, int group) {
     if (!ctx || group >= PROF_COUNT) return JXLGPU_ERR_INVALID_ARG;
     ctx->prof_group = group;

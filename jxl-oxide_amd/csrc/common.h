@@ -357,7 +357,17 @@ struct jxlgpu_ctx {
     int prof_group = -1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;
+    // jxlgpu_set_trace: the reference's span of every launch group, on the calling thread (begin / end of the ENQUEUE)
+    void (*trace_fn)(void* user, const char* span, int begin) = nullptr;
+    void* trace_user = nullptr;
+    static const char* span_name(int g) {
+        // jxl-render/src/vardct/mod.rs:164 ("Load LF groups": LF dequant + CfL + adaptive smoothing sit inside it), :316,
+        // filter/epf.rs:21 (the fused launch group also holds the Gabor-like stage and the colour transform), modular.rs:134
+        static const char* const kNames[PROF_COUNT] = {"Load LF groups", "Dequant and transform", "Edge-preserving filter", "Inverse Modular transform"};
+        return g >= 0 && g < PROF_COUNT ? kNames[g] : "?";
+    }
     void prof_begin(int g, hipStream_t on = nullptr) {
+        if (trace_fn) trace_fn(trace_user, span_name(g), 1);
         if (g != prof_group) return;
         if (!on) on = stream;
         if (prof_used == prof_events.size()) {
@@ -369,6 +379,7 @@ struct jxlgpu_ctx {
         (void)hipEventRecord(prof_events[prof_used].first, on);
     }
     void prof_end(int g, hipStream_t on = nullptr) {
+        if (trace_fn) trace_fn(trace_user, span_name(g), 0);
         if (g != prof_group) return;
         if (!on) on = stream;
         (void)hipEventRecord(prof_events[prof_used].second, on);

@@ -101,6 +101,16 @@ class Context:
             raise JxlGpuError(rc, "jxlgpu_create failed (no MI355X visible?)")
         self.handle = h
 
+    def set_trace(self, callback):
+        """jxlgpu_set_trace: `callback(span: str, begin: bool)` on the calling thread around every launch group, with the reference's
+        span name (None switches it off).  The ctypes thunk is kept alive on the context."""
+        if callback is None:
+            self._trace = None
+            self._check(self.lib.jxlgpu_set_trace(self.handle, None, None))
+            return
+        self._trace = abi.TRACE_FN(lambda user, span, begin: callback(span.decode(), bool(begin)))
+        self._check(self.lib.jxlgpu_set_trace(self.handle, C.cast(self._trace, C.c_void_p), None))
+
     def close(self):
         if self.handle:
             self.lib.jxlgpu_destroy(self.handle)

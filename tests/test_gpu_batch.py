@@ -98,3 +98,43 @@ def test_batch_with_non_default_post_pipelines(gpu_ctx, oracle):
     finally:
         for f in frames:
             f.free()
+
+
+def test_trace_hook_reports_the_references_spans(gpu_ctx, oracle):
+    """jxlgpu_set_trace (ABI 24): every launch group is bracketed, on the calling thread, by begin / end callbacks that carry the
+    span name the reference wraps the same work in (vardct/mod.rs:164, :316, filter/epf.rs:21, modular.rs:134) — balanced, in
+    call order, and without changing a bit of the result."""
+    from jxl_oxide_amd.synth_modular import ModularWorkload
+    events = []
+    gpu_ctx.set_trace(lambda span, begin: events.append((span, begin)))
+    try:
+        wl = VardctWorkload(264, 200, seed=5)
+        f = gpu_ctx.vardct_upload(wl.desc())
+        got = gpu_ctx.vardct_render(f, abi.STAGE_ALL)
+        f.free()
+        exp, _ = oracle.vardct_render(wl.desc(), abi.STAGE_ALL, wl.width, wl.height)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+        assert events == [("Load LF groups", True), ("Load LF groups", False), ("Dequant and transform", True),
+                          ("Dequant and transform", False), ("Edge-preserving filter", True), ("Edge-preserving filter", False)]
+        del events[:]
+        frames = [gpu_ctx.vardct_upload(wl.desc(coeff_transport="grouped")) for _ in range(3)]
+        gpu_ctx.vardct_render_batch(frames, abi.STAGE_ALL)
+        gpu_ctx.synchronize()
+        for fr in frames:
+            fr.free()
+        names = [s for s, b in events if b]
+        assert names == ["Load LF groups", "Dequant and transform", "Edge-preserving filter"]
+        assert sum(1 if b else -1 for _, b in events) == 0
+        del events[:]
+        ml = ModularWorkload(200, 136, kind="squeeze", lossy=True, i16=True, epf_iters=2, seed=3)
+        fm = gpu_ctx.modular_upload(ml.desc())
+        gpu_ctx.modular_render(fm, abi.STAGE_ALL | abi.STAGE_MODULAR_TO_FLOAT)
+        fm.free()
+        assert ("Inverse Modular transform", True) in events and sum(1 if b else -1 for _, b in events) == 0
+    finally:
+        gpu_ctx.set_trace(None)
+    n = len(events)
+    f = gpu_ctx.vardct_upload(wl.desc())
+    gpu_ctx.vardct_render(f, abi.STAGE_ALL)
+    f.free()
+    assert len(events) == n, "the hook is off"

@@ -63,6 +63,15 @@ def parse(src):
                 name = item
             enums.append((name, val))
             val += 1
+    # typedef RET (*NAME)(ARGS);  -> (NAME, RET, [(type, name)])
+    fnptrs = []
+    for ret, name, args in re.findall(r"typedef\s+([\w \*]+?)\s*\(\s*\*\s*(\w+)\s*\)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ps = []
+        for a in [x.strip() for x in " ".join(args.split()).split(",")]:
+            m = re.match(r"^(.*?[\w\*])\s*\b(\w+)$", a)
+            ps.append((m.group(1), m.group(2)))
+        fnptrs.append((name, ret.strip(), ps))
+    src = re.sub(r"typedef\s+[\w \*]+?\s*\(\s*\*\s*\w+\s*\)\s*\([^;{]*?\)\s*;", "", src, flags=re.S)
     opaque = re.findall(r"typedef\s+struct\s+(\w+)\s+\1\s*;", src)
     structs = []
     for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
@@ -91,7 +100,7 @@ def parse(src):
                     ctype = ctype + "*" if not ctype.rstrip().endswith("const") else ctype + "*"
                 params.append((ctype, pname))
         funcs.append((ret.strip(), name, params))
-    return consts, enums, opaque, structs, funcs
+    return consts, enums, opaque, structs, funcs, fnptrs
 
 
 def const_value(name, consts, enums):
@@ -125,7 +134,7 @@ def layout(structs, consts, enums):
 
 
 def generate():
-    consts, enums, opaque, structs, funcs = parse(open(HEADER).read())
+    consts, enums, opaque, structs, funcs, fnptrs = parse(open(HEADER).read())
     names = {s[0] for s in structs}
     out = []
     out.append("// GENERATED by tools/gen_rust_bindings.py from include/jxlgpu.h — do not edit.")
@@ -144,6 +153,11 @@ def generate():
     out.append("")
     for o in opaque:
         out.append(f"#[repr(C)] pub struct {o} {{ _private: [u8; 0] }}")
+    out.append("")
+    for name, ret, ps in fnptrs:   # C function-pointer typedefs: nullable in C, Option<..> in Rust
+        args = ", ".join(f"{p}: {rust_type(t, names)}" for t, p in ps)
+        r = "" if ret == "void" else f" -> {rust_type(ret, names)}"
+        out.append(f'pub type {name} = Option<unsafe extern "C" fn({args}){r}>;')
     out.append("")
     sizes = layout(structs, consts, enums)
     for name, fields in structs:
