@@ -150,7 +150,11 @@ def main():
         band_sharded = args.config == 5 and world > 1
         mine = list(range(n_total)) if band_sharded else list(shard.frame_shard(n_total, rank, world))
         wls = {d: job["make"](d) for d in sorted({i % args.distinct for i in mine})}  # untimed
-        frames = [job["upload"](ctx, wls[i % args.distinct]) for i in mine]            # own device copy each; untimed
+        # a job may ask for frames to alternate between several contexts (config 3 with JXLGPU_BENCH_CONTEXTS > 1, an experiment: each context
+        # has its own streams, so consecutive frames overlap; the reference's caller pattern of one renderer per thread,
+        # jxl-oxide-cli/src/decode.rs:293-304, driven from this one thread because every call is asynchronous)
+        ctxs = [ctx] + [runtime.Context(local_rank) for _ in range(max(1, int(job.get("contexts", 1))) - 1)]
+        frames = [job["upload"](ctxs[k % len(ctxs)], wls[i % args.distinct]) for k, i in enumerate(mine)]   # own device copy each; untimed
         mp_per_frame = job["out_w"] * job["out_h"] / 1e6
 
         passes = args.passes if args.passes else (8 if args.config == 2 else 1)
@@ -203,7 +207,8 @@ def main():
                     gstep[0] += 1
 
         def barrier():
-            ctx.synchronize()
+            for c in ctxs:
+                c.synchronize()
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -446,6 +451,7 @@ def main():
                                  "frames across ranks (shard.frame_shard), no data-path collective; the u8 output gathered to rank 0"),
                     "input": job.get("input", "decoded state resident in HBM"),
                     "launches": "jxlgpu_vardct_render_batch: one launch per stage for <= 32 frames" if job["batched"] else "one frame at a time",
+                    "contexts": len(ctxs),
                 },
                 "roofline": roofline,
                 "roofline_isolated": roofline_isolated,
@@ -462,7 +468,10 @@ def main():
             gather.close()   # collective: unmaps on the writers, frees on rank 0
         for f in frames:
             f.free()
-        ctx.synchronize()
+        for c in ctxs:
+            c.synchronize()
+        for c in ctxs[1:]:
+            c.close()
         if out is not None:
             print(json.dumps(out), flush=True)
 
@@ -598,22 +607,27 @@ def make_job(config, distinct, transport="grouped", nz=0.15):
         from oracle import pyoracle
         d, wl = next(iter(wls.items()))
         f = frames[[i % distinct for i in mine].index(d)]
-        got = ctx.modular_render(f, stages)
+        got = f.ctx.modular_render(f, stages)
         exp = pyoracle.modular_render(wl.desc(), stages, wl.width, wl.height)
         return {"ok": bool(np.array_equal(got.view(np.uint32), exp.view(np.uint32))), "frames_checked": 1,
                 "against": "oracle/, whole 7680x4320 frame (integer Squeeze inverse + float tail)"}
 
     def render(ctx, frames):
-        for f in frames:
-            ctx.modular_render(f, stages, to_host=False)
+        for f in frames:   # (frames alternate between two contexts: `contexts` below)
+            f.ctx.modular_render(f, stages, to_host=False)
 
     return {
         "metric": "Megapixels/sec decoded (8K Modular Squeeze lossy)", "dtype": "int16", "batched": False,
         "workload": "7680x4320 Modular, lossy Squeeze (22 steps) + self-correcting-predictor residuals (single-leaf MA tree) on the 67 carved "
-                    "sub-channels, 16-bit buffers, XYB dequant + EPF iters 2 (sigma_for_modular) + XYB->sRGB (BASELINE config 3)",
+                    "sub-channels, 16-bit buffers, XYB dequant + EPF iters 2 (sigma_for_modular) + XYB->sRGB (BASELINE config 3); whole frames, "
+                    "one render call each, one after the other",
         "out_w": W8K, "out_h": H8K,
         "make": lambda d: ModularWorkload(W8K, H8K, kind="squeeze", lossy=True, i16=True, epf_iters=2, seed=3 + d, residual=6),
         "upload": lambda ctx, wl: ctx.modular_upload(wl.desc()),
+        # JXLGPU_BENCH_CONTEXTS=2 / 3: frames alternate between that many contexts (own streams each), so that the predictor pass of one frame
+        # overlaps the Squeeze / filter launches of another.  Measured (round 6, 8 frames per step): 14.0-14.1 / 15.7 against 15.2-15.3 GP/s
+        # with one context — the predictor's serial chains stretch by what the other frame's launches issue: not the default
+        "contexts": int(os.environ.get("JXLGPU_BENCH_CONTEXTS", "1")),
         "render": render, "groups": (3, 2),
         "group_names": {3: "modular: predict_kernel (per carved sub-channel) + inverse Squeeze (segment-parallel kernels)", 2: "post: to_float + EPF + XYB->sRGB"},
         "alg_bytes": lambda f, g: W8K * H8K * (6 + 12),  # 3 x i16 in + 3 x f32 out per pixel
