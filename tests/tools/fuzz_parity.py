@@ -62,11 +62,44 @@ def modular_case(rng):
         kw["group_dim"] = int(rng.choice([128, 512, 1024, 1024]))
         if kw["group_dim"] == 1024 and rng.random() < 0.5:
             w, h = int(rng.integers(513, 2300)), int(rng.integers(300, 1300))
+    # round 6: per-unit leaves (a leaf of its own per decode unit; "axis": trees that split on y / x inside the unit) and
+    # Squeeze chains that squeeze residual channels again
+    if kind in ("squeeze", "palette") and "residual" not in kw and rng.random() < 0.35:
+        kw["leaves"] = str(rng.choice(["mixed", "axis", "axis"]))
+        if kind == "squeeze":
+            kw["lossy"], kw["xyb"] = False, False
+    if kind == "squeeze" and not kw.get("lossy", True) and w >= 40 and h >= 40 and rng.random() < 0.5:
+        kw["squeeze_plan"] = RESQUEEZE_PLANS[int(rng.integers(0, len(RESQUEEZE_PLANS)))]
+    return w, h, kw
+
+
+RESQUEEZE_PLANS = [
+    [[(1, 1, 0, 3), (0, 1, 0, 3), (1, 1, 0, 3), (0, 1, 9, 3), (1, 1, 9, 3), (0, 1, 0, 3)]],
+    [[(1, 1, 0, 3), (0, 1, 0, 3)], None],
+    [[(1, 0, 1, 2), (0, 0, 1, 2), (1, 1, 0, 7), (0, 1, 0, 7), (1, 1, 3, 4)]],
+    [None, [(0, 1, 3, 2), (1, 1, 3, 2)]],
+]
+
+
+def predictor_case(rng):
+    """Plain RGB8 planes behind one predictor pass: whole-channel and 256 x 256 units, every leaf kind."""
+    w = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 1100)]))
+    h = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 700)]))
+    kw = dict(kind="predictor", i16=bool(rng.integers(0, 2)), seed=int(rng.integers(0, 1000)))
+    r = rng.random()
+    if r < 0.6:
+        kw["leaves"] = str(rng.choice(["mixed", "axis", "axis"]))
+    else:
+        kw["predictor"] = int(rng.integers(0, 14))
+        # (the generator's weighted-predictor forward has no leaf offset)
+        kw["pred_offset"] = 0 if kw["predictor"] == 6 else int(rng.choice([0, 0, -3, 7]))
+    if rng.random() < 0.3:
+        kw["group_dim"] = int(rng.choice([128, 512, 1024]))
     return w, h, kw
 
 
 def run_modular(ctx, rng):
-    w, h, kw = modular_case(rng)
+    w, h, kw = predictor_case(rng) if rng.random() < 0.15 else modular_case(rng)
     wl = ModularWorkload(w, h, **kw)
     d = wl.desc()
     if kw["kind"].startswith("ycbcr"):
@@ -140,6 +173,30 @@ def run_vardct(ctx, rng):
     return ok and ok_r, ("vardct", w, h, dict(kw, transport=transport, passes=shifts, partial=partial, region=(rx, ry, rw, rh), full_ok=bool(ok)))
 
 
+def run_batch(ctx, rng):
+    """A batched render of two to six frames of unrelated sizes and filter settings (the streaming post kernel, its
+    border-ring launches and the list-fed transform families across frame boundaries), twice back to back."""
+    n = int(rng.integers(2, 7))
+    wls, params = [], []
+    for _ in range(n):
+        w, h = int(rng.integers(8, 900)), int(rng.integers(8, 600))
+        kw = dict(seed=int(rng.integers(0, 1000)), epf_iters=int(rng.integers(0, 4)), gabor=bool(rng.integers(0, 2)),
+                  nz_fraction=float(rng.choice([0.02, 0.15, 0.5])))
+        wls.append(VardctWorkload(w, h, **kw))
+        params.append((w, h, kw))
+    exp = [pyoracle.vardct_render(wl.desc(), abi.STAGE_ALL, wl.width, wl.height)[0] for wl in wls]
+    frames = [ctx.vardct_upload(wl.desc(coeff_transport="grouped")) for wl in wls]
+    try:
+        for _ in range(2):
+            ctx.vardct_render_batch(frames, abi.STAGE_ALL)
+        ctx.synchronize()
+        oks = [same_bits(ctx.download_result(f), e) for f, e in zip(frames, exp)]
+    finally:
+        for f in frames:
+            f.free()
+    return all(oks), ("batch", n, 0, dict(frames=params, ok=oks))
+
+
 def run_extra(ctx, rng):
     """An extra channel of random size, bit depth, sample type and upsampling shift on a small rendered frame."""
     wl = VardctWorkload(64, 40, seed=int(rng.integers(0, 1000)))
@@ -168,10 +225,10 @@ def main():
     print("CANARY", runtime.gpu_canary())
     ctx = runtime.Context(0)
     t_end = time.time() + seconds
-    n, bad = {"modular": 0, "vardct": 0, "extra": 0}, []
+    n, bad = {"modular": 0, "vardct": 0, "batch": 0, "extra": 0}, []
     while time.time() < t_end:
         r = rng.random()
-        fn = run_modular if r < 0.55 else (run_vardct if r < 0.9 else run_extra)
+        fn = run_modular if r < 0.5 else (run_vardct if r < 0.8 else (run_batch if r < 0.92 else run_extra))
         try:
             ok, what = fn(ctx, rng)
         except runtime.JxlGpuError as e:
