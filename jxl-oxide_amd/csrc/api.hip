@@ -581,6 +581,7 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     ctx->tune.pred_wg = getenv("JXLGPU_PRED_WG") != nullptr;
     if (const char* v = getenv("JXLGPU_PRED_PRIO")) ctx->tune.pred_prio = atoi(v) != 0;
     ctx->tune.pred_wide = getenv("JXLGPU_PRED_WIDE") != nullptr;
+    if (const char* v = getenv("JXLGPU_PRED_STEP_V1")) ctx->tune.pred_step_v1 = atoi(v) != 0;
     if (const char* v = getenv("JXLGPU_PRED_LATE_STEPS")) ctx->tune.pred_late_steps = std::max(0, atoi(v));
     ctx->tune.sqz_h_rows = getenv("JXLGPU_SQZ_H_ROWS") != nullptr;
     if (const char* v = getenv("JXLGPU_UP2_VARIANT")) ctx->tune.up2_variant = atoi(v);

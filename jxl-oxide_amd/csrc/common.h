@@ -268,6 +268,7 @@ struct Tuning {
     uint32_t sqz_runin = 1;      // JXLGPU_SQZ_RUNIN: 0 forces the Squeeze fix-up path (tests)
     bool sqz_h_rows = false;     // JXLGPU_SQZ_H_ROWS: horizontal Squeeze steps through the lane-per-row segment kernel
     bool pred_wide = false;      // JXLGPU_PRED_WIDE: the self-correcting predictor in 64-bit arithmetic only
+    bool pred_step_v1 = false;   // JXLGPU_PRED_STEP_V1=1: the round-3 step (x-indexed error rows, position-indexed rings) also where every wave has D = 4
     int pred_late_steps = 3;     // JXLGPU_PRED_LATE_STEPS: residuals of the first so many (forward) Squeeze steps get their predictor waves on a
                                  // side stream, beside the deep Squeeze levels; the inverse step that reads them waits (0: everything in front)
     bool pred_prio = false;      // JXLGPU_PRED_PRIO=1 (round 6, measured, not adopted): issue priority by chain length in the narrow predictor kernel

@@ -1669,6 +1669,268 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
     }
 }
 
+// ---- the same pass for launches in which every wave has D = 4 (every subgrid at most 256 columns wide: all of a frame with
+// 256 x 256 groups), round 6.  One wave per SIMD issues at most one instruction per ~5 cycles (tools/valu_cost_probe.hip) and a
+// wave is one serial chain, so the pass lasts (instructions per step) x (steps of the longest wave): the step above is 185 VALU
+// + 25 LDS instructions.  This form computes the same numbers with ~40 % fewer of them:
+//  * no address arithmetic in the step.  A lane's rings are indexed by the STEP (s & 15), not by its stream position: the value
+//    lane k needs from the row above (stream position u + 1 of lane k - 1, or of lane P - 1 one round earlier for lane 0) was
+//    written at step s + 1 - D whatever k is, the one two rows up at s - 2 D; with the step loop unrolled by the ring length
+//    every slot is an immediate offset on a per-lane base register;
+//  * the self-correcting predictor's error rows (`true_err_row` / `subpred_err_row`, predictor.rs:176-190) are a hand-over from
+//    row r - 1 to row r two columns behind it, like the samples: four-slot rings per lane (one ds_write_b128 + ds_write_b32 per
+//    step, one ds_read_b128 + ds_read_b32) instead of five x-indexed rows; row 0 reads a ring of zeros;
+//  * everything read from LDS that does not depend on the step's arithmetic is requested one step ahead (no wait at the top);
+//  * the state update is unconditional (an off-grid lane computes garbage that the next row start overwrites; only the global
+//    store and the range flag look at `on`): the register rotation is a renaming, not v_movs under an exec mask;
+//  * arithmetic: `ww[i] * DIV_LOOKUP[j]` is a table of its own; shift = max(0, 26 - clz(err_sum + 1)) (one saturating
+//    subtraction for the reference's `(err_sum + 1) >> 5` / floor(log2) pair, predictor.rs:372-380); samples are carried as
+//    8 s + 2^23, which makes every sub-predictor a non-negative 24-bit number: |subpred - 8 s| is one v_sad_u32 and the
+//    weighted sum four v_mad_u32_u24, the bias leaves again through - (sum_weights << 23); the clamp is one v_med3_i32.
+// Range guard and redo pass as above.
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {   // low 24 bits of a, b
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ int32_t med3_i32(int32_t a, int32_t b, int32_t c) {
+    int32_t d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+template <typename S, bool VEC>
+__global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const PredWave* waves, const PredSrc* srcs,
+                                                               uint32_t* wave_flags) {
+    constexpr int RO = kRing, E = 4;
+    constexpr int32_t B = 1 << 23;
+    static_assert(RO == 16, "the step loop is unrolled by the ring length");
+    using R = typename std::conditional<sizeof(S) == 2, int16_t, int32_t>::type;
+    typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+    __shared__ uint32_t s_wdiv[4][66];          // ww[i] * DIV_LOOKUP[j]
+    __shared__ uint32_t s_div[65];
+    __shared__ R s_out[64][RO + 1];             // finished samples of the lane's rows, slot = step & 15
+    __shared__ R s_in[64][kRing + 1];           // residuals requested ahead, slot = step & 15
+    __shared__ U4 s_se[65][E + 1];              // sub_err[4] of the lane's last four samples, slot = step & 3 (+1: bank spread); [64] = zeros
+    __shared__ int32_t s_te[65][E + 1];         // true_err likewise
+    const PredWave wv = waves[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t log2p = wv.log2p, log2dp = wv.log2dp, P = 1u << log2p, DPm1 = (1u << log2dp) - 1u;
+    const uint32_t slot = lane >> log2p, k = lane & (P - 1);
+    const bool have_tile = slot < wv.count;
+    const PredTile t = a.tiles[wv.first + (have_tile ? slot : 0)];
+    const GlobalPtr<const S> src = as_global((const S*)srcs[wv.first + (have_tile ? slot : 0)].src);
+    const int32_t gw = have_tile ? (int32_t)t.gw : 0;
+    const uint32_t gh = have_tile ? t.gh : 0;
+    s_div[lane] = div_lookup_dev(lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_wdiv[i][lane] = (uint32_t)a.wp[7 + i] * div_lookup_dev(lane);
+    if (lane == 0) {
+        s_div[64] = div_lookup_dev(64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_wdiv[i][64] = (uint32_t)a.wp[7 + i] * div_lookup_dev(64);
+        wave_flags[blockIdx.x] = 0;
+    }
+    for (uint32_t i = lane; i < 65 * (E + 1); i += 64) {
+        (&s_se[0][0])[i] = U4{0, 0, 0, 0};
+        (&s_te[0][0])[i] = 0;
+    }
+    __syncthreads();
+    const uint32_t lane0 = lane & ~(P - 1);
+    const R* my_out = s_out[lane];
+    R* my_out_w = s_out[lane];
+    R* my_in = s_in[lane];
+    const R* prev = s_out[lane0 + ((k + P - 1) & (P - 1))];
+    const R* prev2 = s_out[lane0 + ((k + 2 * P - 2) & (P - 1))];
+    const U4* prev_se = s_se[lane0 + ((k + P - 1) & (P - 1))];
+    const int32_t* prev_te = s_te[lane0 + ((k + P - 1) & (P - 1))];
+    (void)my_out;
+    const U4* pse = s_se[64];        // the ring row r reads its NE errors from: the previous lane's, or the zeros (row 0)
+    const int32_t* pte = s_te[64];
+    const int32_t wp0 = a.wp[0], wp1 = a.wp[1], wp2 = a.wp[2], wp3 = a.wp[3], wp4 = a.wp[4], wp5 = a.wp[5], wp6 = a.wp[6];
+    const int32_t offb = t.off;      // (the bias leaves the prediction as B / 8 = 2^20: see `value` below)
+
+    int32_t w3b = B, n3b = B, nw3b = B;                      // 8 * sample + B of W, N, NW
+    int32_t te_w = 0, te_nw = 0, te_n = 0, te_ne = 0;
+    uint32_t se_nw_ww[4] = {0, 0, 0, 0}, se_n_w[4] = {0, 0, 0, 0}, se_ne[4] = {0, 0, 0, 0};
+    bool r0 = true, r_ge2 = false, row_ok = false;
+    GlobalPtr<S> row_base = as_global((S*)a.sink);
+    // requested one step ahead
+    int32_t nx_res = 0, nx_pne = 0, nx_pnn = 0, nx_te = 0;
+    U4 nx_se = U4{0, 0, 0, 0};
+    int32_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    typedef uint32_t RawV2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t RawV4 __attribute__((ext_vector_type(4)));
+    using V4 = typename std::conditional<sizeof(S) == 2, RawV2, RawV4>::type;
+    union Pack4 { V4 v; S s[4]; };
+    Pack4 pfv[2], sbuf;
+    pfv[0].v = pfv[1].v = V4{};
+    sbuf.v = V4{};
+    const int32_t steps = (int32_t)wv.steps;
+    const int32_t u0 = -4 * (int32_t)k;
+    auto where = [&](int32_t q, uint32_t* r, uint32_t* x) -> bool {
+        *r = k + (((uint32_t)q >> log2dp) << log2p);
+        *x = (uint32_t)q & DPm1;
+        return q >= 0 && *r < gh && (int32_t)*x < gw;
+    };
+    for (int32_t s0 = -16; s0 < steps; s0 += 16) {
+        bool out_of_range = false;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int32_t u = u0 + s0 + j;
+            // ---- residual pipeline (global memory): park what arrived for the step 8 ahead, request the one 16 ahead; always issued
+            if constexpr (VEC) {
+                if ((j & 3) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) my_in[(j + 8 + i) & 15] = (R)pfv[(j >> 2) & 1].s[i];
+                    uint32_t rq, xq;
+                    const bool ahead = where(u + 16, &rq, &xq);
+                    pfv[(j >> 2) & 1].v = *reinterpret_cast<GlobalPtr<const V4>>(src + (ahead ? (size_t)rq * t.stride + xq : (size_t)0));
+                }
+            } else {
+                uint32_t rq, xq;
+                my_in[(j + 8) & 15] = (R)pf[j & 7];
+                const bool ahead = where(u + 16, &rq, &xq);
+                pf[j & 7] = (int32_t)src[ahead ? (size_t)rq * t.stride + xq : (size_t)0];
+            }
+            const int32_t x = (int32_t)((uint32_t)u & DPm1);
+            // what this step was sent ahead
+            const int32_t res = nx_res, p_ne = nx_pne, p_nn = nx_pnn;
+            int32_t l_te = nx_te;
+            U4 l_se = nx_se;
+            if (x == 0) {
+                // a row starts (also for positions before the lane's first row: row_ok stays false)
+                const uint32_t r = k + (((uint32_t)u >> log2dp) << log2p);
+                row_ok = u >= 0 && r < gh;
+                r0 = r == 0;
+                r_ge2 = r >= 2;
+                row_base = row_ok ? as_global((S*)t.base + (size_t)r * t.stride) : as_global((S*)a.sink);
+                if (r0) {
+                    w3b = n3b = nw3b = B;
+                    te_w = te_n = te_nw = te_ne = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) se_n_w[i] = se_nw_ww[i] = se_ne[i] = 0;
+                    l_te = 0;
+                    l_se = U4{0, 0, 0, 0};
+                    pse = s_se[64];
+                    pte = s_te[64];
+                } else {
+                    // columns 0, 1 and 2 of the row above: written by the previous lane at steps s - 4, s - 3, s - 2
+                    const int32_t c0 = prev[(j + 12) & 15];
+                    w3b = n3b = nw3b = c0 * 8 + B;
+                    te_w = 0;
+                    te_n = te_nw = prev_te[(j + 0) & 3];
+                    const U4 e0 = prev_se[(j + 0) & 3];
+                    const U4 e1v = prev_se[(j + 1) & 3];
+                    const int32_t t1 = prev_te[(j + 1) & 3];
+                    const bool one = gw <= 1;
+                    te_ne = one ? te_n : t1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        se_n_w[i] = se_nw_ww[i] = e0[i];
+                        se_ne[i] = one ? e0[i] : e1v[i];
+                    }
+                    l_te = prev_te[(j + 2) & 3];
+                    l_se = prev_se[(j + 2) & 3];
+                    pse = prev_se;
+                    pte = prev_te;
+                }
+            }
+            // ---- requests for step s + 1 (NE sample: written at s - 2; NN: at s - 7; errors two columns ahead of it: at s - 1)
+            nx_res = my_in[(j + 1) & 15];
+            nx_pne = prev[(j + 14) & 15];
+            nx_pnn = prev2[(j + 9) & 15];
+            nx_te = pte[(j + 3) & 3];
+            nx_se = pse[(j + 3) & 3];
+
+            const bool on = row_ok && x < gw;
+            const int32_t pne3b = p_ne * 8 + B;
+            const int32_t ne3b = (r0 || x + 1 >= gw) ? n3b : pne3b;
+            const int32_t nn3b = r_ge2 ? p_nn * 8 + B : n3b;
+            uint32_t sp[4];   // sub-predictors + B
+            sp[0] = (uint32_t)(w3b + ne3b - n3b);
+            sp[1] = (uint32_t)(n3b - (((te_w + te_n + te_ne) * wp0) >> 5));
+            sp[2] = (uint32_t)(w3b - (((te_w + te_n + te_nw) * wp1) >> 5));
+            sp[3] = (uint32_t)(n3b - ((te_nw * wp2 + te_n * wp3 + te_ne * wp4 + (nn3b - n3b) * wp5 + (nw3b - w3b) * wp6) >> 5));
+            uint32_t weight[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t err_sum = se_nw_ww[i] + se_n_w[i] + se_ne[i];
+                const uint32_t shift = __builtin_elementwise_sub_sat(26u, (uint32_t)__builtin_clz(err_sum + 1u));
+                weight[i] = 4u + (s_wdiv[i][(err_sum >> shift) + 1] >> shift);
+            }
+            uint32_t sum_weights = weight[0] + weight[1] + weight[2] + weight[3];
+            const uint32_t log_weight = 27u - (uint32_t)__builtin_clz(sum_weights);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) weight[i] >>= log_weight;
+            sum_weights = weight[0] + weight[1] + weight[2] + weight[3];
+            const uint32_t dv = s_div[sum_weights];
+            uint32_t accb = (sum_weights >> 1) - (sum_weights << 23) - 1u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accb = mad_u24(sp[i], weight[i], accb);
+            const int32_t acc = (int32_t)accb;
+            int32_t predb = (int32_t)(((int64_t)acc * (int64_t)(int32_t)dv) >> 24) + B;
+            if (((te_n ^ te_w) | (te_n ^ te_nw)) <= 0) {
+                const int32_t mn = min(min(n3b, w3b), ne3b), mx = max(max(n3b, w3b), ne3b);
+                predb = med3_i32(predb, mn, mx);
+            }
+            // (prediction + 3) >> 3 carries B / 8 = 2^20 with it: nothing, for 16-bit samples; taken off for 32-bit ones
+            int32_t pred = (predb + 3) >> 3;
+            if constexpr (sizeof(S) == 4) pred -= B / 8;
+            const S diff = Wrap<S>::add(Wrap<S>::mul((S)res, (S)t.mul), (S)offb);
+            const S value = Wrap<S>::add(diff, (S)pred);
+            const int32_t sample = (int32_t)value;
+            my_out_w[j & 15] = (R)sample;
+            const int32_t s8b = sample * 8 + B;
+            const int32_t true_err = predb - s8b;
+            out_of_range |= on && ((uint32_t)true_err + (1u << 19) >= (1u << 20) || (uint32_t)sample + (1u << 17) >= (1u << 18));
+            U4 sub_err;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sub_err[i] = sad_u32(sp[i], (uint32_t)s8b, 3u) >> 3;
+            s_te[lane][j & 3] = true_err;
+            s_se[lane][j & 3] = sub_err;
+            // SelfCorrectingPredictor::record + Properties::record (unconditional: see above)
+            const bool last2 = x + 2 >= gw;
+            te_w = true_err;
+            te_nw = te_n;
+            te_n = te_ne;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                se_nw_ww[i] = se_n_w[i];
+                se_n_w[i] = se_ne[i] + sub_err[i];
+            }
+            te_ne = last2 ? te_n : l_te;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) se_ne[i] = last2 ? se_n_w[i] : l_se[i];
+            w3b = s8b;
+            nw3b = r0 ? s8b : n3b;
+            n3b = r0 ? s8b : pne3b;
+
+            if constexpr (VEC) {
+                sbuf.s[j & 3] = value;
+                if ((j & 3) == 3) {
+                    // columns x - 3 .. x of one row (or the sink: a lane is on the grid for all four steps of a group or none)
+                    const GlobalPtr<S> g4 = on ? row_base + (x - 3) : as_global((S*)a.sink + lane * 4);
+                    *reinterpret_cast<GlobalPtr<V4>>(g4) = sbuf.v;
+                }
+            } else {
+                const GlobalPtr<S> g1 = on ? row_base + x : as_global((S*)a.sink + lane * 4 + 3);
+                *g1 = value;
+            }
+            lds_step_boundary();
+        }
+        if (__builtin_amdgcn_ballot_w64(out_of_range) != 0) {
+            if (lane == 0) wave_flags[blockIdx.x] = 1;
+            return;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- device: M3, delta-palette predictor pass
 // The predictor pass of Palette::inverse_inner (palette.rs:112-142): ONE PredictorState over the
 // whole channel, so the wavefront spans the image: workgroup b owns rows [256 b, 256 b + 256), lane r
@@ -1959,6 +2221,9 @@ struct Grid {
     int hshift = 0, vshift = 0;
     uint32_t orig_w = 0, orig_h = 0;
     int fwd_step = -1;       // residual rectangle: the (forward) Squeeze step that produced it — step 0's are the largest and the last to be consumed
+    // inverse Squeeze: the chain (SqueezePlan::epoch, workgroup) of small levels the step that last wrote this rectangle may be queued in
+    uint32_t chain_epoch = 0;
+    int chain_slot = -1;
 };
 
 struct ModularState {
@@ -2001,6 +2266,7 @@ struct ModularState {
     std::vector<JxlGpuMaLeaf> unit_leaves;   // copy of JxlGpuModularDesc::unit_leaves (empty: the frame's one leaf)
     std::vector<JxlGpuMaLeaf> axis_leaves;   // copy of JxlGpuModularDesc::axis_leaves (per-row / per-column leaves of the units marked BY_ROW / BY_COLUMN)
     JxlGpuMaLeaf* d_axis_leaves = nullptr;   // ... on the device
+    bool pred_d4 = false;         // every wave of the lane-packed pass has D = 4 (no subgrid wider than 256 columns): predict_lanes_wp4_kernel
     bool pred_big_ring = false;   // a subgrid wider than 512 columns: rows trail by D = 16, the lane kernels with the 64-column sample ring
     float* fpix[3] = {};
 };
@@ -2042,6 +2308,7 @@ int fail(jxlgpu_ctx* ctx, int code, const char* msg) {
 struct SqueezePlan {
     ChainArgs chain;
     bool chain_used = false;
+    uint32_t epoch = 1;   // counts the flushes: a rectangle written in an earlier epoch is in memory for everything queued now
 };
 
 template <typename S>
@@ -2050,6 +2317,7 @@ void flush_chain(hipStream_t s, SqueezePlan& plan) {
     squeeze_chain_kernel<S><<<3, 1024, 0, s>>>(plan.chain);
     memset(&plan.chain, 0, sizeof(plan.chain));
     plan.chain_used = false;
+    ++plan.epoch;
 }
 
 template <typename S>
@@ -2339,6 +2607,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             while (n_wide < tiles.size() && !tiles[n_wide].packed) ++n_wide;
             std::vector<PredWave> waves;
             uint32_t lane_err_w = 256;
+            bool all_d4 = true;
             for (uint32_t i = n_wide; i < tiles.size();) {
                 const uint32_t P = lanes_of(tiles[i]), DP = dp_of(tiles[i]), T = 64 / P;
                 PredWave w{};
@@ -2350,6 +2619,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     w.steps = std::max(w.steps, steps_of(tiles[i]));
                     ++w.count; ++i;
                 }
+                all_d4 &= DP == 4 * P;
                 if (DP > 256) lane_err_w = std::max(lane_err_w, 512u);
                 if (DP > 512) { lane_err_w = 1024; m->pred_big_ring = true; }
                 waves.push_back(w);
@@ -2382,6 +2652,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             for (int k = 0; k < 11; ++k) wp_coded &= m->desc.wp_params[k] >= 0 && m->desc.wp_params[k] < (k < 7 ? 32 : 16);
             // (the 32-bit kernel is the self-correcting predictor only: every unit has to use it)
             m->pred_narrow = any_wp && all_wp && wp_coded && !ctx->tune.pred_wide && !waves.empty();
+            m->pred_d4 = all_d4 && !ctx->tune.pred_step_v1;
             std::vector<PredSrc> srcs(tiles.size());
             for (size_t i = 0; i < tiles.size(); ++i) srcs[i].src = tile_src[tiles[i].base];
             if (int rc = malloc_dev(ctx, f, &m->pred_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(PredTile))) return rc;
@@ -2460,6 +2731,12 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     auto narrow = [&](hipStream_t st, uint32_t first, uint32_t count, bool vec) {
                         if (!count) return;
                         auto go = [&](auto kern) { kern<<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first); };
+                        if (m->pred_d4) {   // static LDS only
+                            auto go4 = [&](auto kern) { kern<<<count, 64, 0, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first); };
+                            if (i16) { if (vec) go4(predict_lanes_wp4_kernel<int16_t, true>); else go4(predict_lanes_wp4_kernel<int16_t, false>); }
+                            else { if (vec) go4(predict_lanes_wp4_kernel<int32_t, true>); else go4(predict_lanes_wp4_kernel<int32_t, false>); }
+                            return;
+                        }
                         const int sel = (i16 ? 4 : 0) | (vec ? 2 : 0) | (m->pred_big_ring ? 1 : 0);
                         switch (sel) {
                             case 0: go(predict_lanes_narrow_kernel<int32_t, false, kRing>); break;
@@ -2571,6 +2848,20 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     const int nk = std::min(3, count - k0);
                     SqzArgs args[3];
                     int slot[3];
+                    // The three workgroups of the small-level launch run side by side: a step may only join workgroup c if
+                    // whatever wrote its inputs is in memory (an earlier epoch) or queued in c itself.  With default parameters
+                    // a channel keeps its index and residuals are never outputs, so this never fires; explicit steps that
+                    // squeeze residual channels again, or move a channel to another index, read across workgroups (found by
+                    // tests/tools/fuzz_parity.py in round 6: 73 x 50, `appended_then_squeezed`).
+                    bool crosses = false;
+                    for (int k = 0; k < nk; ++k) {
+                        const int c = (begin + k0 + k) % 3;
+                        const Grid& g = l[begin + k0 + k];
+                        const Grid& r = res[k0 + k];
+                        crosses |= g.chain_epoch == plan.epoch && g.chain_slot != c;
+                        crosses |= r.chain_epoch == plan.epoch && r.chain_slot != c;
+                    }
+                    if (crosses) { if (i16) flush_chain<int16_t>(s, plan); else flush_chain<int32_t>(s, plan); }
                     for (int k = 0; k < nk; ++k) {
                         Grid& g = l[begin + k0 + k];
                         const Grid& r = res[k0 + k];
@@ -2587,6 +2878,10 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                     }
                     if (i16) launch_squeeze_step<int16_t>(s, ctx->tune, st.horizontal, args, slot, nk, m->chk, m->chk_bytes, m->d_redo, plan);
                     else launch_squeeze_step<int32_t>(s, ctx->tune, st.horizontal, args, slot, nk, m->chk, m->chk_bytes, m->d_redo, plan);
+                    for (int k = 0; k < nk; ++k) {   // (conservative: also when the step was launched on its own)
+                        l[begin + k0 + k].chain_epoch = plan.epoch;
+                        l[begin + k0 + k].chain_slot = slot[k];
+                    }
                     if (ctx->tune.debug_sync) {
                         if (i16) flush_chain<int16_t>(s, plan); else flush_chain<int32_t>(s, plan);
                         hipError_t e = hipStreamSynchronize(s);

@@ -536,6 +536,24 @@ def test_resqueezed_residuals(gpu_ctx, oracle, plan, residual):
                 assert np.array_equal(got[c], wl.expected[c])
 
 
+@pytest.mark.parametrize("plan", ["explicit_steps_over_residuals", "two_squeeze_transforms", "appended_then_squeezed", "default_then_residuals"])
+@pytest.mark.parametrize("i16", [True, False])
+def test_resqueezed_residuals_small_levels(gpu_ctx, oracle, plan, i16):
+    """The same chains at sizes whose steps all go through the ONE launch for the small levels (squeeze_chain_kernel: three
+    workgroups side by side, a workgroup barrier between a workgroup's steps).  A step that squeezes a residual channel again, or
+    a channel that moved to another index, reads what ANOTHER workgroup's step wrote: the queue is flushed first (found by
+    tests/tools/fuzz_parity.py, seed 6001: 73 x 50 `appended_then_squeezed`, a race between workgroups)."""
+    from test_oracle_modular import RESQUEEZE_PLANS
+    plans = dict(RESQUEEZE_PLANS, default_then_residuals=[None, [(0, 1, 3, 2), (1, 1, 3, 2)]])
+    for size, seed, residual in (((73, 50), 953, 0), ((73, 50), 1, None), ((40, 41), 2, 5), ((130, 97), 3, 6), ((200, 160), 4, None)):
+        wl = ModularWorkload(size[0], size[1], kind="squeeze", lossy=False, xyb=False, seed=seed, residual=residual, i16=i16,
+                             squeeze_plan=plans[plan])
+        for _ in range(3):
+            got = _inverse_both(gpu_ctx, oracle, wl)
+            for c in range(3):
+                assert np.array_equal(got[c], wl.expected[c]), (size, plan, residual, c)
+
+
 def _axis_cases():
     from test_oracle_modular import AXIS_TREE_CASES
     return AXIS_TREE_CASES + [dict(width=1100, height=720, kind="squeeze", lossy=False, xyb=False, seed=46, i16=False),
