@@ -1704,6 +1704,17 @@ __device__ __forceinline__ int32_t med3_i32(int32_t a, int32_t b, int32_t c) {
     return d;
 }
 
+__device__ __forceinline__ int32_t mul_i24(int32_t a, int32_t b) {   // |a|, |b| < 2^23
+    int32_t d;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "s"(b), "v"(a));
+    return d;
+}
+__device__ __forceinline__ int32_t mad_i24(int32_t a, int32_t b, int32_t c) {
+    int32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+    return d;
+}
+
 template <typename S, bool VEC>
 __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const PredWave* waves, const PredSrc* srcs,
                                                                uint32_t* wave_flags) {
@@ -1780,6 +1791,7 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
     };
     for (int32_t s0 = -16; s0 < steps; s0 += 16) {
         bool out_of_range = false;
+        uint32_t worst = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int32_t u = u0 + s0 + j;
@@ -1803,7 +1815,8 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
             const int32_t res = nx_res, p_ne = nx_pne, p_nn = nx_pnn;
             int32_t l_te = nx_te;
             U4 l_se = nx_se;
-            if (x == 0) {
+            // a lane's column is congruent to the step modulo 4 (D = 4 and DP is a multiple of 4): rows start at every fourth step only
+            if ((j & 3) == 0 && x == 0) {
                 // a row starts (also for positions before the lane's first row: row_ok stays false)
                 const uint32_t r = k + (((uint32_t)u >> log2dp) << log2p);
                 row_ok = u >= 0 && r < gh;
@@ -1854,9 +1867,11 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
             const int32_t nn3b = r_ge2 ? p_nn * 8 + B : n3b;
             uint32_t sp[4];   // sub-predictors + B
             sp[0] = (uint32_t)(w3b + ne3b - n3b);
-            sp[1] = (uint32_t)(n3b - (((te_w + te_n + te_ne) * wp0) >> 5));
-            sp[2] = (uint32_t)(w3b - (((te_w + te_n + te_nw) * wp1) >> 5));
-            sp[3] = (uint32_t)(n3b - ((te_nw * wp2 + te_n * wp3 + te_ne * wp4 + (nn3b - n3b) * wp5 + (nw3b - w3b) * wp6) >> 5));
+            // (24-bit multiplies: |true_err| < 2^19, the sample differences < 2^21, the WpHeader factors < 32)
+            const int32_t te_wn = te_w + te_n;
+            sp[1] = (uint32_t)(n3b - (mul_i24(te_wn + te_ne, wp0) >> 5));
+            sp[2] = (uint32_t)(w3b - (mul_i24(te_wn + te_nw, wp1) >> 5));
+            sp[3] = (uint32_t)(n3b - (mad_i24(nw3b - w3b, wp6, mad_i24(nn3b - n3b, wp5, mad_i24(te_ne, wp4, mad_i24(te_n, wp3, mul_i24(te_nw, wp2))))) >> 5));
             uint32_t weight[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1875,9 +1890,10 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
             for (int i = 0; i < 4; ++i) accb = mad_u24(sp[i], weight[i], accb);
             const int32_t acc = (int32_t)accb;
             int32_t predb = (int32_t)(((int64_t)acc * (int64_t)(int32_t)dv) >> 24) + B;
-            if (((te_n ^ te_w) | (te_n ^ te_nw)) <= 0) {
+            {
                 const int32_t mn = min(min(n3b, w3b), ne3b), mx = max(max(n3b, w3b), ne3b);
-                predb = med3_i32(predb, mn, mx);
+                const int32_t clamped = med3_i32(predb, mn, mx);
+                predb = ((te_n ^ te_w) | (te_n ^ te_nw)) <= 0 ? clamped : predb;
             }
             // (prediction + 3) >> 3 carries B / 8 = 2^20 with it: nothing, for 16-bit samples; taken off for 32-bit ones
             int32_t pred = (predb + 3) >> 3;
@@ -1888,7 +1904,16 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
             my_out_w[j & 15] = (R)sample;
             const int32_t s8b = sample * 8 + B;
             const int32_t true_err = predb - s8b;
-            out_of_range |= on && ((uint32_t)true_err + (1u << 19) >= (1u << 20) || (uint32_t)sample + (1u << 17) >= (1u << 18));
+            // range guard: the largest excursion of the group of four steps, looked at where the group ends (VEC: a lane is on the grid for
+            // all four steps of a group or none); 16-bit samples cannot leave the sample range
+            uint32_t exc = (uint32_t)true_err + (1u << 19);
+            if constexpr (sizeof(S) == 4) exc = max(exc, ((uint32_t)sample + (1u << 17)) << 2);
+            if constexpr (VEC) {
+                worst = (j & 3) == 0 ? exc : max(worst, exc);
+                if ((j & 3) == 3) out_of_range |= on && worst >= (1u << 20);
+            } else {
+                out_of_range |= on && exc >= (1u << 20);
+            }
             U4 sub_err;
 #pragma unroll
             for (int i = 0; i < 4; ++i) sub_err[i] = sad_u32(sp[i], (uint32_t)s8b, 3u) >> 3;
