@@ -1717,7 +1717,7 @@ __device__ __forceinline__ int32_t mad_i24(int32_t a, int32_t b, int32_t c) {
 
 template <typename S, bool VEC>
 __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const PredWave* waves, const PredSrc* srcs,
-                                                               uint32_t* wave_flags) {
+                                                               uint32_t* wave_flags, uint32_t* queue, uint32_t n_items) {
     constexpr int RO = kRing, E = 4;
     constexpr int32_t B = 1 << 23;
     static_assert(RO == 16, "the step loop is unrolled by the ring length");
@@ -1729,15 +1729,7 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
     __shared__ R s_in[64][kRing + 1];           // residuals requested ahead, slot = step & 15
     __shared__ U4 s_se[65][E + 1];              // sub_err[4] of the lane's last four samples, slot = step & 3 (+1: bank spread); [64] = zeros
     __shared__ int32_t s_te[65][E + 1];         // true_err likewise
-    const PredWave wv = waves[blockIdx.x];
     const uint32_t lane = threadIdx.x;
-    const uint32_t log2p = wv.log2p, log2dp = wv.log2dp, P = 1u << log2p, DPm1 = (1u << log2dp) - 1u;
-    const uint32_t slot = lane >> log2p, k = lane & (P - 1);
-    const bool have_tile = slot < wv.count;
-    const PredTile t = a.tiles[wv.first + (have_tile ? slot : 0)];
-    const GlobalPtr<const S> src = as_global((const S*)srcs[wv.first + (have_tile ? slot : 0)].src);
-    const int32_t gw = have_tile ? (int32_t)t.gw : 0;
-    const uint32_t gh = have_tile ? t.gh : 0;
     s_div[lane] = div_lookup_dev(lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i) s_wdiv[i][lane] = (uint32_t)a.wp[7 + i] * div_lookup_dev(lane);
@@ -1745,13 +1737,37 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
         s_div[64] = div_lookup_dev(64);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s_wdiv[i][64] = (uint32_t)a.wp[7 + i] * div_lookup_dev(64);
-        wave_flags[blockIdx.x] = 0;
     }
     for (uint32_t i = lane; i < 65 * (E + 1); i += 64) {
         (&s_se[0][0])[i] = U4{0, 0, 0, 0};
         (&s_te[0][0])[i] = 0;
     }
     __syncthreads();
+    // `queue` non-null: the launch has fewer workgroups than waves (a fixed number per SIMD) and each takes the next wave of the
+    // list — longest first — when it has finished one: the chains of a frame differ by a factor of 60 in length, and the hardware's
+    // placement of one workgroup per wave leaves half of the SIMDs with twice the work of the others.  Nothing in LDS has to be
+    // reset between waves: whatever a valid lane reads was written earlier in the same wave (the ring of zeros is never written).
+    auto next_item = [&]() -> uint32_t {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(queue, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    for (uint32_t item = queue ? next_item() : blockIdx.x; item < n_items; item = queue ? next_item() : n_items) {
+    const PredWave wv = waves[item];
+    switch (__builtin_amdgcn_readfirstlane((int)wv.pad[1])) {   // JXLGPU_PRED_PRIO (see predict_lanes_narrow_kernel)
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        default: break;
+    }
+    const uint32_t log2p = wv.log2p, log2dp = wv.log2dp, P = 1u << log2p, DPm1 = (1u << log2dp) - 1u;
+    const uint32_t slot = lane >> log2p, k = lane & (P - 1);
+    const bool have_tile = slot < wv.count;
+    const PredTile t = a.tiles[wv.first + (have_tile ? slot : 0)];
+    const GlobalPtr<const S> src = as_global((const S*)srcs[wv.first + (have_tile ? slot : 0)].src);
+    const int32_t gw = have_tile ? (int32_t)t.gw : 0;
+    const uint32_t gh = have_tile ? t.gh : 0;
+    if (lane == 0) wave_flags[item] = 0;
     const uint32_t lane0 = lane & ~(P - 1);
     const R* my_out = s_out[lane];
     R* my_out_w = s_out[lane];
@@ -1950,10 +1966,12 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
             lds_step_boundary();
         }
         if (__builtin_amdgcn_ballot_w64(out_of_range) != 0) {
-            if (lane == 0) wave_flags[blockIdx.x] = 1;
-            return;
+            if (lane == 0) wave_flags[item] = 1;
+            break;
         }
     }
+    lds_step_boundary();
+    }   // next wave of the list
 }
 
 // ---------------------------------------------------------------- device: M3, delta-palette predictor pass
@@ -2291,6 +2309,7 @@ struct ModularState {
     std::vector<JxlGpuMaLeaf> unit_leaves;   // copy of JxlGpuModularDesc::unit_leaves (empty: the frame's one leaf)
     std::vector<JxlGpuMaLeaf> axis_leaves;   // copy of JxlGpuModularDesc::axis_leaves (per-row / per-column leaves of the units marked BY_ROW / BY_COLUMN)
     JxlGpuMaLeaf* d_axis_leaves = nullptr;   // ... on the device
+    uint32_t* pred_queue = nullptr;   // four counters: the wave queues of the (early / late) x (four-sample / one-sample) launches
     bool pred_d4 = false;         // every wave of the lane-packed pass has D = 4 (no subgrid wider than 256 columns): predict_lanes_wp4_kernel
     bool pred_big_ring = false;   // a subgrid wider than 512 columns: rows trail by D = 16, the lane kernels with the 64-column sample ring
     float* fpix[3] = {};
@@ -2655,6 +2674,19 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 if (x.vec != y.vec) return x.vec > y.vec;
                 return x.steps > y.steps;
             });
+            if (ctx->tune.pred_snake) {
+                // experiment (JXLGPU_PRED_SNAKE=N): inside a launch, every other run of N waves in ascending order — if workgroup i and
+                // workgroup i + N land on the same SIMD, the longest chain shares it with the shortest
+                const size_t N = (size_t)ctx->tune.pred_snake;
+                size_t b = 0;
+                while (b < waves.size()) {
+                    size_t e = b;
+                    while (e < waves.size() && waves[e].pad[0] == waves[b].pad[0] && waves[e].vec == waves[b].vec) ++e;
+                    for (size_t r = b + N, odd = 1; r < e; r += N, odd ^= 1)
+                        if (odd) std::reverse(waves.begin() + r, waves.begin() + std::min(e, r + N));
+                    b = e;
+                }
+            }
             {   // issue priority by chain length (predict_lanes_narrow_kernel): the longest quarter 3, then 2, 1, 0
                 uint32_t max_steps = 1;
                 for (const PredWave& w : waves) max_steps = std::max(max_steps, w.steps);
@@ -2670,6 +2702,11 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             m->n_pred_tiles = (uint32_t)tiles.size();
             m->n_pred_wide = n_wide;
             m->n_pred_waves = (uint32_t)waves.size();
+            if (getenv("JXLGPU_PRED_DUMP")) {   // diagnostics: the waves of the lane-packed pass in launch order
+                for (size_t i = 0; i < waves.size(); ++i)
+                    fprintf(stderr, "predwave %zu late=%u vec=%u P=%u DP=%u count=%u steps=%u gw=%u gh=%u\n", i, waves[i].pad[0], waves[i].vec,
+                            1u << waves[i].log2p, 1u << waves[i].log2dp, waves[i].count, waves[i].steps, tiles[waves[i].first].gw, tiles[waves[i].first].gh);
+            }
             m->pred_err_w = any_wp ? max_w : 1;
             m->pred_lane_err_w = any_wp ? lane_err_w : 64;
             // the 32-bit form of the self-correcting predictor: WpHeader fields in their coded ranges (5 / 4 bits)
@@ -2685,6 +2722,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             if (int rc = malloc_dev(ctx, f, &m->pred_srcs, std::max<size_t>(srcs.size(), 1) * sizeof(PredSrc))) return rc;
             if (int rc = malloc_dev(ctx, f, &m->pred_flags, std::max<size_t>(waves.size(), 1) * sizeof(uint32_t))) return rc;
             if (int rc = malloc_dev(ctx, f, &m->pred_sink, 1024)) return rc;
+            if (int rc = malloc_dev(ctx, f, &m->pred_queue, 4 * sizeof(uint32_t))) return rc;
             if (!m->axis_leaves.empty()) {
                 if (int rc = malloc_dev(ctx, f, &m->d_axis_leaves, m->axis_leaves.size() * sizeof(JxlGpuMaLeaf))) return rc;
                 HIP_TRY(ctx, hipMemcpy(m->d_axis_leaves, m->axis_leaves.data(), m->axis_leaves.size() * sizeof(JxlGpuMaLeaf), hipMemcpyHostToDevice));
@@ -2757,7 +2795,16 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                         if (!count) return;
                         auto go = [&](auto kern) { kern<<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first); };
                         if (m->pred_d4) {   // static LDS only
-                            auto go4 = [&](auto kern) { kern<<<count, 64, 0, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first); };
+                            // JXLGPU_PRED_PERSIST=W (default 0 = off): 1024 W workgroups take the waves from a queue, longest first
+                            const uint32_t cap = (uint32_t)ctx->tune.pred_persist * 1024u;
+                            uint32_t* q = nullptr;
+                            if (cap && count > cap) {
+                                q = m->pred_queue + (first == 0 ? 0 : (first == m->n_pred_vec_waves ? 1 : (first == m->n_pred_early ? 2 : 3)));
+                                (void)hipMemsetAsync(q, 0, sizeof(uint32_t), st);
+                            }
+                            auto go4 = [&](auto kern) {
+                                kern<<<q ? cap : count, 64, 0, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first, q, count);
+                            };
                             if (i16) { if (vec) go4(predict_lanes_wp4_kernel<int16_t, true>); else go4(predict_lanes_wp4_kernel<int16_t, false>); }
                             else { if (vec) go4(predict_lanes_wp4_kernel<int32_t, true>); else go4(predict_lanes_wp4_kernel<int32_t, false>); }
                             return;
