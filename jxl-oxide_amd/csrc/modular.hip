@@ -1725,7 +1725,7 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
     typedef uint32_t U4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t s_wdiv[4][66];          // ww[i] * DIV_LOOKUP[j]
     __shared__ uint32_t s_div[65];
-    __shared__ R s_out[64][RO + 1];             // finished samples of the lane's rows, slot = step & 15
+    __shared__ R s_out[65][RO + 1];             // finished samples of the lane's rows, slot = step & 15; [64] = zeros
     __shared__ R s_in[64][kRing + 1];           // residuals requested ahead, slot = step & 15
     __shared__ U4 s_se[65][E + 1];              // sub_err[4] of the lane's last four samples, slot = step & 3 (+1: bank spread); [64] = zeros
     __shared__ int32_t s_te[65][E + 1];         // true_err likewise
@@ -1742,6 +1742,7 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
         (&s_se[0][0])[i] = U4{0, 0, 0, 0};
         (&s_te[0][0])[i] = 0;
     }
+    if (lane < RO + 1) s_out[64][lane] = 0;
     __syncthreads();
     // `queue` non-null: the launch has fewer workgroups than waves (a fixed number per SIMD) and each takes the next wave of the
     // list — longest first — when it has finished one: the chains of a frame differ by a factor of 60 in length, and the hardware's
@@ -1839,36 +1840,27 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
                 r0 = r == 0;
                 r_ge2 = r >= 2;
                 row_base = row_ok ? as_global((S*)t.base + (size_t)r * t.stride) : as_global((S*)a.sink);
-                if (r0) {
-                    w3b = n3b = nw3b = B;
-                    te_w = te_n = te_nw = te_ne = 0;
+                // columns 0, 1 and 2 of the row above: written by the previous lane at steps s - 4, s - 3, s - 2; row 0 reads the
+                // rings of zeros instead (no branch: every value below is a load into its register)
+                const R* ps = r0 ? s_out[64] : prev;
+                pse = r0 ? s_se[64] : prev_se;
+                pte = r0 ? s_te[64] : prev_te;
+                const int32_t c0 = ps[(j + 12) & 15];
+                w3b = n3b = nw3b = c0 * 8 + B;
+                te_w = 0;
+                te_n = te_nw = pte[(j + 0) & 3];
+                const U4 e0 = pse[(j + 0) & 3];
+                const U4 e1v = pse[(j + 1) & 3];
+                const int32_t t1 = pte[(j + 1) & 3];
+                const bool one = gw <= 1;
+                te_ne = one ? te_n : t1;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) se_n_w[i] = se_nw_ww[i] = se_ne[i] = 0;
-                    l_te = 0;
-                    l_se = U4{0, 0, 0, 0};
-                    pse = s_se[64];
-                    pte = s_te[64];
-                } else {
-                    // columns 0, 1 and 2 of the row above: written by the previous lane at steps s - 4, s - 3, s - 2
-                    const int32_t c0 = prev[(j + 12) & 15];
-                    w3b = n3b = nw3b = c0 * 8 + B;
-                    te_w = 0;
-                    te_n = te_nw = prev_te[(j + 0) & 3];
-                    const U4 e0 = prev_se[(j + 0) & 3];
-                    const U4 e1v = prev_se[(j + 1) & 3];
-                    const int32_t t1 = prev_te[(j + 1) & 3];
-                    const bool one = gw <= 1;
-                    te_ne = one ? te_n : t1;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        se_n_w[i] = se_nw_ww[i] = e0[i];
-                        se_ne[i] = one ? e0[i] : e1v[i];
-                    }
-                    l_te = prev_te[(j + 2) & 3];
-                    l_se = prev_se[(j + 2) & 3];
-                    pse = prev_se;
-                    pte = prev_te;
+                for (int i = 0; i < 4; ++i) {
+                    se_n_w[i] = se_nw_ww[i] = e0[i];
+                    se_ne[i] = one ? e0[i] : e1v[i];
                 }
+                l_te = pte[(j + 2) & 3];
+                l_se = pse[(j + 2) & 3];
             }
             // ---- requests for step s + 1 (NE sample: written at s - 2; NN: at s - 7; errors two columns ahead of it: at s - 1)
             nx_res = my_in[(j + 1) & 15];
