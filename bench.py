@@ -150,7 +150,7 @@ def main():
         band_sharded = args.config == 5 and world > 1
         mine = list(range(n_total)) if band_sharded else list(shard.frame_shard(n_total, rank, world))
         wls = {d: job["make"](d) for d in sorted({i % args.distinct for i in mine})}  # untimed
-        # a job may ask for frames to alternate between several contexts (config 3 with JXLGPU_BENCH_CONTEXTS > 1, an experiment: each context
+        # a job may ask for frames to alternate between several contexts (config 3: JXLGPU_BENCH_CONTEXTS, default 3: each context
         # has its own streams, so consecutive frames overlap; the reference's caller pattern of one renderer per thread,
         # jxl-oxide-cli/src/decode.rs:293-304, driven from this one thread because every call is asynchronous)
         ctxs = [ctx] + [runtime.Context(local_rank) for _ in range(max(1, int(job.get("contexts", 1))) - 1)]
@@ -613,21 +613,23 @@ def make_job(config, distinct, transport="grouped", nz=0.15):
                 "against": "oracle/, whole 7680x4320 frame (integer Squeeze inverse + float tail)"}
 
     def render(ctx, frames):
-        for f in frames:   # (frames alternate between two contexts: `contexts` below)
+        for f in frames:   # (frames alternate between the job's contexts: `contexts` below)
             f.ctx.modular_render(f, stages, to_host=False)
 
     return {
         "metric": "Megapixels/sec decoded (8K Modular Squeeze lossy)", "dtype": "int16", "batched": False,
         "workload": "7680x4320 Modular, lossy Squeeze (22 steps) + self-correcting-predictor residuals (single-leaf MA tree) on the 67 carved "
                     "sub-channels, 16-bit buffers, XYB dequant + EPF iters 2 (sigma_for_modular) + XYB->sRGB (BASELINE config 3); whole frames, "
-                    "one render call each, one after the other",
+                    "one render call each, the frames of a step alternating between the job's contexts (JXLGPU_BENCH_CONTEXTS, default 3)",
         "out_w": W8K, "out_h": H8K,
         "make": lambda d: ModularWorkload(W8K, H8K, kind="squeeze", lossy=True, i16=True, epf_iters=2, seed=3 + d, residual=6),
         "upload": lambda ctx, wl: ctx.modular_upload(wl.desc()),
-        # JXLGPU_BENCH_CONTEXTS=2 / 3: frames alternate between that many contexts (own streams each), so that the predictor pass of one frame
-        # overlaps the Squeeze / filter launches of another.  Measured (round 6, 8 frames per step): 14.0-14.1 / 15.7 against 15.2-15.3 GP/s
-        # with one context — the predictor's serial chains stretch by what the other frame's launches issue: not the default
-        "contexts": int(os.environ.get("JXLGPU_BENCH_CONTEXTS", "1")),
+        # Frames alternate between JXLGPU_BENCH_CONTEXTS contexts (own streams each: one renderer per thread is the reference's caller
+        # pattern, jxl-oxide-cli/src/decode.rs:293-304), so that the predictor pass of one frame — VALU issue, no memory — overlaps the
+        # HBM-bound Squeeze / filter launches of others.  Round 6, 8-12 frames per step: 16.5-16.7 GP/s with one context, 16.3 with two
+        # (the two frames stay in lockstep), 18.9-19.6 with three, 18.6-18.7 four, 19.8 five, 19.3-19.7 six / eight
+        # (profiles/r06_predictor_experiments.txt).  With the round-3 predictor step the same spread gave 15.2 / 14.0 / 15.7.
+        "contexts": int(os.environ.get("JXLGPU_BENCH_CONTEXTS", "3")),
         "render": render, "groups": (3, 2),
         "group_names": {3: "modular: predict_kernel (per carved sub-channel) + inverse Squeeze (segment-parallel kernels)", 2: "post: to_float + EPF + XYB->sRGB"},
         "alg_bytes": lambda f, g: W8K * H8K * (6 + 12),  # 3 x i16 in + 3 x f32 out per pixel
