@@ -1915,7 +1915,7 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
             // range guard: the largest excursion of the group of four steps, looked at where the group ends (VEC: a lane is on the grid for
             // all four steps of a group or none); 16-bit samples cannot leave the sample range
             uint32_t exc = (uint32_t)true_err + (1u << 19);
-            if constexpr (sizeof(S) == 4) exc = max(exc, ((uint32_t)sample + (1u << 17)) << 2);
+            if constexpr (sizeof(S) == 4) exc = max(exc, (uint32_t)sample + (1u << 17) >= (1u << 18) ? (1u << 20) : 0u);
             if constexpr (VEC) {
                 worst = (j & 3) == 0 ? exc : max(worst, exc);
                 if ((j & 3) == 3) out_of_range |= on && worst >= (1u << 20);
