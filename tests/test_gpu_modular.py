@@ -192,6 +192,21 @@ print("NARROW_OK")
         assert sum(redone) > 0, "the test did not exercise the 64-bit redo"
 
 
+@pytest.mark.parametrize("first", [1 << 18, 1 << 30, -(1 << 30), (1 << 31) - 1])
+def test_self_correcting_predictor_large_flat_samples(gpu_ctx, oracle, first):
+    """Samples far outside the 32-bit form's range with SMALL prediction errors (one large first residual, then a flat image): the
+    range guard has to look at the sample itself — 8 * sample does not fit — and must not lose a large value to its own
+    arithmetic (2^30 + 2^17, shifted left by two, is back in range)."""
+    wl = ModularWorkload(300, 270, kind="predictor", predictor=1, i16=False, seed=2)
+    rng = np.random.default_rng(7)
+    wl.buffers = [rng.integers(-3, 4, size=(270, 300)).astype(np.int32) for _ in range(3)]
+    for b in wl.buffers:
+        b[0, 0] = first
+    wl.residual_predictor, wl.residual_multiplier, wl.residual_offset = 6, 1, 0
+    wl.expected = None
+    _inverse_both(gpu_ctx, oracle, wl)
+
+
 def test_workgroup_per_subgrid_kernel_still_matches(oracle, monkeypatch):
     """JXLGPU_PRED_WG routes every subgrid through the workgroup-per-subgrid kernel (the form that serves subgrids
     wider than 512 columns)."""
