@@ -580,8 +580,6 @@ int jxlgpu_create(int device, jxlgpu_ctx** out_ctx) {
     if (const char* v = getenv("JXLGPU_SQZ_RUNIN")) ctx->tune.sqz_runin = (uint32_t)atoi(v);
     ctx->tune.pred_wg = getenv("JXLGPU_PRED_WG") != nullptr;
     if (const char* v = getenv("JXLGPU_PRED_PRIO")) ctx->tune.pred_prio = atoi(v) != 0;
-    if (const char* v = getenv("JXLGPU_PRED_SNAKE")) ctx->tune.pred_snake = std::max(0, atoi(v));
-    if (const char* v = getenv("JXLGPU_PRED_PERSIST")) ctx->tune.pred_persist = std::min(8, std::max(0, atoi(v)));
     ctx->tune.pred_wide = getenv("JXLGPU_PRED_WIDE") != nullptr;
     if (const char* v = getenv("JXLGPU_PRED_STEP_V1")) ctx->tune.pred_step_v1 = atoi(v) != 0;
     if (const char* v = getenv("JXLGPU_PRED_LATE_STEPS")) ctx->tune.pred_late_steps = std::max(0, atoi(v));

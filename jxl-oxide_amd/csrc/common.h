@@ -271,8 +271,6 @@ struct Tuning {
     bool pred_step_v1 = false;   // JXLGPU_PRED_STEP_V1=1: the round-3 step (x-indexed error rows, position-indexed rings) also where every wave has D = 4
     int pred_late_steps = 3;     // JXLGPU_PRED_LATE_STEPS: residuals of the first so many (forward) Squeeze steps get their predictor waves on a
                                  // side stream, beside the deep Squeeze levels; the inverse step that reads them waits (0: everything in front)
-    int pred_persist = 0;        // JXLGPU_PRED_PERSIST=W (round 6, measured, not adopted: 16.4-16.8 against 16.6 GP/s): the D = 4 predictor pass as 1024 W workgroups over a queue of waves (0: one workgroup per wave)
-    int pred_snake = 0;          // JXLGPU_PRED_SNAKE=N (round 6 experiment): launch order of the predictor waves, see modular.hip
     bool pred_prio = false;      // JXLGPU_PRED_PRIO=1 (round 6, measured, not adopted): issue priority by chain length in the narrow predictor kernel
                                  // (s_setprio 3 .. 0 for the longest quarter .. the short waves).  Config 3: 14.1-14.2 against 15.2-15.3 GP/s — the waves
                                  // of the misaligned subgrids on the side stream (no priority of their own) take 0.48 instead of 0.30 ms

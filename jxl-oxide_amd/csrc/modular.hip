@@ -1717,7 +1717,7 @@ __device__ __forceinline__ int32_t mad_i24(int32_t a, int32_t b, int32_t c) {
 
 template <typename S, bool VEC>
 __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const PredWave* waves, const PredSrc* srcs,
-                                                               uint32_t* wave_flags, uint32_t* queue, uint32_t n_items) {
+                                                               uint32_t* wave_flags) {
     constexpr int RO = kRing, E = 4;
     constexpr int32_t B = 1 << 23;
     static_assert(RO == 16, "the step loop is unrolled by the ring length");
@@ -1744,16 +1744,7 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
     }
     if (lane < RO + 1) s_out[64][lane] = 0;
     __syncthreads();
-    // `queue` non-null: the launch has fewer workgroups than waves (a fixed number per SIMD) and each takes the next wave of the
-    // list — longest first — when it has finished one: the chains of a frame differ by a factor of 60 in length, and the hardware's
-    // placement of one workgroup per wave leaves half of the SIMDs with twice the work of the others.  Nothing in LDS has to be
-    // reset between waves: whatever a valid lane reads was written earlier in the same wave (the ring of zeros is never written).
-    auto next_item = [&]() -> uint32_t {
-        uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(queue, 1u);
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-    };
-    for (uint32_t item = queue ? next_item() : blockIdx.x; item < n_items; item = queue ? next_item() : n_items) {
+    const uint32_t item = blockIdx.x;
     const PredWave wv = waves[item];
     switch (__builtin_amdgcn_readfirstlane((int)wv.pad[1])) {   // JXLGPU_PRED_PRIO (see predict_lanes_narrow_kernel)
         case 3: __builtin_amdgcn_s_setprio(3); break;
@@ -1959,11 +1950,9 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
         }
         if (__builtin_amdgcn_ballot_w64(out_of_range) != 0) {
             if (lane == 0) wave_flags[item] = 1;
-            break;
+            return;
         }
     }
-    lds_step_boundary();
-    }   // next wave of the list
 }
 
 // ---------------------------------------------------------------- device: M3, delta-palette predictor pass
@@ -2301,7 +2290,6 @@ struct ModularState {
     std::vector<JxlGpuMaLeaf> unit_leaves;   // copy of JxlGpuModularDesc::unit_leaves (empty: the frame's one leaf)
     std::vector<JxlGpuMaLeaf> axis_leaves;   // copy of JxlGpuModularDesc::axis_leaves (per-row / per-column leaves of the units marked BY_ROW / BY_COLUMN)
     JxlGpuMaLeaf* d_axis_leaves = nullptr;   // ... on the device
-    uint32_t* pred_queue = nullptr;   // four counters: the wave queues of the (early / late) x (four-sample / one-sample) launches
     bool pred_d4 = false;         // every wave of the lane-packed pass has D = 4 (no subgrid wider than 256 columns): predict_lanes_wp4_kernel
     bool pred_big_ring = false;   // a subgrid wider than 512 columns: rows trail by D = 16, the lane kernels with the 64-column sample ring
     float* fpix[3] = {};
@@ -2666,19 +2654,6 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 if (x.vec != y.vec) return x.vec > y.vec;
                 return x.steps > y.steps;
             });
-            if (ctx->tune.pred_snake) {
-                // experiment (JXLGPU_PRED_SNAKE=N): inside a launch, every other run of N waves in ascending order — if workgroup i and
-                // workgroup i + N land on the same SIMD, the longest chain shares it with the shortest
-                const size_t N = (size_t)ctx->tune.pred_snake;
-                size_t b = 0;
-                while (b < waves.size()) {
-                    size_t e = b;
-                    while (e < waves.size() && waves[e].pad[0] == waves[b].pad[0] && waves[e].vec == waves[b].vec) ++e;
-                    for (size_t r = b + N, odd = 1; r < e; r += N, odd ^= 1)
-                        if (odd) std::reverse(waves.begin() + r, waves.begin() + std::min(e, r + N));
-                    b = e;
-                }
-            }
             {   // issue priority by chain length (predict_lanes_narrow_kernel): the longest quarter 3, then 2, 1, 0
                 uint32_t max_steps = 1;
                 for (const PredWave& w : waves) max_steps = std::max(max_steps, w.steps);
@@ -2714,7 +2689,6 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             if (int rc = malloc_dev(ctx, f, &m->pred_srcs, std::max<size_t>(srcs.size(), 1) * sizeof(PredSrc))) return rc;
             if (int rc = malloc_dev(ctx, f, &m->pred_flags, std::max<size_t>(waves.size(), 1) * sizeof(uint32_t))) return rc;
             if (int rc = malloc_dev(ctx, f, &m->pred_sink, 1024)) return rc;
-            if (int rc = malloc_dev(ctx, f, &m->pred_queue, 4 * sizeof(uint32_t))) return rc;
             if (!m->axis_leaves.empty()) {
                 if (int rc = malloc_dev(ctx, f, &m->d_axis_leaves, m->axis_leaves.size() * sizeof(JxlGpuMaLeaf))) return rc;
                 HIP_TRY(ctx, hipMemcpy(m->d_axis_leaves, m->axis_leaves.data(), m->axis_leaves.size() * sizeof(JxlGpuMaLeaf), hipMemcpyHostToDevice));
@@ -2787,16 +2761,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                         if (!count) return;
                         auto go = [&](auto kern) { kern<<<count, 64, lds, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first); };
                         if (m->pred_d4) {   // static LDS only
-                            // JXLGPU_PRED_PERSIST=W (default 0 = off): 1024 W workgroups take the waves from a queue, longest first
-                            const uint32_t cap = (uint32_t)ctx->tune.pred_persist * 1024u;
-                            uint32_t* q = nullptr;
-                            if (cap && count > cap) {
-                                q = m->pred_queue + (first == 0 ? 0 : (first == m->n_pred_vec_waves ? 1 : (first == m->n_pred_early ? 2 : 3)));
-                                (void)hipMemsetAsync(q, 0, sizeof(uint32_t), st);
-                            }
-                            auto go4 = [&](auto kern) {
-                                kern<<<q ? cap : count, 64, 0, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first, q, count);
-                            };
+                            auto go4 = [&](auto kern) { kern<<<count, 64, 0, st>>>(pa, m->pred_waves + first, m->pred_srcs, m->pred_flags + first); };
                             if (i16) { if (vec) go4(predict_lanes_wp4_kernel<int16_t, true>); else go4(predict_lanes_wp4_kernel<int16_t, false>); }
                             else { if (vec) go4(predict_lanes_wp4_kernel<int32_t, true>); else go4(predict_lanes_wp4_kernel<int32_t, false>); }
                             return;
