@@ -1,5 +1,5 @@
 """A CPU model of the SCHEDULE of the lane-packed predictor kernels (csrc/modular.hip, predict_lanes_kernel /
-predict_lanes_narrow_kernel): which lane produces which sample at which step, which LDS ring slot it lands in, and which
+predict_lanes_narrow_kernel; at the end of the file predict_lanes_wp4_kernel, whose rings are indexed by the step): which lane produces which sample at which step, which LDS ring slot it lands in, and which
 slots the rows below read — checked for every read against what the ring holds at that moment.  It pins the three sizing rules
 the host code applies (run_inverse, "M4"):
 
@@ -151,3 +151,110 @@ def test_error_row_width_rule():
             p, _ = plan(gw)
             assert w * p // 64 >= gw, (widths, gw, w)
         assert w == lane_err_w(list(reversed(widths)))
+
+
+# ---------------------------------------------------------------- predict_lanes_wp4_kernel (round 6): D = 4, rings indexed by the STEP
+def simulate_wp4(gw, gh, sample_ring=16, err_ring=4):
+    """The D = 4 form of the self-correcting predictor step.  A lane writes its sample into slot s & 15 of its own ring and its
+    error record into slot s & 3, whatever its stream position; what the row below needs was written at a step that does not
+    depend on the lane: NE (column x + 1) at s + 1 - D, NN at s - 2 D, the errors of column x + 2 at s + 2 - D — also across the
+    wrap from lane 0 to lane P - 1 of the round before.  Everything is requested one step before it is used (into
+    registers); a row start (only at steps that are multiples of 4) reads columns 0, 1, 2 of the row above in place.  Row 0
+    reads a ring of zeros (not modelled: it has nothing to check).  Statement order of a step, as in the kernel: park
+    residuals, row-start reads, requests for step s + 1, [arithmetic], writes."""
+    P, DP = plan(gw)
+    D = DP // P
+    assert D == 4, "the kernel serves launches in which every wave has D = 4"
+    log2dp = DP.bit_length() - 1
+    s_out = [[None] * sample_ring for _ in range(P)]
+    s_err = [[None] * err_ring for _ in range(P)]
+    s_in = [[None] * 16 for _ in range(P)]
+    nx = [dict(res=None, pne=None, pnn=None, err=None) for _ in range(P)]     # registers: requested at the previous step
+    use_prev_err = [False] * P                                                  # pse / pte: the previous lane's ring (True) or the zeros
+    produced = set()
+    steps = gw + D * (gh - 1)
+
+    def where(k, q):
+        if q < 0:
+            return None
+        r, x = k + (q >> log2dp) * P, q & (DP - 1)
+        return (r, x) if r < gh and x < gw else None
+
+    for s0 in range(-16, steps, 16):
+        for j in range(16):
+            s = s0 + j
+            cur = [dict(n) for n in nx]
+            # 1. residuals: four at a time at every fourth step (positions u + 8 .. u + 11 of every lane)
+            if j % 4 == 0:
+                for k in range(P):
+                    u = s - D * k
+                    for i in range(4):
+                        s_in[k][(j + 8 + i) & 15] = where(k, u + 8 + i)
+            # 2. row starts: columns 0, 1, 2 of the row above, in place
+            for k in range(P):
+                u = s - D * k
+                here = where(k, u)
+                x = u & (DP - 1)
+                if j % 4 == 0 and x == 0:
+                    r = k + (u >> log2dp) * P if u >= 0 else None
+                    use_prev_err[k] = bool(r)      # row 0 (and positions before the first row): the zeros
+                    if here is not None and r >= 1:
+                        kp = (k - 1) % P
+                        assert s_out[kp][(j + 12) % sample_ring] == (r - 1, 0), f"wp4 gw {gw} gh {gh}: N of column 0 at step {s}"
+                        assert s_err[kp][(j + 0) % err_ring] == (r - 1, 0), f"wp4 gw {gw} gh {gh}: errors of column 0 at step {s}"
+                        if gw > 1:
+                            assert s_err[kp][(j + 1) % err_ring] == (r - 1, 1), f"wp4 gw {gw} gh {gh}: errors of column 1 at step {s}"
+                        if gw > 2:
+                            assert s_err[kp][(j + 2) % err_ring] == (r - 1, 2), f"wp4 gw {gw} gh {gh}: errors of column 2 at step {s}"
+                            cur[k]["err"] = s_err[kp][(j + 2) % err_ring]
+            # 3. requests for step s + 1
+            ahead = 1
+            for k in range(P):
+                kp, kpp = (k - 1) % P, (k - 2) % P
+                nx[k] = dict(res=s_in[k][(j + ahead) & 15],
+                             pne=s_out[kp][(j + ahead + 1 - D) % sample_ring],
+                             pnn=s_out[kpp][(j + ahead - 2 * D) % sample_ring],
+                             err=s_err[kp][(j + ahead + 2 - D) % err_ring] if use_prev_err[k] else None)
+            # 4. what the arithmetic of this step consumes
+            tags = []
+            for k in range(P):
+                u = s - D * k
+                here = where(k, u)
+                tags.append(here)
+                if here is None:
+                    continue
+                r, x = here
+                assert cur[k]["res"] == (r, x), f"wp4 gw {gw} gh {gh}: residual of {(r, x)} at step {s}: {cur[k]['res']}"
+                if r >= 1 and x + 1 < gw:
+                    assert cur[k]["pne"] == (r - 1, x + 1), f"wp4 gw {gw} gh {gh}: NE of {(r, x)}: {cur[k]['pne']}"
+                if r >= 2:
+                    assert cur[k]["pnn"] == (r - 2, x), f"wp4 gw {gw} gh {gh}: NN of {(r, x)}: {cur[k]['pnn']}"
+                if r >= 1 and x + 2 < gw:
+                    assert cur[k]["err"] == (r - 1, x + 2), f"wp4 gw {gw} gh {gh}: errors two columns ahead of {(r, x)}: {cur[k]['err']}"
+                produced.add(here)
+            # 5. writes (unconditional: an off-grid lane writes garbage)
+            for k in range(P):
+                s_out[k][j % sample_ring] = tags[k]
+                s_err[k][j % err_ring] = tags[k]
+    assert len(produced) == gw * gh, f"wp4 gw {gw} gh {gh}: {len(produced)} of {gw * gh} samples produced"
+
+
+@pytest.mark.parametrize("gw", [w for w in _WIDTHS if w <= 256])
+def test_step_indexed_rings_hold_what_the_rows_below_read(gw):
+    P, DP = plan(gw)
+    assert DP == 4 * P
+    for gh in sorted({1, 2, 3, 4, P - 1, P, P + 1, 2 * P + 1, 3 * P, 5 * P + 2} - {0, -1}):
+        if gw * gh > 120_000:
+            continue
+        simulate_wp4(gw, gh)
+
+
+def test_the_step_indexed_model_sees_its_own_limits():
+    """Four error slots are exactly enough (a row start reads the slot that this step's write is about to take: reads come
+    first); two or three are not.  The sample ring needs eight columns (NN: written 8 steps earlier, requested 7 steps
+    later); the kernel has 16, the unroll length of its step loop; four lose NN."""
+    simulate_wp4(100, 40)
+    simulate_wp4(100, 40, sample_ring=8)
+    for kw in (dict(err_ring=2), dict(err_ring=3), dict(sample_ring=4)):
+        with pytest.raises(AssertionError):
+            simulate_wp4(100, 40, **kw)
