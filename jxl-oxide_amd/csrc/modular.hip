@@ -1436,7 +1436,8 @@ __global__ __launch_bounds__(64) void predict_lanes_kernel(PredArgs a, const Pre
     }
 }
 
-// ---- the self-correcting predictor in 32-bit arithmetic (the default for predictor 6 in the lane-packed form).
+// ---- the self-correcting predictor in 32-bit arithmetic (predictor 6 in the lane-packed form; since round 6 for launches with a wave of
+// D > 4 only — subgrids wider than 256 columns, group_dim 512 / 1024 — and under JXLGPU_PRED_STEP_V1: predict_lanes_wp4_kernel below serves the rest).
 // The reference computes in i64 (predictor.rs:312-441) and the kernels above follow it: 20 v_mad_u64_u32, 40
 // carry pairs and a dozen 64-bit compares per sample, most of the ~320 instructions of a step.  With
 // |sample| < 2^17, |true_err| < 2^19 and the WpHeader fields in their coded ranges (p1, p2, p3a-e < 32,
