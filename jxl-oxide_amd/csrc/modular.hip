@@ -1472,7 +1472,7 @@ __global__ __launch_bounds__(64) void predict_lanes_narrow_kernel(PredArgs a, co
     // latency stretches with every other wave that shares the SIMD's issue slots.  The host ranks the waves by length
     // (PredWave::pad[1]): the long ones issue ahead of the short ones, which have slack — JXLGPU_PRED_PRIO=1, an experiment of round 6 that
     // LOST 7 % on config 3 (Tuning::pred_prio): off by default, pad[1] is 0.
-    switch (__builtin_amdgcn_readfirstlane((int)wv.pad[1])) {
+    switch (__builtin_amdgcn_readfirstlane((int)(wv.pad[1] & 3u))) {
         case 3: __builtin_amdgcn_s_setprio(3); break;
         case 2: __builtin_amdgcn_s_setprio(2); break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -1747,7 +1747,7 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
     __syncthreads();
     const uint32_t item = blockIdx.x;
     const PredWave wv = waves[item];
-    switch (__builtin_amdgcn_readfirstlane((int)wv.pad[1])) {   // JXLGPU_PRED_PRIO (see predict_lanes_narrow_kernel)
+    switch (__builtin_amdgcn_readfirstlane((int)(wv.pad[1] & 3u))) {   // JXLGPU_PRED_PRIO (see predict_lanes_narrow_kernel); bit 8: all16, below
         case 3: __builtin_amdgcn_s_setprio(3); break;
         case 2: __builtin_amdgcn_s_setprio(2); break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -1788,10 +1788,12 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
     typedef uint32_t RawV4 __attribute__((ext_vector_type(4)));
     using V4 = typename std::conditional<sizeof(S) == 2, RawV2, RawV4>::type;
     union Pack4 { V4 v; S s[4]; };
-    Pack4 pfv[2], sbuf;
+    Pack4 pfv[2], packs[4];
     pfv[0].v = pfv[1].v = V4{};
-    sbuf.v = V4{};
-    const int32_t steps = (int32_t)wv.steps;
+    packs[0].v = packs[1].v = packs[2].v = packs[3].v = V4{};
+    const bool all16 = __builtin_amdgcn_readfirstlane((int)(wv.pad[1] >> 8)) != 0;
+    // (a subgrid whose width is not a multiple of 16 stores its last block up to 12 steps after its last sample)
+    const int32_t steps = (int32_t)wv.steps + (VEC && !all16 ? 12 : 0);
     const int32_t u0 = -4 * (int32_t)k;
     auto where = [&](int32_t q, uint32_t* r, uint32_t* x) -> bool {
         *r = k + (((uint32_t)q >> log2dp) << log2p);
@@ -1937,11 +1939,29 @@ __global__ __launch_bounds__(64) void predict_lanes_wp4_kernel(PredArgs a, const
             n3b = r0 ? s8b : pne3b;
 
             if constexpr (VEC) {
-                sbuf.s[j & 3] = value;
+                // Samples leave SIXTEEN at a time: a lane keeps the four groups of its current 16-column block (packs[g], g = the group
+                // of the unrolled loop that wrote it) and stores them back to back when the block ends, i.e. at the end of the group in
+                // which its column is 15 (mod 16) — a different one of the four for lanes k, k + 1, k + 2, k + 3.  With one 8-byte
+                // store per lane per group, 64 lanes = 64 rows = 64 cache lines per instruction, each line took 16 visits 4 steps
+                // apart and L2 wrote a partial sector out for nearly every one: WRITE_SIZE 890 MB for the 200 MB of an 8K frame
+                // (profiles/r06_cfg3_pmc.txt).  Groups past the subgrid's last column, and lanes between rows, store to the sink.
+                packs[(j >> 2) & 3].s[j & 3] = value;
                 if ((j & 3) == 3) {
-                    // columns x - 3 .. x of one row (or the sink: a lane is on the grid for all four steps of a group or none)
-                    const GlobalPtr<S> g4 = on ? row_base + (x - 3) : as_global((S*)a.sink + lane * 4);
-                    *reinterpret_cast<GlobalPtr<V4>>(g4) = sbuf.v;
+                    const int g = (j >> 2) & 3;   // (a constant of the unrolled loop)
+                    const int32_t x0 = x - 15;
+                    const bool block_ends = row_ok && (x & 12) == 12 && x0 < gw;
+                    const GlobalPtr<S> sink = as_global((S*)a.sink + lane * 4);
+                    if (all16) {   // (wave-uniform) every subgrid of the wave is a multiple of 16 columns wide: one test for the four groups
+                        const GlobalPtr<S> b16 = block_ends ? row_base + x0 : sink;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) *reinterpret_cast<GlobalPtr<V4>>(b16 + 4 * q) = packs[(g + 1 + q) & 3].v;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const GlobalPtr<S> b4 = (block_ends && x0 + 4 * q < gw) ? row_base + (x0 + 4 * q) : sink;
+                            *reinterpret_cast<GlobalPtr<V4>>(b4) = packs[(g + 1 + q) & 3].v;
+                        }
+                    }
                 }
             } else {
                 const GlobalPtr<S> g1 = on ? row_base + x : as_global((S*)a.sink + lane * 4 + 3);
@@ -2278,7 +2298,7 @@ struct ModularState {
     PredWave* pred_waves = nullptr;            // lane-packed launch: one entry per wave
     PredSrc* pred_srcs = nullptr;              // per subgrid: its residuals in the read-only upload
     uint32_t* pred_flags = nullptr;            // per wave: left the 32-bit range (redone by the 64-bit kernel)
-    void* pred_sink = nullptr;                 // 1 KB nobody reads: where off-grid lanes store
+    void* pred_sink = nullptr;                 // 4 KB nobody reads: where off-grid lanes store
     uint32_t n_pred_vec_waves = 0;             // the first so many waves take four-sample accesses
     // "late" subgrids: residuals of the first JXLGPU_PRED_LATE_STEPS forward Squeeze steps (the top levels: half / three
     // quarters of the samples), consumed by the LAST inverse steps — their predictor waves run on a side stream beside the
@@ -2614,7 +2634,8 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             // four-sample accesses: both copies of the subgrid aligned to four samples, rows too, width a multiple of four
             auto vec_of = [&](const PredTile& t) {
                 const uintptr_t al = 4 * esz;
-                return t.predictor < JXLGPU_LEAF_BY_ROW && (uintptr_t)t.base % al == 0 && (uintptr_t)tile_src[t.base] % al == 0 && t.stride % 4 == 0 && t.gw % 4 == 0;
+                return t.predictor < JXLGPU_LEAF_BY_ROW && (uintptr_t)t.base % al == 0 && (uintptr_t)tile_src[t.base] % al == 0 && t.stride % 4 == 0 && t.gw % 4 == 0 &&
+                       dp_of(t) >= 16;   // (a lane's 16-column blocks end inside a round: predict_lanes_wp4_kernel)
             };
             // wide subgrids first (own launch), then the lane-packed ones by (vec, P, DP), longest chains first inside a class
             std::stable_sort(tiles.begin(), tiles.end(), [&](const PredTile& x, const PredTile& y) {
@@ -2661,6 +2682,12 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
                 const bool on = ctx->tune.pred_prio;
                 for (PredWave& w : waves)
                     w.pad[1] = !on ? 0u : (w.steps * 4 >= max_steps * 3 ? 3u : (w.steps * 2 >= max_steps ? 2u : (w.steps * 4 >= max_steps ? 1u : 0u)));
+                // bit 8: every subgrid of the wave is a multiple of 16 columns wide (predict_lanes_wp4_kernel's 16-sample stores)
+                for (PredWave& w : waves) {
+                    bool all16 = true;
+                    for (uint32_t q = 0; q < w.count; ++q) all16 &= tiles[w.first + q].gw % 16 == 0;
+                    w.pad[1] |= all16 ? 0x100u : 0u;
+                }
             }
             m->n_pred_vec_waves = m->n_pred_early = m->n_pred_late_vec = 0;
             for (const PredWave& w : waves) {
@@ -2689,7 +2716,7 @@ int run_inverse(jxlgpu_ctx* ctx, jxlgpu_frame* f) {
             if (int rc = malloc_dev(ctx, f, &m->pred_waves, std::max<size_t>(waves.size(), 1) * sizeof(PredWave))) return rc;
             if (int rc = malloc_dev(ctx, f, &m->pred_srcs, std::max<size_t>(srcs.size(), 1) * sizeof(PredSrc))) return rc;
             if (int rc = malloc_dev(ctx, f, &m->pred_flags, std::max<size_t>(waves.size(), 1) * sizeof(uint32_t))) return rc;
-            if (int rc = malloc_dev(ctx, f, &m->pred_sink, 1024)) return rc;
+            if (int rc = malloc_dev(ctx, f, &m->pred_sink, 4096)) return rc;   // 64 lanes x (4 + 12) samples of up to 4 bytes
             if (!m->axis_leaves.empty()) {
                 if (int rc = malloc_dev(ctx, f, &m->d_axis_leaves, m->axis_leaves.size() * sizeof(JxlGpuMaLeaf))) return rc;
                 HIP_TRY(ctx, hipMemcpy(m->d_axis_leaves, m->axis_leaves.data(), m->axis_leaves.size() * sizeof(JxlGpuMaLeaf), hipMemcpyHostToDevice));
