@@ -258,3 +258,49 @@ def test_the_step_indexed_model_sees_its_own_limits():
     for kw in (dict(err_ring=2), dict(err_ring=3), dict(sample_ring=4)):
         with pytest.raises(AssertionError):
             simulate_wp4(100, 40, **kw)
+
+
+def simulate_wp4_stores(gw, gh):
+    """The four-sample path's stores: a lane keeps the four groups of its current 16-column block (packs[g], g = group of the
+    16 x unrolled loop) and stores them when its column is 15 (mod 16); groups past the subgrid's width go to the sink; a wave
+    with a width that is not a multiple of 16 runs 12 steps longer (its last block ends after its last sample).  Every sample
+    must reach memory exactly once, at its own (row, column)."""
+    P, DP = plan(gw)
+    assert DP == 4 * P and DP >= 16 and gw % 4 == 0
+    log2dp = DP.bit_length() - 1
+    all16 = gw % 16 == 0
+    steps = gw + 4 * (gh - 1) + (0 if all16 else 12)
+    packs = [[[None] * 4 for _ in range(4)] for _ in range(P)]
+    row_ok, row = [False] * P, [None] * P
+    stored = {}
+    for s0 in range(-16, steps, 16):
+        for j in range(16):
+            s = s0 + j
+            for k in range(P):
+                u = s - 4 * k
+                x = u & (DP - 1)
+                if j % 4 == 0 and x == 0:
+                    r = k + (u >> log2dp) * P if u >= 0 else None
+                    row_ok[k] = r is not None and r < gh
+                    row[k] = r
+                on = row_ok[k] and x < gw
+                packs[k][(j >> 2) & 3][j & 3] = (row[k], x) if on else None
+                if j % 4 == 3:
+                    g, x0 = (j >> 2) & 3, x - 15
+                    if row_ok[k] and (x & 12) == 12 and x0 < gw:
+                        for q in range(4):
+                            if x0 + 4 * q < gw:
+                                for i, tag in enumerate(packs[k][(g + 1 + q) & 3]):
+                                    want = (row[k], x0 + 4 * q + i)
+                                    assert tag == want, f"stores gw {gw} gh {gh}: {tag} stored at {want}"
+                                    assert want not in stored, f"stores gw {gw} gh {gh}: {want} stored twice"
+                                    stored[want] = s
+    assert len(stored) == gw * gh, f"stores gw {gw} gh {gh}: {len(stored)} of {gw * gh} samples stored"
+
+
+@pytest.mark.parametrize("gw", [12, 16, 20, 32, 44, 64, 72, 120, 128, 200, 256])
+def test_sixteen_sample_blocks_reach_memory_once(gw):
+    P, _ = plan(gw)
+    for gh in sorted({1, 2, 3, P - 1, P, P + 1, 2 * P + 1, 3 * P + 2} - {0}):
+        if gw * gh <= 120_000:
+            simulate_wp4_stores(gw, gh)
